@@ -1,0 +1,128 @@
+/*
+ * hodor_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the NTT / LDE / Merkle-commit / FRI-commit hot path of
+ * matter-labs/hodor.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may link or call this; the product path (hodor_amd/csrc,
+ * libhodor_gpu.so) never does and fails loudly without a GPU.
+ *
+ * PARITY STATUS: **parity unpinned against the Rust binary.**  The reference is a
+ * Rust crate (no rustc/cargo in this image -> unbuildable here, no oracle/_ref) and
+ * none of its own tests holds a known-answer vector for this path (all are
+ * differential).  The arithmetic lives in un-vendored crates:
+ * ff_ce "0.7" (Montgomery Fr, R = 2^256 for 4-limb fields) and blake2s_simd "0.5"
+ * (RFC 7693).  This restatement is pinned instead against
+ *   (i)  Python big-int mathematics (oracle/pyref.py) and SURVEY.md Appendix A/B values,
+ *   (ii) hashlib.blake2s(key=..., person=...) as an independent RFC 7693 implementation,
+ *   (iii) the reference's own differential identities restated as tests (tests/).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).
+ */
+#ifndef HODOR_ORACLE_H
+#define HODOR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Fr(FrRepr([u64;4])) — Montgomery form, little-endian limbs (src/bn256.rs:4-7, ff_ce derive). */
+typedef struct { uint64_t l[4]; } ofr;
+
+typedef struct {
+    uint64_t p[4];        /* modulus */
+    uint64_t pinv;        /* -p^{-1} mod 2^64 */
+    ofr r;                /* R mod p   (== Fr::one()) */
+    ofr r2;               /* R^2 mod p */
+    ofr generator;        /* multiplicative_generator(), Montgomery */
+    ofr root_of_unity;    /* generator^t, p-1 = 2^S * t, Montgomery */
+    uint32_t s;           /* F::S */
+    uint32_t num_bits;    /* F::NUM_BITS */
+    uint32_t capacity;    /* F::CAPACITY = NUM_BITS - 1 */
+} ofield;
+
+/* ---- field (ff_ce PrimeField semantics) ---- */
+int  ofield_init(ofield *f, const uint64_t modulus[4], uint64_t generator);
+void ofr_add(const ofield *f, ofr *a, const ofr *b);              /* a += b  */
+void ofr_sub(const ofield *f, ofr *a, const ofr *b);              /* a -= b  */
+void ofr_neg(const ofield *f, ofr *a);
+void ofr_dbl(const ofield *f, ofr *a);
+void ofr_mul(const ofield *f, ofr *a, const ofr *b);              /* a *= b  */
+void ofr_sqr(const ofield *f, ofr *a);
+void ofr_pow(const ofield *f, ofr *out, const ofr *base, uint64_t e);
+int  ofr_inverse(const ofield *f, ofr *out, const ofr *a);        /* 0 ok, -1 if a == 0 */
+int  ofr_from_repr(const ofield *f, ofr *out, const uint64_t canon[4]);  /* -1 if >= p */
+void ofr_into_repr(const ofield *f, uint64_t canon[4], const ofr *a);
+void ofr_from_u64(const ofield *f, ofr *out, uint64_t v);
+int  ofr_eq(const ofr *a, const ofr *b);
+int  ofr_is_zero(const ofr *a);
+
+/* ---- Domain::new_for_size (src/domains/mod.rs:21-44) ---- */
+typedef struct { uint64_t size; uint64_t power_of_two; ofr generator; } odomain;
+int odomain_new_for_size(const ofield *f, uint64_t size, odomain *out);  /* -1: SynthesisError */
+
+/* ---- transforms (in place, natural -> natural) ---- */
+void o_serial_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n);          /* src/fft/fft.rs:21-66 */
+void o_serial_fft_radix_4(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n);  /* src/fft/radix4_fft/mod.rs:45-123 */
+void o_parallel_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                    uint32_t log_cpus);                                                          /* src/fft/fft.rs:68-124 */
+void o_best_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                uint32_t cpus);                                                                  /* src/fft/fft.rs:5-19 */
+void o_serial_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                  size_t lde_factor);                                                            /* src/fft/lde.rs:15-126 */
+void o_distribute_powers(const ofield *f, ofr *a, size_t n, const ofr *g, uint32_t cpus);       /* src/fft/mod.rs:110-123 */
+void o_naive_dft(const ofield *f, const ofr *in, ofr *out, size_t n, const ofr *omega);         /* definition, O(n^2) */
+
+/* ---- Polynomial<F, _> (src/polynomials/mod.rs) ---- */
+int o_poly_fft(const ofield *f, ofr *a, size_t n, uint32_t cpus);          /* :611-624 */
+int o_poly_coset_fft(const ofield *f, ofr *a, size_t n, uint32_t cpus);    /* :626-631 */
+int o_poly_ifft(const ofield *f, ofr *a, size_t n, uint32_t cpus);         /* :773-798 */
+int o_poly_icoset_fft(const ofield *f, ofr *a, size_t n, uint32_t cpus);   /* :800-807 */
+/* lde_using_multiple_cosets :418-482 (coset=0) / coset_lde_using_multiple_cosets :544-609 (coset=1).
+ * out has n*factor elements. */
+int o_poly_lde(const ofield *f, const ofr *coeffs, size_t n, size_t factor, int coset,
+               ofr *out, uint32_t cpus);
+void o_poly_evaluate_at(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out);  /* :685-711 */
+
+/* ---- BLAKE2s IOP (src/iop/blake2s_trivial_iop.rs) ---- */
+void o_blake2s(uint8_t out[32], const uint8_t *key, size_t keylen, const uint8_t *personal,
+               size_t personal_len, const uint8_t *data, size_t len);   /* RFC 7693, blake2s_simd Params */
+void o_hash_leaf(uint8_t out[32], const ofr *leaf);                     /* :36-42, :81-91 */
+void o_hash_node(uint8_t out[32], const uint8_t l[32], const uint8_t r[32]);   /* :93-104 */
+int  o_iop_create(const ofr *leafs, size_t n, uint8_t *nodes /* n*32 */, uint32_t cpus);  /* :131-219 */
+void o_interpret_hash(const ofield *f, const uint8_t h[32], ofr *out);  /* :48-60 */
+size_t o_iop_path(const uint8_t *nodes, const ofr *leafs, size_t n, size_t tree_index,
+                  uint8_t *path /* log2(n)*32 */);                      /* :251-279 */
+int  o_iop_verify(const uint8_t root[32], const ofr *leaf, const uint8_t *path, size_t path_len,
+                  size_t tree_index);                                   /* :236-249 */
+
+/* ---- FRI commit phase (src/fri/fri_on_values.rs:11-159) ---- */
+typedef struct {
+    size_t num_steps;
+    size_t initial_degree_plus_one, output_coeffs_at_degree_plus_one, lde_factor;
+    uint8_t *l0_nodes;            /* N*32: l0_commitment tree */
+    uint8_t **inter_nodes;        /* num_steps trees */
+    ofr **inter_values;           /* num_steps vectors, sizes N/2, N/4, ... */
+    size_t *inter_sizes;
+    ofr *challenges;              /* num_steps */
+    uint8_t final_root[32];
+    ofr *final_coeffs;            /* output_coeffs_at_degree_plus_one */
+} ofri_proto;
+int  o_fri_commit(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
+                  size_t out_deg_plus_one, uint32_t cpus, ofri_proto **out);
+void o_fri_free(ofri_proto *p);
+/* canonical prototype encoding (defined by this build, the reference has none — SURVEY F10):
+ * u64le num_steps | roots[num_steps+1] (l0 + intermediates, 32 B each) | challenges[num_steps]
+ * (32 B Montgomery LE) | final_root (32 B) | u64le n_final | final_coeffs (32 B each). */
+size_t o_fri_serialize(const ofri_proto *p, uint8_t *buf, size_t cap);
+
+/* threads helper */
+uint32_t o_num_cpus(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

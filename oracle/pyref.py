@@ -1,0 +1,260 @@
+"""pyref.py — Python big-int restatement of the hodor hot path (TEST INFRASTRUCTURE ONLY).
+
+Independent of oracle/hodor_oracle.c: plain Python integers + hashlib.blake2s.  Used to
+(a) pin the C oracle and (b) generate the small golden vectors under tests/golden/
+(tests/golden/gen_golden.py).  PARITY STATUS: parity unpinned against the Rust binary — the
+reference cannot be built in this image and holds no known-answer vectors.
+
+Reference citations are relative to /root/reference.
+"""
+import hashlib
+
+# Fields defined by the reference
+BN256_FR_MODULUS = 52435875175126190479447740508185965837690552500527637822603658699938581184513  # src/bn256.rs:5
+BN256_FR_GENERATOR = 7                                                                             # src/bn256.rs:6
+EXPERIMENTS_FR_MODULUS = 3618502788666131213697322783095070105623107215331596699973092056135872020481  # src/experiments/mod.rs:19
+EXPERIMENTS_FR_GENERATOR = 3
+
+IOP_KEY = b"Squeamish Ossifrage"    # src/iop/blake2s_trivial_iop.rs:12
+IOP_PERSONAL = b"Shaftoe"           # src/iop/blake2s_trivial_iop.rs:13
+
+
+class Field:
+    """ff_ce #[derive(PrimeField)] constants for a 4-limb field (R = 2^256)."""
+
+    def __init__(self, p, g):
+        self.p, self.g = p, g
+        self.R = (1 << 256) % p
+        self.Rinv = pow(self.R, -1, p)
+        self.num_bits = p.bit_length()
+        self.capacity = self.num_bits - 1
+        t, s = p - 1, 0
+        while t % 2 == 0:
+            t //= 2
+            s += 1
+        self.S, self.t = s, t
+        self.root_of_unity = pow(g, t, p)
+
+    # Montgomery <-> canonical
+    def to_mont(self, x):
+        return (x * self.R) % self.p
+
+    def from_mont(self, m):
+        return (m * self.Rinv) % self.p
+
+    def domain_generator(self, size):
+        """Domain::new_for_size, src/domains/mod.rs:21-44 (canonical value)."""
+        sz = 1
+        while sz < size:
+            sz <<= 1
+        k = sz.bit_length() - 1
+        if k > self.S:
+            raise ValueError("SynthesisError::Error")
+        return pow(self.root_of_unity, 1 << (self.S - k), self.p), k, sz
+
+
+BN256 = Field(BN256_FR_MODULUS, BN256_FR_GENERATOR)
+EXPERIMENTS = Field(EXPERIMENTS_FR_MODULUS, EXPERIMENTS_FR_GENERATOR)
+
+
+def mont_to_bytes(m):
+    """Fr(FrRepr([u64;4])) memory image == encode_leaf (blake2s_trivial_iop.rs:36-42)."""
+    return int(m).to_bytes(32, "little")
+
+
+def bytes_to_mont(b):
+    return int.from_bytes(b, "little")
+
+
+# ------------------------------------------------------------------ transforms (canonical ints)
+def naive_dft(F, a, omega):
+    n, p = len(a), F.p
+    return [sum(a[i] * pow(omega, (i * k) % n, p) for i in range(n)) % p for k in range(n)]
+
+
+def ntt(F, a, omega):
+    """Radix-2 DIT after bit reversal, src/fft/fft.rs:21-66 (canonical ints, table twiddles)."""
+    n, p = len(a), F.p
+    log_n = n.bit_length() - 1
+    a = list(a)
+    for k in range(n):
+        rk = int(format(k, "0%db" % log_n)[::-1], 2) if log_n else 0
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    m = 1
+    while m < n:
+        w_m = pow(omega, n // (2 * m), p)
+        for k in range(0, n, 2 * m):
+            w = 1
+            for j in range(m):
+                t = a[k + j + m] * w % p
+                u = a[k + j]
+                a[k + j] = (u + t) % p
+                a[k + j + m] = (u - t) % p
+                w = w * w_m % p
+        m *= 2
+    return a
+
+
+def distribute_powers(F, a, g):
+    """src/fft/mod.rs:110-123"""
+    p, out, u = F.p, [], 1
+    for v in a:
+        out.append(v * u % p)
+        u = u * g % p
+    return out
+
+
+def poly_fft(F, a):
+    omega, _, _ = F.domain_generator(len(a))
+    return ntt(F, a, omega)
+
+
+def poly_ifft(F, a):
+    """src/polynomials/mod.rs:773-798"""
+    omega, _, _ = F.domain_generator(len(a))
+    minv = pow(len(a), -1, F.p)
+    return [v * minv % F.p for v in ntt(F, a, pow(omega, -1, F.p))]
+
+
+def poly_coset_fft(F, a):
+    return poly_fft(F, distribute_powers(F, a, F.g))
+
+
+def poly_icoset_fft(F, a):
+    return distribute_powers(F, poly_ifft(F, a), pow(F.g, -1, F.p))
+
+
+def poly_lde(F, coeffs, factor, coset=False):
+    """lde_using_multiple_cosets / coset_lde_using_multiple_cosets,
+    src/polynomials/mod.rs:418-482, :544-609: out[idx] = res[idx % f][idx // f]."""
+    n = len(coeffs)
+    if factor == 1:
+        return poly_coset_fft(F, coeffs) if coset else poly_fft(F, coeffs)
+    Omega, _, _ = F.domain_generator(n * factor)
+    omega, _, _ = F.domain_generator(n)
+    results = []
+    for i in range(factor):
+        gen = pow(Omega, i, F.p)
+        if coset:
+            gen = gen * F.g % F.p
+        results.append(ntt(F, distribute_powers(F, coeffs, gen), omega))
+    return [results[idx % factor][idx // factor] for idx in range(n * factor)]
+
+
+# ------------------------------------------------------------------ BLAKE2s IOP
+def b2s(data):
+    return hashlib.blake2s(data, digest_size=32, key=IOP_KEY, person=IOP_PERSONAL).digest()
+
+
+def hash_leaf(mont):
+    return b2s(mont_to_bytes(mont))
+
+
+def hash_node(l, r):
+    return b2s(l + r)
+
+
+def iop_create(leafs_mont):
+    """Blake2sIopTree::create, blake2s_trivial_iop.rs:131-219. Returns nodes (list of 32-B, heap)."""
+    n = len(leafs_mont)
+    assert n >= 2 and n & (n - 1) == 0
+    lh = [hash_leaf(v) for v in leafs_mont]
+    nodes = [b"\x00" * 32] * n
+    for i in range(n // 2):
+        nodes[n // 2 + i] = hash_node(lh[2 * i], lh[2 * i + 1])
+    w = n // 4
+    while w >= 1:
+        for i in range(w):
+            nodes[w + i] = hash_node(nodes[2 * (w + i)], nodes[2 * (w + i) + 1])
+        w //= 2
+    return nodes
+
+
+def interpret_hash(F, h):
+    """blake2s_trivial_iop.rs:48-60 -> canonical int."""
+    v = int.from_bytes(h, "big")
+    shave = 256 - F.capacity
+    top_mask = (0xFFFFFFFFFFFFFFFF >> (shave % 64))
+    v &= (top_mask << 192) | ((1 << 192) - 1)
+    assert v < F.p
+    return v
+
+
+def iop_path(nodes, leafs_mont, tree_index):
+    """get_path, blake2s_trivial_iop.rs:251-279"""
+    n = len(nodes)
+    path = [hash_leaf(leafs_mont[tree_index ^ 1])]
+    idx = tree_index >> 1
+    w = n // 2
+    while w >= 2:
+        path.append(nodes[w + (idx ^ 1)])
+        idx >>= 1
+        w //= 2
+    return path
+
+
+def iop_verify(root, leaf_mont, path, tree_index):
+    h = hash_leaf(leaf_mont)
+    idx = tree_index
+    for el in path:
+        h = hash_node(h, el) if idx & 1 == 0 else hash_node(el, h)
+        idx >>= 1
+    return h == root
+
+
+# ------------------------------------------------------------------ FRI commit (by values)
+def fri_commit(F, lde_values, lde_factor, out_deg_plus_one):
+    """src/fri/fri_on_values.rs:11-159. lde_values canonical ints.
+    Returns dict(roots=[l0 + intermediates], challenges, final_root, final_coeffs, inter_values)."""
+    p = F.p
+    n = len(lde_values)
+    omega, _, _ = F.domain_generator(n)
+    omega_inv = pow(omega, -1, p)
+    two_inv = pow(2, -1, p)
+    num_steps = ((n // lde_factor) // out_deg_plus_one).bit_length() - 1
+    assert num_steps >= 1
+    nodes = iop_create([F.to_mont(v) for v in lde_values])
+    roots = [nodes[1]]
+    challenge = interpret_hash(F, nodes[1])
+    challenges = [challenge]
+    values = list(lde_values)
+    inter = []
+    for i in range(num_steps):
+        half = len(values) // 2
+        stride = 1 << i
+        nxt = []
+        for idx in range(half):
+            a, b = values[idx], values[idx + half]
+            even = (a + b) % p
+            odd = (a - b) * pow(omega_inv, idx * stride, p) % p
+            nxt.append((odd * challenge + even) * two_inv % p)
+        nodes = iop_create([F.to_mont(v) for v in nxt])
+        roots.append(nodes[1])
+        challenge = interpret_hash(F, nodes[1])
+        challenges.append(challenge)
+        inter.append(nxt)
+        values = nxt
+    challenges.pop()
+    final_coeffs = poly_ifft(F, values)[:out_deg_plus_one]
+    return dict(roots=roots, challenges=challenges, final_root=roots[-1],
+                final_coeffs=final_coeffs, inter_values=inter)
+
+
+def fri_fold_coeffs(F, coeffs, beta):
+    """src/fri/mod.rs:194-203: a_{2i} + beta * a_{2i+1}"""
+    return [(coeffs[2 * i] + beta * coeffs[2 * i + 1]) % F.p for i in range(len(coeffs) // 2)]
+
+
+def fri_serialize(F, proto):
+    """Canonical prototype encoding defined by this build (same layout as o_fri_serialize)."""
+    out = len(proto["challenges"]).to_bytes(8, "little")
+    for r in proto["roots"]:
+        out += r
+    for c in proto["challenges"]:
+        out += mont_to_bytes(F.to_mont(c))
+    out += proto["final_root"]
+    out += len(proto["final_coeffs"]).to_bytes(8, "little")
+    for c in proto["final_coeffs"]:
+        out += mont_to_bytes(F.to_mont(c))
+    return out
