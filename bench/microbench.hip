@@ -1,0 +1,276 @@
+// microbench.hip — instruction-rate probes for gfx950 (which integer/FP op should carry the
+// 256-bit modular multiply?).  Build: hipcc --offload-arch=gfx950 -O3 bench/microbench.hip -o bench/microbench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../hodor_amd/csrc/fr.cuh"
+
+using namespace hodor;
+#define ITERS 2048
+#define ILP 8
+
+__global__ void k_mad64(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint64_t acc[ILP];
+    uint32_t x = a + threadIdx.x, y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint64_t r;
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(acc[i]) : "vcc");
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_mullo(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_mulhi(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_mad24(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(acc[i]), "v"(y), "v"(acc[i]));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_addc(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_addc_co_u32 %0, vcc, %1, %2, vcc" : "=v"(r) : "v"(acc[i]), "v"(y) : "vcc");
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_add32(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_lshladd64(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint64_t acc[ILP];
+    uint64_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint64_t r;
+            asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_fma64(uint64_t *out, uint32_t a, uint32_t b)
+{
+    double acc[ILP];
+    double y = 1.0 + 1e-9 * (b + blockIdx.x), z = 1e-3 * a;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            double r;
+            asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc[i]), "v"(y), "v"(z));
+            acc[i] = r;
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint64_t)s;
+}
+
+__global__ void k_fma32(uint64_t *out, uint32_t a, uint32_t b)
+{
+    float acc[ILP];
+    float y = 1.0f + 1e-6f * (b + blockIdx.x), z = 1e-3f * a;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            float r;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(acc[i]), "v"(y), "v"(z));
+            acc[i] = r;
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint64_t)s;
+}
+
+#define MUL_ITERS 256
+__global__ void k_frmul(uint64_t *out, FrParams P, uint32_t seed)
+{
+    Fr x[2], w;
+    for (int i = 0; i < 8; i++) { x[0].v[i] = seed + i + threadIdx.x; x[1].v[i] = seed * 3 + i + blockIdx.x; w.v[i] = seed * 7 + i; }
+    x[0].v[7] &= 0x0fffffff; x[1].v[7] &= 0x0fffffff; w.v[7] &= 0x0fffffff;
+    for (int it = 0; it < MUL_ITERS; it++) {
+        x[0] = fr_mul(x[0], w, P);
+        x[1] = fr_mul(x[1], w, P);
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 8; i++) s += x[0].v[i] + x[1].v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_fraddsub(uint64_t *out, FrParams P, uint32_t seed)
+{
+    Fr x[2], w;
+    for (int i = 0; i < 8; i++) { x[0].v[i] = seed + i + threadIdx.x; x[1].v[i] = seed * 3 + i + blockIdx.x; w.v[i] = seed * 7 + i; }
+    x[0].v[7] &= 0x0fffffff; x[1].v[7] &= 0x0fffffff; w.v[7] &= 0x0fffffff;
+    for (int it = 0; it < MUL_ITERS; it++) {
+        x[0] = fr_add(x[0], w, P);
+        x[1] = fr_sub(x[1], w, P);
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 8; i++) s += x[0].v[i] + x[1].v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_copy(const uint4 *in, uint4 *out, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
+template <class F>
+static float time_it(F f, int reps = 5)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    f();
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < reps; r++) {
+        hipEventRecord(a);
+        f();
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    printf("device: %s CUs=%d clock=%d MHz lds/block=%zu maxLds/CU=%zu\n", prop.name, prop.multiProcessorCount,
+           prop.clockRate / 1000, prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor);
+    const int blocks = prop.multiProcessorCount * 8, threads = 256;
+    uint64_t *out;
+    hipMalloc(&out, (size_t)blocks * threads * 8);
+    double lanes = (double)blocks * threads;
+#define RUN(name, kern)                                                                               \
+    {                                                                                                 \
+        float ms = time_it([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, 3u, 5u); }); \
+        double ops = lanes * ITERS * ILP;                                                             \
+        printf("%-16s %8.3f ms  %8.2f Gop/s  %6.2f lane-ops/clk/CU @2.4GHz\n", name, ms, ops / ms * 1e-6, \
+               ops / (ms * 1e-3) / (prop.multiProcessorCount * 2.4e9));                               \
+    }
+    RUN("v_mad_u64_u32", k_mad64)
+    RUN("v_mul_lo_u32", k_mullo)
+    RUN("v_mul_hi_u32", k_mulhi)
+    RUN("v_mad_u32_u24", k_mad24)
+    RUN("v_addc_co_u32", k_addc)
+    RUN("v_add_u32", k_add32)
+    RUN("v_lshl_add_u64", k_lshladd64)
+    RUN("v_fma_f64", k_fma64)
+    RUN("v_fma_f32", k_fma32)
+    FrParams P;
+    // BLS12-381 Fr (the field in src/bn256.rs)
+    const uint32_t p[8] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753};
+    for (int i = 0; i < 8; i++) { P.p[i] = p[i]; P.one[i] = 0; }
+    P.pinv = 0xffffffff;
+    {
+        float ms = time_it([&] { hipLaunchKernelGGL(k_frmul, dim3(blocks), dim3(threads), 0, 0, out, P, 12345u); });
+        double muls = lanes * MUL_ITERS * 2;
+        printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr_mul", ms, muls / ms * 1e-6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_fraddsub, dim3(blocks), dim3(threads), 0, 0, out, P, 12345u); });
+        printf("%-16s %8.3f ms  %8.2f Gop/s\n", "fr_add+fr_sub", ms, muls / ms * 1e-6);
+    }
+    {
+        size_t n = (size_t)1 << 26;   // 1 GiB of uint4
+        uint4 *a, *b;
+        hipMalloc(&a, n * 16); hipMalloc(&b, n * 16);
+        hipMemset(a, 1, n * 16);
+        float ms = time_it([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(threads), 0, 0, a, b, n); });
+        printf("%-16s %8.3f ms  %8.2f GB/s (read+write)\n", "copy 1GiB", ms, 2.0 * n * 16 / ms * 1e-6);
+    }
+    return 0;
+}

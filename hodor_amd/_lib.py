@@ -1,0 +1,354 @@
+"""ctypes binding of libhodor_gpu.so (include/hodor_gpu.h).
+
+Host arrays are numpy uint64 of shape (n, 4) — the memory image of Rust `&[Fr]`.  Device arrays are
+anything exposing `.data_ptr()` (torch int64/uint64 CUDA tensors of shape (n, 4)) or a raw int
+address.  No compute happens in Python and there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libhodor_gpu.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+# Fields the reference defines (src/bn256.rs:5-6, src/experiments/mod.rs:19-20)
+BN256_FR_MODULUS = 52435875175126190479447740508185965837690552500527637822603658699938581184513
+BN256_FR_GENERATOR = 7
+EXPERIMENTS_FR_MODULUS = 3618502788666131213697322783095070105623107215331596699973092056135872020481
+EXPERIMENTS_FR_GENERATOR = 3
+
+OK, ERR_SIZE, ERR_INVALID, ERR_DEVICE = 0, 1, 2, 3
+
+# every symbol include/hodor_gpu.h declares
+EXPORTS = [
+    "hodor_ctx_create", "hodor_ctx_destroy", "hodor_ctx_field_info", "hodor_last_error",
+    "hodor_ctx_synchronize",
+    "hodor_fr_mul", "hodor_fr_add", "hodor_fr_sub", "hodor_fr_pow", "hodor_fr_inverse",
+    "hodor_fr_from_repr", "hodor_fr_into_repr", "hodor_domain_new_for_size",
+    "hodor_fft", "hodor_lde", "hodor_distribute_powers",
+    "hodor_poly_fft", "hodor_poly_coset_fft", "hodor_poly_ifft", "hodor_poly_icoset_fft",
+    "hodor_poly_lde", "hodor_poly_coset_lde",
+    "hodor_iop_create", "hodor_iop_challenge", "hodor_iop_path", "hodor_iop_verify",
+    "hodor_fri_commit", "hodor_fri_free", "hodor_fri_num_steps", "hodor_fri_roots",
+    "hodor_fri_final_root", "hodor_fri_challenges", "hodor_fri_final_coefficients",
+    "hodor_fri_intermediate_values", "hodor_fri_tree_nodes", "hodor_fri_serialize",
+    "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
+    "hodor_fft_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
+    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_distribute_powers_dev",
+    "hodor_iop_create_dev", "hodor_fri_commit_dev",
+]
+
+
+class HodorError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        names = {ERR_SIZE: "HODOR_ERR_SIZE", ERR_INVALID: "HODOR_ERR_INVALID", ERR_DEVICE: "HODOR_ERR_DEVICE"}
+        super().__init__("%s %s" % (names.get(code, code), msg))
+
+
+class _Fr(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+
+class _FieldInfo(C.Structure):
+    _fields_ = [("modulus", C.c_uint64 * 4), ("s", C.c_uint32), ("num_bits", C.c_uint32),
+                ("capacity", C.c_uint32), ("one", _Fr), ("generator", _Fr), ("root_of_unity", _Fr)]
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)
+            if f.endswith((".hip", ".cuh", ".hpp"))] + [os.path.join(_HERE, "..", "include", "hodor_gpu.h")]
+    stale = force or not os.path.exists(_LIB) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-j8"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    """Load libhodor_gpu.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError("libhodor_gpu.so is missing: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (there is no CPU fallback)")
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  Whichever is
+            # loaded first serves the whole process, and torch cannot initialise on top of the system
+            # copy — so when torch is installed, let it load its runtime before libhodor_gpu.so binds.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _lib = C.CDLL(_LIB)
+        _lib.hodor_last_error.restype = C.c_char_p
+        _lib.hodor_fri_num_steps.restype = C.c_size_t
+        _lib.hodor_fri_serialize.restype = C.c_size_t
+        _lib.hodor_ctx_destroy.restype = None
+        _lib.hodor_fri_free.restype = None
+    return _lib
+
+
+def _limbs(x):
+    return [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def _to_int(l):
+    return sum(int(l[i]) << (64 * i) for i in range(4))
+
+
+def _fr(x):
+    return _Fr((C.c_uint64 * 4)(*_limbs(x)))
+
+
+def _hptr(a):
+    assert isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dptr(t):
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class FriPrototype:
+    """Mirror of FRIProofPrototype (src/fri/mod.rs:106-117) held by the library."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        L = ctx.L
+        self.num_steps = int(L.hodor_fri_num_steps(handle))
+        roots = np.zeros((self.num_steps + 1, 32), dtype=np.uint8)
+        ctx._chk(L.hodor_fri_roots(handle, roots.ctypes.data_as(C.c_void_p)))
+        self.roots = [bytes(r) for r in roots]
+        fr = (C.c_uint8 * 32)()
+        ctx._chk(L.hodor_fri_final_root(handle, fr))
+        self.final_root = bytes(fr)
+        ch = np.zeros((self.num_steps, 4), dtype=np.uint64)
+        ctx._chk(L.hodor_fri_challenges(handle, _hptr(ch)))
+        self.challenges = [_to_int(r) for r in ch]
+        need = L.hodor_fri_serialize(handle, None, C.c_size_t(0))
+        buf = (C.c_uint8 * need)()
+        L.hodor_fri_serialize(handle, buf, C.c_size_t(need))
+        self.serialized = bytes(buf)
+        # final coefficients: count is encoded in the serialization tail
+        off = 8 + 32 * (self.num_steps + 1) + 32 * self.num_steps + 32
+        nf = int.from_bytes(self.serialized[off:off + 8], "little")
+        fc = np.zeros((nf, 4), dtype=np.uint64)
+        ctx._chk(L.hodor_fri_final_coefficients(handle, _hptr(fc)))
+        self.final_coeffs = fc
+
+    def intermediate_values(self, step, size):
+        out = np.zeros((size, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.hodor_fri_intermediate_values(self.h, C.c_size_t(step), _hptr(out)))
+        return out
+
+    def tree_nodes(self, step, size):
+        out = np.zeros((size, 32), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.hodor_fri_tree_nodes(self.h, C.c_int(step), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.L.hodor_fri_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """hodor_ctx: one prime field + one device (device=-1: host-only helpers, no compute)."""
+
+    def __init__(self, modulus=BN256_FR_MODULUS, generator=BN256_FR_GENERATOR, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        mod = (C.c_uint64 * 4)(*_limbs(modulus))
+        rc = self.L.hodor_ctx_create(mod, C.c_uint64(generator), C.c_int(device), C.byref(self.h))
+        if rc != OK:
+            raise HodorError(rc, "hodor_ctx_create")
+        self.modulus = modulus
+        info = _FieldInfo()
+        self._chk(self.L.hodor_ctx_field_info(self.h, C.byref(info)))
+        self.S, self.num_bits, self.capacity = int(info.s), int(info.num_bits), int(info.capacity)
+        self.one = _to_int(info.one.l)
+        self.generator = _to_int(info.generator.l)
+        self.root_of_unity = _to_int(info.root_of_unity.l)
+
+    def close(self):
+        if self.h:
+            self.L.hodor_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise HodorError(rc, (self.L.hodor_last_error(self.h) or b"").decode())
+
+    def synchronize(self):
+        self._chk(self.L.hodor_ctx_synchronize(self.h))
+
+    # ---- host scalar helpers
+    def _bin(self, name, a, b):
+        out = _Fr()
+        x, y = _fr(a), _fr(b)
+        self._chk(getattr(self.L, name)(self.h, C.byref(x), C.byref(y), C.byref(out)))
+        return _to_int(out.l)
+
+    def mul(self, a, b):
+        return self._bin("hodor_fr_mul", a, b)
+
+    def add(self, a, b):
+        return self._bin("hodor_fr_add", a, b)
+
+    def sub(self, a, b):
+        return self._bin("hodor_fr_sub", a, b)
+
+    def pow(self, a, e):
+        out, x = _Fr(), _fr(a)
+        self._chk(self.L.hodor_fr_pow(self.h, C.byref(x), C.c_uint64(e), C.byref(out)))
+        return _to_int(out.l)
+
+    def inverse(self, a):
+        out, x = _Fr(), _fr(a)
+        self._chk(self.L.hodor_fr_inverse(self.h, C.byref(x), C.byref(out)))
+        return _to_int(out.l)
+
+    def from_repr(self, canonical):
+        out = _Fr()
+        c = (C.c_uint64 * 4)(*_limbs(canonical))
+        self._chk(self.L.hodor_fr_from_repr(self.h, c, C.byref(out)))
+        return _to_int(out.l)
+
+    def into_repr(self, mont):
+        c, x = (C.c_uint64 * 4)(), _fr(mont)
+        self._chk(self.L.hodor_fr_into_repr(self.h, C.byref(x), c))
+        return _to_int(c)
+
+    def domain(self, size):
+        """Domain::new_for_size -> (size, log_n, generator)"""
+        sz, k, g = C.c_uint64(), C.c_uint32(), _Fr()
+        self._chk(self.L.hodor_domain_new_for_size(self.h, C.c_uint64(size), C.byref(sz), C.byref(k), C.byref(g)))
+        return int(sz.value), int(k.value), _to_int(g.l)
+
+    # ---- slice API
+    def fft(self, a, omega, log_n):
+        w = _fr(omega)
+        self._chk(self.L.hodor_fft(self.h, _hptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n)))
+
+    def lde(self, a, omega, log_n, lde_factor):
+        w = _fr(omega)
+        self._chk(self.L.hodor_lde(self.h, _hptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                                   C.c_size_t(lde_factor)))
+
+    def distribute_powers(self, a, g):
+        gg = _fr(g)
+        self._chk(self.L.hodor_distribute_powers(self.h, _hptr(a), C.c_size_t(len(a)), C.byref(gg)))
+
+    def poly_fft(self, a):
+        self._chk(self.L.hodor_poly_fft(self.h, _hptr(a), C.c_size_t(len(a))))
+
+    def poly_coset_fft(self, a):
+        self._chk(self.L.hodor_poly_coset_fft(self.h, _hptr(a), C.c_size_t(len(a))))
+
+    def poly_ifft(self, a):
+        self._chk(self.L.hodor_poly_ifft(self.h, _hptr(a), C.c_size_t(len(a))))
+
+    def poly_icoset_fft(self, a):
+        self._chk(self.L.hodor_poly_icoset_fft(self.h, _hptr(a), C.c_size_t(len(a))))
+
+    def poly_lde(self, coeffs, factor, coset=False):
+        out = np.zeros((len(coeffs) * factor, 4), dtype=np.uint64)
+        fn = self.L.hodor_poly_coset_lde if coset else self.L.hodor_poly_lde
+        self._chk(fn(self.h, _hptr(coeffs), C.c_size_t(len(coeffs)), C.c_size_t(factor), _hptr(out)))
+        return out
+
+    def iop_create(self, leafs):
+        nodes = np.zeros((len(leafs), 32), dtype=np.uint8)
+        self._chk(self.L.hodor_iop_create(self.h, _hptr(leafs), C.c_size_t(len(leafs)),
+                                          nodes.ctypes.data_as(C.c_void_p)))
+        return nodes
+
+    def iop_challenge(self, root):
+        out = _Fr()
+        self._chk(self.L.hodor_iop_challenge(self.h, bytes(root), C.byref(out)))
+        return _to_int(out.l)
+
+    def iop_path(self, nodes, leafs, tree_index):
+        n = len(leafs)
+        path = np.zeros((max(1, n.bit_length() - 1), 32), dtype=np.uint8)
+        cnt = C.c_size_t()
+        self._chk(self.L.hodor_iop_path(self.h, nodes.ctypes.data_as(C.c_void_p), _hptr(leafs),
+                                        C.c_size_t(n), C.c_size_t(tree_index),
+                                        path.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return path[:cnt.value]
+
+    def iop_verify(self, root, leaf_mont, path, tree_index):
+        ok, x = C.c_int(), _fr(leaf_mont)
+        path = np.ascontiguousarray(path)
+        self._chk(self.L.hodor_iop_verify(self.h, bytes(root), C.byref(x), path.ctypes.data_as(C.c_void_p),
+                                          C.c_size_t(len(path)), C.c_size_t(tree_index), C.byref(ok)))
+        return bool(ok.value)
+
+    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one):
+        h = C.c_void_p()
+        self._chk(self.L.hodor_fri_commit(self.h, _hptr(lde_values), C.c_size_t(len(lde_values)),
+                                          C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.byref(h)))
+        return FriPrototype(self, h)
+
+    # ---- device API (tensors / raw device pointers)
+    def fft_dev(self, src, dst, log_n, omega, stream=None):
+        w = _fr(omega)
+        self._chk(self.L.hodor_fft_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst), C.c_uint32(log_n),
+                                       C.byref(w)))
+
+    def _poly_dev(self, name, src, dst, log_n, stream):
+        self._chk(getattr(self.L, name)(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst), C.c_uint32(log_n)))
+
+    def poly_fft_dev(self, src, dst, log_n, stream=None):
+        self._poly_dev("hodor_poly_fft_dev", src, dst, log_n, stream)
+
+    def poly_ifft_dev(self, src, dst, log_n, stream=None):
+        self._poly_dev("hodor_poly_ifft_dev", src, dst, log_n, stream)
+
+    def poly_coset_fft_dev(self, src, dst, log_n, stream=None):
+        self._poly_dev("hodor_poly_coset_fft_dev", src, dst, log_n, stream)
+
+    def poly_icoset_fft_dev(self, src, dst, log_n, stream=None):
+        self._poly_dev("hodor_poly_icoset_fft_dev", src, dst, log_n, stream)
+
+    def poly_lde_dev(self, src, dst, log_n, factor, coset=False, stream=None):
+        self._chk(self.L.hodor_poly_lde_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                            C.c_uint32(log_n), C.c_size_t(factor), C.c_int(1 if coset else 0)))
+
+    def distribute_powers_dev(self, a, n, g, stream=None):
+        gg = _fr(g)
+        self._chk(self.L.hodor_distribute_powers_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.byref(gg)))
+
+    def iop_create_dev(self, leafs, n, nodes, stream=None):
+        self._chk(self.L.hodor_iop_create_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n), _dptr(nodes)))
+
+    def fri_commit_dev(self, lde_values, n, lde_factor, out_deg_plus_one, stream=None):
+        h = C.c_void_p()
+        self._chk(self.L.hodor_fri_commit_dev(self.h, C.c_void_p(stream), _dptr(lde_values), C.c_size_t(n),
+                                              C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.byref(h)))
+        return FriPrototype(self, h)

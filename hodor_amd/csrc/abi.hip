@@ -1,0 +1,915 @@
+// abi.hip — implementation of include/hodor_gpu.h: context, twiddle cache, NTT planning, and the
+// C entry points that stand where the reference's L2/L3 Rust functions stand.  No CPU fallback: a
+// context without a device refuses every compute call with HODOR_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hodor_gpu.h"
+#include "host_blake2s.hpp"
+#include "host_field.hpp"
+#include "ntt.cuh"
+
+namespace hodor {
+
+// kernels' host launchers (ntt.hip, pointwise.hip, merkle.hip, fri.hip)
+hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr *scale, const FrParams &);
+hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
+                            uint32_t log_stride, uint64_t count, const FrParams &);
+hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
+hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
+hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &);
+hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, const Fr &r2,
+                            uint32_t shave_bits, const FrParams &);
+hipError_t fri_fold_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half,
+                           const TwoLevel &winv, uint32_t log_stride, const uint4 *challenge,
+                           const FrParams &);
+
+static Fr to_dev(const HFr &a)
+{
+    Fr r;
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)a.l[i];
+        r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
+    }
+    return r;
+}
+
+struct PowTable {
+    HFr base;
+    uint32_t log_n;
+    uint32_t lo_bits;
+    uint4 *lo, *hi;
+};
+
+struct RadixTable {
+    HFr omega;
+    uint32_t log_n, log_r;
+    uint4 *rtw;
+};
+
+}  // namespace hodor
+
+using namespace hodor;
+
+struct hodor_ctx {
+    int device = -1;
+    HostField F;
+    FrParams P;
+    B2Mid mid;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::vector<PowTable> pow_tables;
+    std::vector<RadixTable> radix_tables;
+    void *scratch[2] = {nullptr, nullptr};
+    size_t scratch_bytes[2] = {0, 0};
+    uint32_t max_log_r = 8;    // largest per-pass radix (2^max_log_r points)
+    uint32_t tile_log = 11;    // elements per workgroup tile = 2^tile_log
+    std::string err;
+};
+
+struct hodor_fri_proto {
+    hodor_ctx *ctx;
+    size_t n, num_steps, lde_factor, out_deg, initial_degree_plus_one;
+    void *l0_nodes = nullptr;                 // device, n*32
+    std::vector<void *> inter_values;         // device
+    std::vector<void *> inter_nodes;          // device
+    std::vector<size_t> inter_sizes;
+    std::vector<uint8_t> roots;               // host: (num_steps+1)*32
+    std::vector<hodor_fr> challenges;         // host: num_steps
+    std::vector<hodor_fr> final_coeffs;       // host
+    uint8_t final_root[32];
+};
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);            \
+            return HODOR_ERR_DEVICE;                                                  \
+        }                                                                             \
+    } while (0)
+
+#define NEED_DEVICE()                                                                 \
+    do {                                                                              \
+        if (!ctx) return HODOR_ERR_INVALID;                                           \
+        if (ctx->device < 0) { ctx->err = "context has no HIP device"; return HODOR_ERR_DEVICE; } \
+        HIPCHK(hipSetDevice(ctx->device));                                            \
+    } while (0)
+
+static inline HFr to_h(const hodor_fr *a)
+{
+    HFr r;
+    memcpy(r.l, a->l, 32);
+    return r;
+}
+static inline void from_h(const HFr &a, hodor_fr *out) { memcpy(out->l, a.l, 32); }
+static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static inline uint32_t log2u(size_t n)
+{
+    uint32_t r = 0;
+    while (n > 1) { n >>= 1; r++; }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------------
+static int free_tables(hodor_ctx *ctx)
+{
+    HIPCHK(hipDeviceSynchronize());
+    for (auto &t : ctx->pow_tables) { (void)hipFree(t.lo); (void)hipFree(t.hi); }
+    for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
+    ctx->pow_tables.clear();
+    ctx->radix_tables.clear();
+    return HODOR_OK;
+}
+
+// base^e = lo[e & mask] * hi[e >> lo_bits] for e < 2^log_n
+static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out)
+{
+    for (auto &t : ctx->pow_tables)
+        if (t.log_n == log_n && t.base == base) {
+            *out = TwoLevel{t.lo, t.hi, t.lo_bits};
+            return HODOR_OK;
+        }
+    if (ctx->pow_tables.size() >= 48) { int rc = free_tables(ctx); if (rc) return rc; }
+    PowTable t;
+    t.base = base;
+    t.log_n = log_n;
+    t.lo_bits = (log_n + 1) / 2;
+    uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
+    HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * 32));
+    HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * 32));
+    Fr b = to_dev(base), one = to_dev(ctx->F.one);
+    HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, ctx->P));
+    HIPCHK(pow_table_launch(ctx->stream, t.hi, b, one, t.lo_bits, hi_cnt, ctx->P));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // tables are shared across streams afterwards
+    ctx->pow_tables.push_back(t);
+    *out = TwoLevel{t.lo, t.hi, t.lo_bits};
+    return HODOR_OK;
+}
+
+// omega_R^e = omega^(e << (log_n - log_r)), e < R/2
+static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uint32_t log_r,
+                           const uint4 **out)
+{
+    for (auto &t : ctx->radix_tables)
+        if (t.log_n == log_n && t.log_r == log_r && t.omega == omega) {
+            *out = t.rtw;
+            return HODOR_OK;
+        }
+    if (ctx->radix_tables.size() >= 96) { int rc = free_tables(ctx); if (rc) return rc; }
+    RadixTable t;
+    t.omega = omega;
+    t.log_n = log_n;
+    t.log_r = log_r;
+    uint64_t cnt = log_r ? (1ull << (log_r - 1)) : 1;
+    HIPCHK(hipMalloc((void **)&t.rtw, cnt * 32));
+    HIPCHK(pow_table_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt,
+                            ctx->P));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->radix_tables.push_back(t);
+    *out = t.rtw;
+    return HODOR_OK;
+}
+
+static int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes)
+{
+    if (ctx->scratch_bytes[which] >= bytes) return HODOR_OK;
+    if (ctx->scratch[which]) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(ctx->scratch[which]));
+        ctx->scratch[which] = nullptr;
+        ctx->scratch_bytes[which] = 0;
+    }
+    HIPCHK(hipMalloc(&ctx->scratch[which], bytes));
+    ctx->scratch_bytes[which] = bytes;
+    return HODOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT planning + execution
+// ------------------------------------------------------------------------------------------------
+static void plan_radices(const hodor_ctx *ctx, uint32_t log_n, std::vector<uint32_t> *out)
+{
+    out->clear();
+    if (log_n <= ctx->tile_log) {   // the whole transform fits one workgroup tile
+        out->push_back(log_n);
+        return;
+    }
+    uint32_t passes = (log_n + ctx->max_log_r - 1) / ctx->max_log_r;
+    uint32_t base = log_n / passes, rem = log_n % passes;
+    for (uint32_t i = 0; i < passes; i++) out->push_back(base + (i < rem ? 1 : 0));
+}
+
+// dst[k] = post^k * scale * sum_i (pre^i * src[i]) omega^(ik),  src[i] = 0 for i >= nnz.
+// src may equal dst.  Caller holds ctx->mu.
+static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n,
+                    const HFr &omega, uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post)
+{
+    std::vector<uint32_t> radices;
+    plan_radices(ctx, log_n, &radices);
+    const size_t passes = radices.size();
+    const size_t bytes = (size_t)32 << log_n;
+
+    TwoLevel tw = {nullptr, nullptr, 0}, pre_t = {nullptr, nullptr, 0}, post_t = {nullptr, nullptr, 0};
+    int rc;
+    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw))) return rc;
+    if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t))) return rc;
+    if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t))) return rc;
+
+    // ping-pong buffers: the last pass writes dst; a pass never runs in place unless it is the only
+    // one (a single tile is fully staged in LDS before anything is written back).
+    std::vector<uint4 *> outs(passes);
+    if (passes == 1) {
+        outs[0] = dst;
+    } else {
+        bool in_place = (src == dst);
+        if ((rc = ensure_scratch(ctx, 0, bytes))) return rc;
+        uint4 *s0 = (uint4 *)ctx->scratch[0], *s1 = nullptr;
+        // walk backwards: pass P-1 -> dst, P-2 -> s0, P-3 -> dst (or s1 if that would clobber src)...
+        for (size_t i = 0; i < passes; i++) {
+            size_t from_end = passes - 1 - i;
+            outs[i] = (from_end % 2 == 0) ? dst : s0;
+        }
+        if (in_place && outs[0] == dst) {
+            // pass 0 would overwrite its own (strided) input: route passes 0 and 1 through s1/s0
+            if ((rc = ensure_scratch(ctx, 1, bytes))) return rc;
+            s1 = (uint4 *)ctx->scratch[1];
+            outs[0] = s1;   // then pass 1 -> s0, pass 2 -> dst, ... parity preserved
+        }
+    }
+
+    uint32_t log_l = 0;
+    const uint4 *cur = src;
+    Fr scale_d;
+    if (scale) scale_d = to_dev(*scale);
+    for (size_t i = 0; i < passes; i++) {
+        uint32_t log_r = radices[i];
+        PassArgs A;
+        A.src = cur;
+        A.dst = outs[i];
+        if ((rc = get_radix_table(ctx, omega, log_n, log_r, &A.rtw))) return rc;
+        A.tw = tw;
+        A.pre = (i == 0) ? pre_t : TwoLevel{nullptr, nullptr, 0};
+        A.post = (i + 1 == passes) ? post_t : TwoLevel{nullptr, nullptr, 0};
+        A.nnz = (i == 0) ? nnz : (1ull << log_n);
+        A.log_n = log_n;
+        A.log_r = log_r;
+        uint32_t log_c = ctx->tile_log > log_r ? ctx->tile_log - log_r : 0;
+        if (log_c > log_n - log_r) log_c = log_n - log_r;
+        A.log_c = log_c;
+        A.log_l = log_l;
+        A.apply_tw = (i == 0) ? 0 : 1;
+        A.tw_always = 0;
+        HIPCHK(ntt_launch_pass(stream, A, (scale && i + 1 == passes) ? &scale_d : nullptr, ctx->P));
+        cur = outs[i];
+        log_l += log_r;
+    }
+    return HODOR_OK;
+}
+
+static int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega)
+{
+    uint64_t sz;
+    uint32_t k;
+    if (log_n > 63 || !ctx->F.domain(1ull << log_n, &sz, &k, omega)) {
+        ctx->err = "domain too large for the field's 2-adicity";
+        return HODOR_ERR_SIZE;
+    }
+    return HODOR_OK;
+}
+
+enum PolyOp { OP_FFT, OP_COSET_FFT, OP_IFFT, OP_ICOSET_FFT };
+
+static int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
+                          uint32_t log_n, PolyOp op)
+{
+    HFr omega;
+    int rc = poly_domain(ctx, log_n, &omega);
+    if (rc) return rc;
+    uint64_t n = 1ull << log_n;
+    switch (op) {
+    case OP_FFT:
+        return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, nullptr, nullptr);
+    case OP_COSET_FFT:   // distribute_powers(g) then fft — src/polynomials/mod.rs:626-631
+        return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, &ctx->F.generator, nullptr);
+    case OP_IFFT:
+    case OP_ICOSET_FFT: {   // best_fft(omegainv) then * minv (then * geninv^i) — :773-807
+        HFr oinv, minv, ginv;
+        ctx->F.inverse(omega, &oinv);
+        ctx->F.inverse(ctx->F.from_u64(n), &minv);
+        ctx->F.inverse(ctx->F.generator, &ginv);
+        return ntt_exec(ctx, stream, src, dst, log_n, oinv, n, &minv, nullptr,
+                        op == OP_ICOSET_FFT ? &ginv : nullptr);
+    }
+    }
+    return HODOR_ERR_INVALID;
+}
+
+// lde / coset_lde: one zero-padded transform of size n*factor — identical output to the
+// reference's per-coset schedule (asserted by its own tests, src/polynomials/mod.rs:1026-1031)
+static int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
+                         uint32_t log_n, size_t factor, int coset)
+{
+    if (!is_pow2(factor)) { ctx->err = "lde factor must be a power of two"; return HODOR_ERR_SIZE; }
+    uint32_t log_big = log_n + log2u(factor);
+    HFr Omega;
+    int rc = poly_domain(ctx, log_big, &Omega);
+    if (rc) return rc;
+    return ntt_exec(ctx, stream, src, dst, log_big, Omega, 1ull << log_n, nullptr,
+                    coset ? &ctx->F.generator : nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device,
+                                hodor_ctx **out)
+{
+    if (!modulus || !out) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = new (std::nothrow) hodor_ctx();
+    if (!ctx) return HODOR_ERR_INVALID;
+    if (!ctx->F.init(modulus, generator)) { delete ctx; return HODOR_ERR_INVALID; }
+    for (int i = 0; i < 4; i++) {
+        ctx->P.p[2 * i] = (uint32_t)ctx->F.p[i];
+        ctx->P.p[2 * i + 1] = (uint32_t)(ctx->F.p[i] >> 32);
+    }
+    ctx->P.pinv = (uint32_t)ctx->F.pinv;
+    Fr one = to_dev(ctx->F.one);
+    for (int i = 0; i < 8; i++) ctx->P.one[i] = one.v[i];
+    // BASE_BLAKE2S_PARAMS, src/iop/blake2s_trivial_iop.rs:8-16
+    HostBlake2s::keyed_midstate(ctx->mid.h, (const uint8_t *)"Squeamish Ossifrage", 19,
+                                (const uint8_t *)"Shaftoe", 7);
+    ctx->device = device;
+    if (device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device >= count ||
+            hipSetDevice(device) != hipSuccess ||
+            hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return HODOR_ERR_DEVICE;
+        }
+        const char *e = getenv("HODOR_MAX_LOG_R");
+        if (e && atoi(e) >= 2 && atoi(e) <= 11) ctx->max_log_r = (uint32_t)atoi(e);
+        e = getenv("HODOR_TILE_LOG");
+        if (e && atoi(e) >= 6 && atoi(e) <= 12) ctx->tile_log = (uint32_t)atoi(e);
+        if (ctx->max_log_r > ctx->tile_log) ctx->max_log_r = ctx->tile_log;
+    }
+    *out = ctx;
+    return HODOR_OK;
+}
+
+extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        for (auto &t : ctx->pow_tables) { (void)hipFree(t.lo); (void)hipFree(t.hi); }
+        for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
+        for (int i = 0; i < 2; i++)
+            if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+extern "C" int hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out)
+{
+    if (!ctx || !out) return HODOR_ERR_INVALID;
+    memcpy(out->modulus, ctx->F.p, 32);
+    out->s = ctx->F.s;
+    out->num_bits = ctx->F.num_bits;
+    out->capacity = ctx->F.capacity;
+    from_h(ctx->F.one, &out->one);
+    from_h(ctx->F.generator, &out->generator);
+    from_h(ctx->F.root_of_unity, &out->root_of_unity);
+    return HODOR_OK;
+}
+
+extern "C" const char *hodor_last_error(const hodor_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" int hodor_ctx_synchronize(hodor_ctx *ctx)
+{
+    NEED_DEVICE();
+    HIPCHK(hipDeviceSynchronize());
+    return HODOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host scalar helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int hodor_fr_mul(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
+{
+    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.mul(to_h(a), to_h(b)), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_add(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
+{
+    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.add(to_h(a), to_h(b)), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_sub(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
+{
+    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.sub(to_h(a), to_h(b)), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_pow(const hodor_ctx *ctx, const hodor_fr *a, uint64_t e, hodor_fr *out)
+{
+    if (!ctx || !a || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.pow(to_h(a), e), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_inverse(const hodor_ctx *ctx, const hodor_fr *a, hodor_fr *out)
+{
+    if (!ctx || !a || !out) return HODOR_ERR_INVALID;
+    HFr r;
+    if (!ctx->F.inverse(to_h(a), &r)) return HODOR_ERR_INVALID;
+    from_h(r, out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_from_repr(const hodor_ctx *ctx, const uint64_t c[4], hodor_fr *out)
+{
+    if (!ctx || !c || !out) return HODOR_ERR_INVALID;
+    HFr r;
+    if (!ctx->F.from_repr(c, &r)) return HODOR_ERR_INVALID;
+    from_h(r, out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_into_repr(const hodor_ctx *ctx, const hodor_fr *a, uint64_t c[4])
+{
+    if (!ctx || !a || !c) return HODOR_ERR_INVALID;
+    ctx->F.into_repr(to_h(a), c);
+    return HODOR_OK;
+}
+
+extern "C" int hodor_domain_new_for_size(const hodor_ctx *ctx, uint64_t size, uint64_t *out_size,
+                                         uint32_t *out_log_n, hodor_fr *out_generator)
+{
+    if (!ctx || !out_size || !out_log_n || !out_generator) return HODOR_ERR_INVALID;
+    HFr g;
+    if (!ctx->F.domain(size, out_size, out_log_n, &g)) return HODOR_ERR_SIZE;
+    from_h(g, out_generator);
+    return HODOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device API
+// ------------------------------------------------------------------------------------------------
+extern "C" int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr)
+{
+    NEED_DEVICE();
+    if (!dev_ptr) return HODOR_ERR_INVALID;
+    HIPCHK(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return HODOR_OK;
+}
+extern "C" int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr)
+{
+    NEED_DEVICE();
+    HIPCHK(hipFree(dev_ptr));
+    return HODOR_OK;
+}
+extern "C" int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes)
+{
+    NEED_DEVICE();
+    HIPCHK(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return HODOR_OK;
+}
+extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
+{
+    NEED_DEVICE();
+    HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return HODOR_OK;
+}
+
+static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
+{
+    return stream ? (hipStream_t)stream : ctx->stream;
+}
+
+extern "C" int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                             uint32_t log_n, const hodor_fr *omega)
+{
+    NEED_DEVICE();
+    if (!src || !dst || !omega) return HODOR_ERR_INVALID;
+    if (log_n > ctx->F.s || log_n > 40) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, to_h(omega),
+                    1ull << log_n, nullptr, nullptr, nullptr);
+}
+
+static int poly_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n,
+                    PolyOp op)
+{
+    NEED_DEVICE();
+    if (!src || !dst) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_transform(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, op);
+}
+extern "C" int hodor_poly_fft_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst, uint32_t log_n)
+{ return poly_dev(ctx, s, src, dst, log_n, OP_FFT); }
+extern "C" int hodor_poly_ifft_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst, uint32_t log_n)
+{ return poly_dev(ctx, s, src, dst, log_n, OP_IFFT); }
+extern "C" int hodor_poly_coset_fft_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst, uint32_t log_n)
+{ return poly_dev(ctx, s, src, dst, log_n, OP_COSET_FFT); }
+extern "C" int hodor_poly_icoset_fft_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst, uint32_t log_n)
+{ return poly_dev(ctx, s, src, dst, log_n, OP_ICOSET_FFT); }
+
+extern "C" int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                                  uint32_t log_n, size_t factor, int coset)
+{
+    NEED_DEVICE();
+    if (!src || !dst) return HODOR_ERR_INVALID;
+    if (src == dst && factor != 1) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_lde_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, factor,
+                         coset);
+}
+
+extern "C" int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n,
+                                           const hodor_fr *g)
+{
+    NEED_DEVICE();
+    if (!a || !g) return HODOR_ERR_INVALID;
+    HIPCHK(distribute_powers_launch(pick_stream(ctx, stream), (uint4 *)a, n, to_dev(to_h(g)), ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n,
+                                    uint8_t *nodes)
+{
+    NEED_DEVICE();
+    if (!leafs || !nodes) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2) { ctx->err = "iop_create: n must be a power of two >= 2"; return HODOR_ERR_SIZE; }
+    HIPCHK(merkle_build_launch(pick_stream(ctx, stream), (const uint4 *)leafs, (uint4 *)nodes, n, ctx->mid));
+    return HODOR_OK;
+}
+
+extern "C" void hodor_fri_free(hodor_fri_proto *p)
+{
+    if (!p) return;
+    if (p->ctx && p->ctx->device >= 0) {
+        (void)hipSetDevice(p->ctx->device);
+        if (p->l0_nodes) (void)hipFree(p->l0_nodes);
+        for (void *q : p->inter_values) if (q) (void)hipFree(q);
+        for (void *q : p->inter_nodes) if (q) (void)hipFree(q);
+    }
+    delete p;
+}
+
+extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
+                                    size_t lde_factor, size_t out_deg, hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;
+    size_t initial_degree_plus_one = n / lde_factor;
+    if (initial_degree_plus_one < 2 * out_deg) {   // num_steps == 0: the reference panics at roots.pop() (:124)
+        ctx->err = "fri_commit: needs at least one folding step";
+        return HODOR_ERR_SIZE;
+    }
+    size_t num_steps = log2u(initial_degree_plus_one / out_deg);
+    if ((n >> num_steps) < 2) return HODOR_ERR_SIZE;
+    uint32_t log_n = log2u(n);
+    HFr omega, omega_inv;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = poly_domain(ctx, log_n, &omega);
+    if (rc) return rc;
+    ctx->F.inverse(omega, &omega_inv);
+    hipStream_t stream = pick_stream(ctx, stream_);
+
+    hodor_fri_proto *p = new (std::nothrow) hodor_fri_proto();
+    if (!p) return HODOR_ERR_INVALID;
+    p->ctx = ctx;
+    p->n = n;
+    p->num_steps = num_steps;
+    p->lde_factor = lde_factor;
+    p->out_deg = out_deg;
+    p->initial_degree_plus_one = initial_degree_plus_one;
+
+#define FRICHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);             \
+            hodor_fri_free(p);                                                         \
+            if (d_small) (void)hipFree(d_small);                                       \
+            return HODOR_ERR_DEVICE;                                                   \
+        }                                                                              \
+    } while (0)
+
+    // small device block: challenges [num_steps+1] | roots [num_steps+1] | final values/coeffs
+    uint8_t *d_small = nullptr;
+    size_t fin_n = n >> num_steps;
+    size_t small_bytes = 32 * (num_steps + 1) * 2 + 32 * fin_n * 2;
+    FRICHK(hipMalloc((void **)&d_small, small_bytes));
+    uint4 *d_chal = (uint4 *)d_small;
+    uint4 *d_roots = (uint4 *)(d_small + 32 * (num_steps + 1));
+    uint4 *d_fin = (uint4 *)(d_small + 64 * (num_steps + 1));
+
+    TwoLevel winv;
+    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv))) { hodor_fri_free(p); (void)hipFree(d_small); return rc; }
+    uint32_t shave = 256 - ctx->F.capacity;
+    Fr r2 = to_dev(ctx->F.r2);
+
+    FRICHK(hipMalloc(&p->l0_nodes, n * 32));
+    FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
+    FRICHK(challenge_launch(stream, (const uint4 *)p->l0_nodes, d_chal, r2, shave, ctx->P));             // :51
+    FRICHK(hipMemcpyAsync(d_roots, (const uint8_t *)p->l0_nodes + 32, 32, hipMemcpyDeviceToDevice, stream));
+
+    const uint4 *values = (const uint4 *)lde_values;
+    size_t next_size = n / 2;
+    for (size_t i = 0; i < num_steps; i++) {                                                             // :61
+        void *next = nullptr, *nodes = nullptr;
+        FRICHK(hipMalloc(&next, next_size * 32));
+        p->inter_values.push_back(next);
+        FRICHK(hipMalloc(&nodes, next_size * 32));
+        p->inter_nodes.push_back(nodes);
+        p->inter_sizes.push_back(next_size);
+        FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv, (uint32_t)i, d_chal + 2 * i,
+                               ctx->P));                                                                 // :70-104
+        FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid));   // :106
+        FRICHK(challenge_launch(stream, (const uint4 *)nodes, d_chal + 2 * (i + 1), r2, shave, ctx->P));
+        FRICHK(hipMemcpyAsync((uint8_t *)d_roots + 32 * (i + 1), (const uint8_t *)nodes + 32, 32,
+                              hipMemcpyDeviceToDevice, stream));
+        values = (const uint4 *)next;
+        next_size >>= 1;
+    }
+    // final: values -> ifft -> truncate (:130-145)
+    rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
+    if (rc) { hodor_fri_free(p); (void)hipFree(d_small); return rc; }
+
+    p->roots.resize(32 * (num_steps + 1));
+    p->challenges.resize(num_steps);
+    p->final_coeffs.resize(out_deg);
+    FRICHK(hipMemcpyAsync(p->roots.data(), d_roots, 32 * (num_steps + 1), hipMemcpyDeviceToHost, stream));
+    FRICHK(hipMemcpyAsync(p->challenges.data(), d_chal, 32 * num_steps, hipMemcpyDeviceToHost, stream));
+    FRICHK(hipMemcpyAsync(p->final_coeffs.data(), d_fin, 32 * out_deg, hipMemcpyDeviceToHost, stream));
+    FRICHK(hipStreamSynchronize(stream));
+    memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
+    (void)hipFree(d_small);
+#undef FRICHK
+    *out = p;
+    return HODOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slice API: host memory in, host memory out
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+// run `op` on a device copy of a[0..n_in) producing n_out elements back into `out`
+template <class Op>
+static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *out, size_t n_out, Op op)
+{
+    DevBuf din, dout;
+    HIPCHK(hipMalloc(&din.p, (n_in ? n_in : 1) * 32));
+    void *dptr_out = din.p;
+    if (n_out != n_in) {
+        HIPCHK(hipMalloc(&dout.p, (n_out ? n_out : 1) * 32));
+        dptr_out = dout.p;
+    }
+    HIPCHK(hipMemcpyAsync(din.p, in, n_in * 32, hipMemcpyHostToDevice, ctx->stream));
+    int rc = op((const uint4 *)din.p, (uint4 *)dptr_out);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HIPCHK(hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_fft(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *omega, uint32_t log_n)
+{
+    NEED_DEVICE();
+    if (!a || !omega) return HODOR_ERR_INVALID;
+    if (log_n > 40 || n != ((size_t)1 << log_n)) { ctx->err = "fft: n != 1 << log_n"; return HODOR_ERR_SIZE; }   // assert_eq at src/fft/fft.rs:34
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HFr w = to_h(omega);
+    return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
+        return ntt_exec(ctx, ctx->stream, s, d, log_n, w, n, nullptr, nullptr, nullptr);
+    });
+}
+
+extern "C" int hodor_lde(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *omega, uint32_t log_n,
+                         size_t lde_factor)
+{
+    NEED_DEVICE();
+    if (!a || !omega) return HODOR_ERR_INVALID;
+    if (log_n > 40 || n != ((size_t)1 << log_n) || !is_pow2(lde_factor) || lde_factor > n) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HFr w = to_h(omega);
+    return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
+        return ntt_exec(ctx, ctx->stream, s, d, log_n, w, n / lde_factor, nullptr, nullptr, nullptr);
+    });
+}
+
+extern "C" int hodor_distribute_powers(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *g)
+{
+    NEED_DEVICE();
+    if (!a || !g) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Fr gd = to_dev(to_h(g));
+    return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) -> int {
+        (void)s;
+        HIPCHK(distribute_powers_launch(ctx->stream, d, n, gd, ctx->P));
+        return HODOR_OK;
+    });
+}
+
+static int poly_slice(hodor_ctx *ctx, hodor_fr *a, size_t n, PolyOp op)
+{
+    NEED_DEVICE();
+    if (!a) return HODOR_ERR_INVALID;
+    if (!is_pow2(n)) { ctx->err = "polynomial size must be a power of two"; return HODOR_ERR_SIZE; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint32_t log_n = log2u(n);
+    return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
+        return poly_transform(ctx, ctx->stream, s, d, log_n, op);
+    });
+}
+extern "C" int hodor_poly_fft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_FFT); }
+extern "C" int hodor_poly_coset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_COSET_FFT); }
+extern "C" int hodor_poly_ifft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_IFFT); }
+extern "C" int hodor_poly_icoset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_ICOSET_FFT); }
+
+static int poly_lde_slice(hodor_ctx *ctx, const hodor_fr *coeffs, size_t n, size_t factor, hodor_fr *out,
+                          int coset)
+{
+    NEED_DEVICE();
+    if (!coeffs || !out) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || !is_pow2(factor)) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint32_t log_n = log2u(n);
+    return with_device_copy(ctx, coeffs, n, out, n * factor, [&](const uint4 *s, uint4 *d) {
+        return poly_lde_exec(ctx, ctx->stream, s, d, log_n, factor, coset);
+    });
+}
+extern "C" int hodor_poly_lde(hodor_ctx *ctx, const hodor_fr *c, size_t n, size_t f, hodor_fr *out)
+{ return poly_lde_slice(ctx, c, n, f, out, 0); }
+extern "C" int hodor_poly_coset_lde(hodor_ctx *ctx, const hodor_fr *c, size_t n, size_t f, hodor_fr *out)
+{ return poly_lde_slice(ctx, c, n, f, out, 1); }
+
+extern "C" int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n, uint8_t *nodes)
+{
+    NEED_DEVICE();
+    if (!leafs || !nodes) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2) { ctx->err = "iop_create: n must be a power of two >= 2"; return HODOR_ERR_SIZE; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DevBuf dl, dn;
+    HIPCHK(hipMalloc(&dl.p, n * 32));
+    HIPCHK(hipMalloc(&dn.p, n * 32));
+    HIPCHK(hipMemcpyAsync(dl.p, leafs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(merkle_build_launch(ctx->stream, (const uint4 *)dl.p, (uint4 *)dn.p, n, ctx->mid));
+    HIPCHK(hipMemcpyAsync(nodes, dn.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_challenge(const hodor_ctx *ctx, const uint8_t root[32], hodor_fr *out)
+{
+    if (!ctx || !root || !out) return HODOR_ERR_INVALID;
+    uint64_t repr[4];
+    for (int i = 0; i < 4; i++) {   // read_be
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) w = (w << 8) | root[8 * i + b];
+        repr[3 - i] = w;
+    }
+    uint32_t shave = 256 - ctx->F.capacity;
+    repr[3] &= 0xffffffffffffffffull >> (shave % 64);
+    HFr r;
+    if (!ctx->F.from_repr(repr, &r)) return HODOR_ERR_INVALID;   // "in a field" expect
+    from_h(r, out);
+    return HODOR_OK;
+}
+
+static void host_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32])
+{
+    HostBlake2s::finish(ctx->mid.h, (const uint8_t *)leaf->l, 32, out);   // LE limbs == memory image
+}
+static void host_hash_node(const hodor_ctx *ctx, const uint8_t *l, const uint8_t *r, uint8_t out[32])
+{
+    uint8_t buf[64];
+    memcpy(buf, l, 32);
+    memcpy(buf + 32, r, 32);
+    HostBlake2s::finish(ctx->mid.h, buf, 64, out);
+}
+
+extern "C" int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
+                              size_t tree_index, uint8_t *path, size_t *path_len)
+{
+    if (!ctx || !nodes || !leafs || !path || !path_len) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2 || tree_index >= n) return HODOR_ERR_SIZE;
+    size_t cnt = 0;
+    host_hash_leaf(ctx, &leafs[tree_index ^ 1], path);
+    cnt++;
+    size_t idx = tree_index >> 1;
+    for (size_t w = n / 2; w >= 2; w /= 2) {
+        memcpy(path + 32 * cnt, nodes + 32 * (w + (idx ^ 1)), 32);
+        cnt++;
+        idx >>= 1;
+    }
+    *path_len = cnt;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *leaf,
+                                const uint8_t *path, size_t path_len, size_t tree_index, int *ok)
+{
+    if (!ctx || !root || !leaf || (!path && path_len) || !ok) return HODOR_ERR_INVALID;
+    uint8_t h[32], t[32];
+    host_hash_leaf(ctx, leaf, h);
+    size_t idx = tree_index;
+    for (size_t i = 0; i < path_len; i++) {
+        if ((idx & 1) == 0) host_hash_node(ctx, h, path + 32 * i, t);
+        else host_hash_node(ctx, path + 32 * i, h, t);
+        memcpy(h, t, 32);
+        idx >>= 1;
+    }
+    *ok = memcmp(h, root, 32) == 0;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                                size_t out_deg, hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
+    DevBuf dv;
+    HIPCHK(hipMalloc(&dv.p, n * 32));
+    HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
+    return hodor_fri_commit_dev(ctx, nullptr, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
+}
+
+extern "C" size_t hodor_fri_num_steps(const hodor_fri_proto *p) { return p ? p->num_steps : 0; }
+
+extern "C" int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots)
+{
+    if (!p || !roots) return HODOR_ERR_INVALID;
+    memcpy(roots, p->roots.data(), p->roots.size());
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_final_root(const hodor_fri_proto *p, uint8_t root[32])
+{
+    if (!p || !root) return HODOR_ERR_INVALID;
+    memcpy(root, p->final_root, 32);
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_challenges(const hodor_fri_proto *p, hodor_fr *c)
+{
+    if (!p || !c) return HODOR_ERR_INVALID;
+    memcpy(c, p->challenges.data(), 32 * p->num_steps);
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_final_coefficients(const hodor_fri_proto *p, hodor_fr *c)
+{
+    if (!p || !c) return HODOR_ERR_INVALID;
+    memcpy(c, p->final_coeffs.data(), 32 * p->out_deg);
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_intermediate_values(hodor_fri_proto *p, size_t step, hodor_fr *values)
+{
+    if (!p || !values || step >= p->num_steps) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = p->ctx;
+    NEED_DEVICE();
+    HIPCHK(hipMemcpy(values, p->inter_values[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes)
+{
+    if (!p || !nodes || step < -1 || step >= (int)p->num_steps) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = p->ctx;
+    NEED_DEVICE();
+    if (step < 0) HIPCHK(hipMemcpy(nodes, p->l0_nodes, p->n * 32, hipMemcpyDeviceToHost));
+    else HIPCHK(hipMemcpy(nodes, p->inter_nodes[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
+    return HODOR_OK;
+}
+
+extern "C" size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap)
+{
+    if (!p) return 0;
+    size_t need = 8 + 32 * (p->num_steps + 1) + 32 * p->num_steps + 32 + 8 + 32 * p->out_deg;
+    if (!buf || cap < need) return need;
+    size_t o = 0;
+    uint64_t ns = p->num_steps, nf = p->out_deg;
+    memcpy(buf + o, &ns, 8); o += 8;                                   // little-endian host
+    memcpy(buf + o, p->roots.data(), p->roots.size()); o += p->roots.size();
+    memcpy(buf + o, p->challenges.data(), 32 * p->num_steps); o += 32 * p->num_steps;
+    memcpy(buf + o, p->final_root, 32); o += 32;
+    memcpy(buf + o, &nf, 8); o += 8;
+    memcpy(buf + o, p->final_coeffs.data(), 32 * p->out_deg); o += 32 * p->out_deg;
+    return o;
+}

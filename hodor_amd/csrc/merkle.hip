@@ -1,0 +1,212 @@
+// merkle.hip — K6/K8: keyed BLAKE2s leaf hashing + Merkle tree build, root -> field challenge.
+//
+// Replaces (paths relative to /root/reference):
+//   Blake2sLeafEncoder::encode_leaf / Blake2sTreeHasher::{hash_leaf,hash_node}
+//                                                   src/iop/blake2s_trivial_iop.rs:36-42, 81-104
+//   Blake2sIopTree::create                          src/iop/blake2s_trivial_iop.rs:131-219
+//   interpret_hash / get_challenge_scalar_from_root src/iop/blake2s_trivial_iop.rs:48-60, 226-234
+//
+// BLAKE2s-256, key "Squeamish Ossifrage", personal "Shaftoe" (:8-16).  The keyed first block is the
+// same for every hash, so its chaining value (the "midstate") is computed once on the host and passed
+// as a kernel argument: each leaf/node hash is ONE compression here instead of the CPU path's two.
+// Leaf bytes are the 32 bytes of the Montgomery limbs as they sit in memory (little-endian host).
+//
+// Tree layout = the reference's heap array: nodes[1] root, level l at nodes[2^l .. 2^(l+1)),
+// nodes[0] unused (zeroed), leaf hashes are not stored.
+//
+// 32-bit ARX integer work: no MFMA.  One hash per lane, all 16 state words + 16 message words in
+// VGPRs, sigma schedule resolved at compile time.
+#include "fr.cuh"
+
+namespace hodor {
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n)
+{
+    return __builtin_rotateright32(x, n);
+}
+
+#define B2S_G(a, b, c, d, x, y)                                   \
+    do {                                                          \
+        a = a + b + (x); d = rotr32(d ^ a, 16);                   \
+        c = c + d;       b = rotr32(b ^ c, 12);                   \
+        a = a + b + (y); d = rotr32(d ^ a, 8);                    \
+        c = c + d;       b = rotr32(b ^ c, 7);                    \
+    } while (0)
+
+#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    do {                                                                                  \
+        B2S_G(v0, v4, v8, v12, m[s0], m[s1]);                                             \
+        B2S_G(v1, v5, v9, v13, m[s2], m[s3]);                                             \
+        B2S_G(v2, v6, v10, v14, m[s4], m[s5]);                                            \
+        B2S_G(v3, v7, v11, v15, m[s6], m[s7]);                                            \
+        B2S_G(v0, v5, v10, v15, m[s8], m[s9]);                                            \
+        B2S_G(v1, v6, v11, v12, m[s10], m[s11]);                                          \
+        B2S_G(v2, v7, v8, v13, m[s12], m[s13]);                                           \
+        B2S_G(v3, v4, v9, v14, m[s14], m[s15]);                                           \
+    } while (0)
+
+// One final-block compression on top of the key-block midstate.  `t` = total bytes incl. the
+// 64-byte key block (96 for a leaf, 128 for a node).
+__device__ __forceinline__ void b2s_final(const B2Mid &mid, const uint32_t m[16], uint32_t t,
+                                          uint32_t out[8])
+{
+    uint32_t v0 = mid.h[0], v1 = mid.h[1], v2 = mid.h[2], v3 = mid.h[3];
+    uint32_t v4 = mid.h[4], v5 = mid.h[5], v6 = mid.h[6], v7 = mid.h[7];
+    uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+    uint32_t v12 = 0x510E527Fu ^ t, v13 = 0x9B05688Cu, v14 = ~0x1F83D9ABu, v15 = 0x5BE0CD19u;
+    B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    B2S_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3);
+    B2S_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4);
+    B2S_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8);
+    B2S_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13);
+    B2S_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9);
+    B2S_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11);
+    B2S_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10);
+    B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5);
+    B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0);
+    out[0] = mid.h[0] ^ v0 ^ v8;  out[1] = mid.h[1] ^ v1 ^ v9;
+    out[2] = mid.h[2] ^ v2 ^ v10; out[3] = mid.h[3] ^ v3 ^ v11;
+    out[4] = mid.h[4] ^ v4 ^ v12; out[5] = mid.h[5] ^ v5 ^ v13;
+    out[6] = mid.h[6] ^ v6 ^ v14; out[7] = mid.h[7] ^ v7 ^ v15;
+}
+
+// hash of one 32-byte leaf (message words 8..15 are zero and fold away at compile time)
+__device__ __forceinline__ void b2s_leaf(const B2Mid &mid, const uint4 &lo, const uint4 &hi,
+                                         uint32_t out[8])
+{
+    uint32_t m[16] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0, 0, 0, 0, 0, 0, 0, 0};
+    b2s_final(mid, m, 96, out);
+}
+
+__device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], const uint32_t r[8],
+                                         uint32_t out[8])
+{
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { m[i] = l[i]; m[8 + i] = r[i]; }
+    b2s_final(mid, m, 128, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_leaf_level: thread g hashes leaves 2g, 2g+1 and their parent -> nodes[n/2 + g].
+// Lane g reads 64 contiguous bytes; a wave reads 4 KiB contiguous.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_leaf_level(const uint4 *leafs, uint4 *nodes, uint64_t n, B2Mid mid)
+{
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t half = n >> 1;
+    if (g >= half) return;
+    const uint4 *p = leafs + 4 * g;
+    uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+    uint32_t hl[8], hr[8], out[8];
+    b2s_leaf(mid, a0, a1, hl);
+    b2s_leaf(mid, b0, b1, hr);
+    b2s_node(mid, hl, hr, out);
+    uint4 *o = nodes + 2 * (half + g);
+    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// k_node_level: nodes[width + g] = H(nodes[2*(width+g)] || nodes[2*(width+g)+1]),  g < width
+__global__ void __launch_bounds__(256)
+k_node_level(uint4 *nodes, uint64_t width, B2Mid mid)
+{
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= width) return;
+    const uint4 *p = nodes + 4 * (width + g);
+    uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+    uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    uint32_t out[8];
+    b2s_node(mid, l, r, out);
+    uint4 *o = nodes + 2 * (width + g);
+    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// k_tree_top: one workgroup finishes the tree from level `width` (<= 1024 nodes already written)
+// down to the root, level by level through global memory within the same workgroup (the data is
+// tiny; the point is to avoid ~10 dependent kernel launches).  Also zeroes nodes[0].
+__global__ void __launch_bounds__(256)
+k_tree_top(uint4 *nodes, uint32_t width, B2Mid mid)
+{
+    __shared__ uint4 lvl[2 * 2048];   // digests of the current level (<= 2048), 32 B each
+    const uint32_t tid = threadIdx.x;
+    // load level `2*width` (the children of the first level we compute)
+    uint32_t cw = 2 * width;
+    for (uint32_t i = tid; i < 2 * cw; i += 256) lvl[i] = nodes[2 * cw + i];
+    if (tid == 0) { nodes[0] = make_uint4(0, 0, 0, 0); nodes[1] = make_uint4(0, 0, 0, 0); }
+    __syncthreads();
+    for (uint32_t w = width; w >= 1; w >>= 1) {
+        uint32_t outs[4][8];
+        int cnt = 0;
+        for (uint32_t g = tid; g < w; g += 256, cnt++) {
+            uint4 a0 = lvl[4 * g], a1 = lvl[4 * g + 1], b0 = lvl[4 * g + 2], b1 = lvl[4 * g + 3];
+            uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            b2s_node(mid, l, r, outs[cnt]);
+        }
+        __syncthreads();
+        cnt = 0;
+        for (uint32_t g = tid; g < w; g += 256, cnt++) {
+            uint4 o0 = make_uint4(outs[cnt][0], outs[cnt][1], outs[cnt][2], outs[cnt][3]);
+            uint4 o1 = make_uint4(outs[cnt][4], outs[cnt][5], outs[cnt][6], outs[cnt][7]);
+            lvl[2 * g] = o0; lvl[2 * g + 1] = o1;
+            nodes[2 * (w + g)] = o0; nodes[2 * (w + g) + 1] = o1;
+        }
+        __syncthreads();
+    }
+}
+
+// K8: root digest -> field challenge (interpret_hash): big-endian read, clear the top
+// 256 - CAPACITY bits, convert to Montgomery form (multiply by R^2).
+__global__ void k_challenge(const uint4 *nodes, uint4 *out, Fr r2, uint32_t shave_bits, FrParams P)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(nodes + 2);   // nodes[1]
+    Fr x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x.v[i] = __builtin_bswap32(d[7 - i]);   // byte-reverse 32 bytes
+    uint32_t s = shave_bits & 63;   // the reference shifts a 64-bit mask by SHAVE_BITS % 64
+    uint64_t mask = ~0ull >> s;
+    x.v[7] &= (uint32_t)(mask >> 32);
+    x.v[6] &= (uint32_t)mask;
+    Fr m = fr_mul(x, r2, P);
+    fr_store(out, m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t TREE_TOP_WIDTH = 512;   // k_tree_top computes levels of width <= this
+
+hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,
+                               const B2Mid &mid)
+{
+    // n >= 2, power of two (checked by the caller)
+    uint64_t half = n >> 1;
+    hipLaunchKernelGGL(k_leaf_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, leafs,
+                       nodes, n, mid);
+    uint64_t w = half >> 1;
+    for (; w > TREE_TOP_WIDTH; w >>= 1)
+        hipLaunchKernelGGL(k_node_level, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, s, nodes, w,
+                           mid);
+    if (w >= 1) {
+        hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(256), 0, s, nodes, (uint32_t)w, mid);
+    } else {
+        // n == 2: the leaf level already wrote the root at nodes[1]; zero nodes[0]
+        hipError_t e = hipMemsetAsync(nodes, 0, 32, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+hipError_t challenge_launch(hipStream_t s, const uint4 *nodes, uint4 *out, const Fr &r2,
+                            uint32_t shave_bits, const FrParams &P)
+{
+    hipLaunchKernelGGL(k_challenge, dim3(1), dim3(64), 0, s, nodes, out, r2, shave_bits, P);
+    return hipGetLastError();
+}
+
+}  // namespace hodor

@@ -1,0 +1,37 @@
+// ntt.cuh — shared declarations for the NTT pass kernels (K2/K3/K4/K5).
+#pragma once
+#include "fr.cuh"
+
+namespace hodor {
+
+// Power tables for one (omega, log_n) pair, all in device memory, Montgomery form.
+//   lo[j]  = omega^j                 j < 2^lo_bits
+//   hi[j]  = scale * omega^(j << lo_bits)   j < 2^(log_n - lo_bits)     (scale folds n^-1 for iNTT)
+//   hi1[j] = omega^(j << lo_bits)    (unscaled copy; == hi when scale == 1)
+// so omega^e = lo[e & mask] * hi1[e >> lo_bits] with one extra product (or none when the low part
+// of e is known to be zero).  The reference recomputes twiddles by running products
+// (src/fft/fft.rs:58) or tabulates all n of them (src/precomputations/mod.rs:14-66); a two-level
+// table keeps the working set L2-resident instead of streaming n x 32 B from HBM.
+struct TwoLevel {
+    const uint4 *lo;
+    const uint4 *hi;
+    uint32_t lo_bits;
+};
+
+struct PassArgs {
+    const uint4 *src;        // n elements (only the first nnz are read; the rest are implicit zeros)
+    uint4 *dst;              // n elements
+    const uint4 *rtw;        // omega_R^e, e < R/2  (R = radix of this pass)
+    TwoLevel tw;             // inter-pass twiddles (powers of the size-n omega; hi possibly scaled)
+    TwoLevel pre;            // optional input scaling x[i] *= g^i  (coset shift), lo == nullptr if unused
+    TwoLevel post;           // optional output scaling X[k] *= h^k, lo == nullptr if unused
+    uint64_t nnz;            // number of leading non-zero inputs (== n unless LDE zero padding)
+    uint32_t log_n;          // transform size
+    uint32_t log_r;          // radix of this pass (R = 2^log_r points per sub-transform)
+    uint32_t log_c;          // tile columns (C consecutive sub-transforms per workgroup)
+    uint32_t log_l;          // product of the radices of the previous passes (L = 2^log_l)
+    uint32_t apply_tw;       // 0: no inter-pass twiddle (first pass)  1: lo*hi  2: hi only
+    uint32_t tw_always;      // 1: multiply even when the exponent is 0 (hi carries the iNTT scale)
+};
+
+}  // namespace hodor

@@ -1,0 +1,162 @@
+/*
+ * hodor_gpu.h — C ABI of the MI355X-native NTT / LDE / Merkle-commit / FRI-commit path.
+ *
+ * This is the drop-in boundary for matter-labs/hodor's prover: the reference has no FFI seam of its
+ * own (one Rust crate, monomorphised over F: PrimeField), so the exports below are exactly the L2/L3
+ * functions its upper layers (src/arp, src/ali, src/prover, src/fri) call, re-expressed as
+ * `extern "C"` over plain pointers and sizes.  Each export cites the Rust item it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Element type: `hodor_fr` is the memory image of Rust `Fr(FrRepr([u64; 4]))` — Montgomery form,
+ * R = 2^256, limb 0 least significant, value in [0, p) (src/bn256.rs:4-7, ff_ce derive).  A Rust
+ * `&mut [Fr]` maps to `(ptr as *mut hodor_fr, len)`.
+ *
+ * Two families:
+ *   - slice API (host pointers, synchronous): copies in, runs the HIP kernels, copies out.
+ *   - `_dev` API (device pointers + a hipStream_t passed as void*): stream-ordered, no host copies;
+ *     this is what the benchmarks and a device-resident prover use.
+ * All entry points return an int status and never throw or abort across the boundary.  There is no
+ * CPU fallback: without a usable HIP device every compute entry point returns HODOR_ERR_DEVICE.
+ */
+#ifndef HODOR_GPU_H
+#define HODOR_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } hodor_fr;
+typedef struct hodor_ctx hodor_ctx;
+typedef struct hodor_fri_proto hodor_fri_proto;
+
+enum {
+    HODOR_OK = 0,
+    HODOR_ERR_SIZE = 1,     /* non power of two, n != 1<<log_n, log_n > S ...   (SynthesisError::Error, src/domains/mod.rs:30-32; asserts at src/fft/fft.rs:34, src/iop/blake2s_trivial_iop.rs:137) */
+    HODOR_ERR_INVALID = 2,  /* null pointer / unsupported modulus / non-invertible element */
+    HODOR_ERR_DEVICE = 3    /* HIP runtime error or no device */
+};
+
+typedef struct {
+    uint64_t modulus[4];
+    uint32_t s;               /* F::S  (2-adicity)           */
+    uint32_t num_bits;        /* F::NUM_BITS                 */
+    uint32_t capacity;        /* F::CAPACITY                 */
+    hodor_fr one;             /* F::one()  = R mod p         */
+    hodor_fr generator;       /* F::multiplicative_generator() */
+    hodor_fr root_of_unity;   /* F::root_of_unity()          */
+} hodor_field_info;
+
+/* ---- context: the constants `#[derive(PrimeField)]` generates (src/bn256.rs:4-7,
+ * src/experiments/mod.rs:18-21) + device state (streams, twiddle cache, scratch).
+ * `modulus` must be an odd prime with 2^192 < p < 2^255 (4-limb ff_ce field, R = 2^256). */
+int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
+void hodor_ctx_destroy(hodor_ctx *ctx);
+int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
+const char *hodor_last_error(const hodor_ctx *ctx);
+int  hodor_ctx_synchronize(hodor_ctx *ctx);
+
+/* ---- scalar field helpers on the host (ff_ce Field/PrimeField methods the callers use to derive
+ * omegainv / minv / geninv, src/polynomials/mod.rs:146-166) */
+int hodor_fr_mul(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out);
+int hodor_fr_add(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out);
+int hodor_fr_sub(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out);
+int hodor_fr_pow(const hodor_ctx *ctx, const hodor_fr *a, uint64_t e, hodor_fr *out);
+int hodor_fr_inverse(const hodor_ctx *ctx, const hodor_fr *a, hodor_fr *out);
+int hodor_fr_from_repr(const hodor_ctx *ctx, const uint64_t canonical[4], hodor_fr *out);
+int hodor_fr_into_repr(const hodor_ctx *ctx, const hodor_fr *a, uint64_t canonical[4]);
+
+/* ---- Domain::new_for_size (src/domains/mod.rs:21-44) */
+int hodor_domain_new_for_size(const hodor_ctx *ctx, uint64_t size, uint64_t *out_size,
+                              uint32_t *out_log_n, hodor_fr *out_generator);
+
+/* ================================ slice API (host memory) ================================ */
+
+/* best_fft(a: &mut [F], worker, omega: &F, log_n, hint)  — src/fft/mod.rs:50, src/fft/fft.rs:5-19.
+ * In place, natural -> natural, A[k] = sum_i a[i] omega^(ik); omega is any element of order n. */
+int hodor_fft(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *omega, uint32_t log_n);
+/* best_lde(a, worker, omega, log_n, lde_factor) — src/fft/mod.rs:46, src/fft/lde.rs:4-13.
+ * Same output as hodor_fft when a[n/lde_factor..] is zero (which the callee assumes). */
+int hodor_lde(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *omega, uint32_t log_n,
+              size_t lde_factor);
+/* distribute_powers(coeffs, worker, g): a[i] *= g^i — src/fft/mod.rs:110-123 */
+int hodor_distribute_powers(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *g);
+
+/* Polynomial<F, Coefficients>::{fft, coset_fft} — src/polynomials/mod.rs:611-631 (n power of two) */
+int hodor_poly_fft(hodor_ctx *ctx, hodor_fr *a, size_t n);
+int hodor_poly_coset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n);
+/* Polynomial<F, Values>::{ifft, icoset_fft} — src/polynomials/mod.rs:773-807 */
+int hodor_poly_ifft(hodor_ctx *ctx, hodor_fr *a, size_t n);
+int hodor_poly_icoset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n);
+/* Polynomial::lde / coset_lde (-> lde_using_multiple_cosets / coset_lde_using_multiple_cosets)
+ * — src/polynomials/mod.rs:343, 349, 418-482, 544-609.  out has n*factor elements:
+ * out[idx] = P(Omega^idx)  resp.  P(g * Omega^idx), natural order on the size n*factor domain. */
+int hodor_poly_lde(hodor_ctx *ctx, const hodor_fr *coeffs, size_t n, size_t factor, hodor_fr *out);
+int hodor_poly_coset_lde(hodor_ctx *ctx, const hodor_fr *coeffs, size_t n, size_t factor,
+                         hodor_fr *out);
+
+/* IopTree::create + get_root — src/iop/blake2s_trivial_iop.rs:131-224.  nodes: n x 32 bytes, heap
+ * layout (root = nodes[32..64]).  n power of two, n >= 2. */
+int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n, uint8_t *nodes);
+/* encode_root_into_challenge / interpret_hash — :48-60, :226-234 (host) */
+int hodor_iop_challenge(const hodor_ctx *ctx, const uint8_t root[32], hodor_fr *out);
+/* get_path — :251-279 (host; path holds log2(n) digests, returns the count in *path_len) */
+int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
+                   size_t tree_index, uint8_t *path, size_t *path_len);
+/* verify — :236-249 (host); *ok = 1 when the path leads to root */
+int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *leaf,
+                     const uint8_t *path, size_t path_len, size_t tree_index, int *ok);
+
+/* FriIop::proof_from_lde (NaiveFriIop::proof_from_lde_by_values) — src/fri/fri_on_values.rs:11-159.
+ * The result mirrors FRIProofPrototype field for field (src/fri/mod.rs:106-117). */
+int  hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                      size_t output_coeffs_at_degree_plus_one, hodor_fri_proto **out);
+void hodor_fri_free(hodor_fri_proto *p);
+size_t hodor_fri_num_steps(const hodor_fri_proto *p);
+/* roots: l0 root followed by the intermediate roots -> (num_steps + 1) x 32 bytes (get_roots, src/fri/mod.rs:120-128) */
+int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots);
+int hodor_fri_final_root(const hodor_fri_proto *p, uint8_t root[32]);
+int hodor_fri_challenges(const hodor_fri_proto *p, hodor_fr *challenges /* num_steps */);
+int hodor_fri_final_coefficients(const hodor_fri_proto *p, hodor_fr *coeffs /* output_coeffs_at_degree_plus_one */);
+/* intermediate_values[step] (size n >> (step+1)) and the tree of step (-1 = l0 tree, size n) */
+int hodor_fri_intermediate_values(hodor_fri_proto *p, size_t step, hodor_fr *values);
+int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes);
+/* canonical prototype encoding (the reference defines none, README.md:44):
+ * u64le num_steps | roots | challenges | final_root | u64le n_final | final_coefficients.
+ * Returns the byte count; writes only when buf != NULL and cap is large enough. */
+size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap);
+
+/* ================================ device API (device memory) ============================== */
+/* `stream` is a hipStream_t (NULL = the context's own stream).  All work is enqueued in stream
+ * order; nothing synchronises with the host unless stated.  A context owns one scratch pool, so use
+ * one context per concurrently active stream. */
+int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr);
+int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr);
+int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
+/* out-of-place natural->natural NTT of size 1<<log_n with an arbitrary omega (src == dst allowed) */
+int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n,
+                  const hodor_fr *omega);
+/* Polynomial-level transforms on the canonical domain of size 1<<log_n */
+int hodor_poly_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
+int hodor_poly_ifft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
+int hodor_poly_coset_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
+int hodor_poly_icoset_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
+/* LDE: src has 1<<log_n coefficients, dst has (1<<log_n)*factor values; coset != 0 -> coset_lde */
+int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                       uint32_t log_n, size_t factor, int coset);
+int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
+/* Merkle tree over n device-resident leaves into n*32 device bytes */
+int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, uint8_t *nodes);
+/* FRI commit over a device-resident codeword; the prototype keeps its vectors/trees on the device */
+int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
+                         size_t lde_factor, size_t output_coeffs_at_degree_plus_one,
+                         hodor_fri_proto **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HODOR_GPU_H */

@@ -1,0 +1,87 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol the header
+declares, host-side helpers agree with the Python big-int restatement, and compute entry points
+refuse to run without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import hodor_amd
+from hodor_amd import _lib
+from oracle import pyref as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    hodor_amd.build()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "hodor_gpu.h")).read()
+    declared = set(re.findall(r"\b(hodor_[a-z0-9_]+)\s*\(", header))
+    declared -= {"hodor_fr", "hodor_ctx", "hodor_fri_proto", "hodor_field_info"}
+    assert declared == set(_lib.EXPORTS)
+    L = ctypes.CDLL(hodor_amd.lib_path())
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
+@pytest.mark.parametrize("F", [P.BN256, P.EXPERIMENTS], ids=["bn256", "experiments"])
+def test_host_field_constants_and_helpers(F):
+    ctx = hodor_amd.Context(F.p, F.g, device=-1)
+    assert ctx.S == F.S and ctx.num_bits == F.num_bits and ctx.capacity == F.capacity
+    assert ctx.one == F.R
+    assert ctx.generator == F.to_mont(F.g)
+    assert ctx.root_of_unity == F.to_mont(F.root_of_unity)
+    a, b = F.to_mont(0x1234567890ABCDEF1234567890ABCDEF % F.p), F.to_mont(F.p - 5)
+    assert ctx.mul(a, b) == F.to_mont(F.from_mont(a) * F.from_mont(b) % F.p)
+    assert ctx.add(a, b) == (a + b) % F.p
+    assert ctx.sub(a, b) == (a - b) % F.p
+    assert ctx.pow(a, 65537) == F.to_mont(pow(F.from_mont(a), 65537, F.p))
+    assert ctx.inverse(a) == F.to_mont(pow(F.from_mont(a), -1, F.p))
+    assert ctx.into_repr(ctx.from_repr(12345)) == 12345
+    with pytest.raises(hodor_amd.HodorError):
+        ctx.from_repr(F.p)          # from_repr rejects non-canonical input
+    with pytest.raises(hodor_amd.HodorError):
+        ctx.inverse(0)
+    for size in (1, 2, 3, 1000, 1 << 20, 1 << 30):
+        if size.bit_length() - 1 > F.S:
+            continue
+        w, k, sz = F.domain_generator(size)
+        assert ctx.domain(size) == (sz, k, F.to_mont(w))
+    if F.S < 40:
+        with pytest.raises(hodor_amd.HodorError) as e:
+            ctx.domain(1 << (F.S + 1))      # SynthesisError::Error, src/domains/mod.rs:30-32
+        assert e.value.code == _lib.ERR_SIZE
+    ctx.close()
+
+
+def test_host_iop_helpers_match_hashlib():
+    F = P.BN256
+    ctx = hodor_amd.Context(F.p, F.g, device=-1)
+    leafs = [F.to_mont(pow(3, i, F.p)) for i in range(16)]
+    nodes = P.iop_create(leafs)
+    arr = np.array([[(v >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in leafs], dtype=np.uint64)
+    nodes_np = np.frombuffer(b"".join(nodes), dtype=np.uint8).reshape(16, 32).copy()
+    assert ctx.iop_challenge(nodes[1]) == F.to_mont(P.interpret_hash(F, nodes[1]))
+    for idx in range(16):
+        path = ctx.iop_path(nodes_np, arr, idx)
+        assert [bytes(x) for x in path] == P.iop_path(nodes, leafs, idx)
+        assert ctx.iop_verify(nodes[1], leafs[idx], path, idx)
+        assert not ctx.iop_verify(nodes[1], leafs[idx] ^ 1, path, idx)
+    ctx.close()
+
+
+def test_no_cpu_fallback_without_device():
+    ctx = hodor_amd.Context(device=-1)
+    a = np.zeros((4, 4), dtype=np.uint64)
+    for call in (lambda: ctx.poly_fft(a), lambda: ctx.iop_create(a), lambda: ctx.poly_lde(a, 2),
+                 lambda: ctx.fri_commit(np.zeros((16, 4), dtype=np.uint64), 4, 1)):
+        with pytest.raises(hodor_amd.HodorError) as e:
+            call()
+        assert e.value.code == _lib.ERR_DEVICE
+    ctx.close()

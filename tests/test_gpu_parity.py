@@ -1,0 +1,277 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs — bit-exact (integer field arithmetic / byte hashes).  Mirrors the reference's own
+differential tests: radix-2 == radix-4 == GPU, LDE == FFT of zero-padded coefficients,
+forward∘inverse == identity, every Merkle path verifies, FRI by-values prototype equality.
+Nothing here reads /root/reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+from oracle.oracle import array_to_ints, ints_to_array
+
+pytestmark = pytest.mark.gpu
+
+PYF = {"bn256": P.BN256, "experiments": P.EXPERIMENTS}
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---------------------------------------------------------------- NTT (best_fft semantics)
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17])
+def test_fft_matches_oracle(gpu_ctxs, oracles, field_name, log_n):
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n = 1 << log_n
+    a = O.random_elements(n, 100 + log_n)
+    _, k, omega = O.domain(n)
+    exp = a.copy()
+    O.serial_fft(exp, omega, log_n)            # src/fft/fft.rs:21-66
+    got = a.copy()
+    ctx.fft(got, omega, log_n)
+    assert np.array_equal(got, exp)
+    if log_n % 2 == 0 and log_n >= 2:          # test_sequential_radix4_fft, src/fft/mod.rs:66-108
+        r4 = a.copy()
+        O.serial_fft_radix_4(r4, omega, log_n)
+        assert np.array_equal(got, r4)
+    if log_n <= 6:                             # definition
+        assert np.array_equal(got, O.naive_dft(a, omega))
+
+
+@pytest.mark.parametrize("log_n", [18, 20])
+def test_fft_large_matches_parallel_oracle(gpu_ctxs, oracles, log_n):
+    """config[0] size (2^20) on the bn256.rs field; oracle = restated parallel_fft (fft.rs:68-124)."""
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    a = O.random_elements(n, 7)
+    _, _, omega = O.domain(n)
+    exp = a.copy()
+    O.best_fft(exp, omega, log_n)
+    got = a.copy()
+    ctx.fft(got, omega, log_n)
+    assert _digest(got) == _digest(exp)
+
+
+def test_fft_arbitrary_omega_and_inverse_roundtrip(gpu_ctxs, oracles, field_name):
+    """test_worker_size (src/fft/mod.rs:281-328): forward then inverse * n^-1 == identity."""
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    for log_n in (5, 12, 15):
+        n = 1 << log_n
+        a = O.random_elements(n, 5)
+        _, _, omega = O.domain(n)
+        oinv = O.inverse(omega)
+        b = a.copy()
+        ctx.fft(b, omega, log_n)
+        ctx.fft(b, oinv, log_n)
+        exp = a.copy()
+        O.serial_fft(exp, omega, log_n)
+        O.serial_fft(exp, oinv, log_n)
+        assert np.array_equal(b, exp)
+        # omega^3 is also a generator of the order-n subgroup: "omega is any element"
+        w3 = O.pow(omega, 3)
+        c, e = a.copy(), a.copy()
+        ctx.fft(c, w3, log_n)
+        O.serial_fft(e, w3, log_n)
+        assert np.array_equal(c, e)
+
+
+def test_fft_rejects_bad_sizes(gpu_ctxs):
+    import hodor_amd
+    ctx = gpu_ctxs["bn256"]
+    a = np.zeros((12, 4), dtype=np.uint64)
+    with pytest.raises(hodor_amd.HodorError) as e:
+        ctx.fft(a, ctx.one, 4)                  # n != 1 << log_n  (assert_eq, src/fft/fft.rs:34)
+    assert e.value.code == 1
+    with pytest.raises(hodor_amd.HodorError):
+        ctx.poly_fft(a)                         # not a power of two
+    with pytest.raises(hodor_amd.HodorError):
+        ctx.iop_create(a)                       # src/iop/blake2s_trivial_iop.rs:137
+
+
+# ---------------------------------------------------------------- Polynomial transforms
+@pytest.mark.parametrize("log_n", [0, 1, 3, 8, 11, 12, 15])
+def test_poly_transforms(gpu_ctxs, oracles, field_name, log_n):
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n = 1 << log_n
+    a = O.random_elements(n, 31 + log_n)
+    for name in ("poly_fft", "poly_coset_fft", "poly_ifft", "poly_icoset_fft"):
+        exp, got = a.copy(), a.copy()
+        getattr(O, name)(exp)
+        getattr(ctx, name)(got)
+        assert np.array_equal(got, exp), name
+    # coset_fft then icoset_fft is the identity
+    b = a.copy()
+    ctx.poly_coset_fft(b)
+    ctx.poly_icoset_fft(b)
+    assert np.array_equal(b, a)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7 * 0 + 8, 1 << 10, 1 << 13])
+def test_distribute_powers(gpu_ctxs, oracles, field_name, n):
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    a = O.random_elements(n, 3)
+    g = O.const("generator")
+    exp, got = a.copy(), a.copy()
+    O.distribute_powers(exp, g)
+    ctx.distribute_powers(got, g)
+    assert np.array_equal(got, exp)
+
+
+# ---------------------------------------------------------------- LDE
+@pytest.mark.parametrize("log_n,factor", [(0, 2), (2, 16), (3, 1), (4, 8), (8, 8), (10, 4), (12, 8), (13, 16)])
+def test_lde_matches_oracle_and_padded_fft(gpu_ctxs, oracles, field_name, log_n, factor):
+    """test_lde_correctness / test_coset_lde_correctness (src/polynomials/mod.rs:988-1083)."""
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n = 1 << log_n
+    coeffs = O.random_elements(n, 77 + log_n)
+    for coset in (False, True):
+        exp = O.poly_lde(coeffs, factor, coset)      # multi-coset schedule, :418-482 / :544-609
+        got = ctx.poly_lde(coeffs, factor, coset)
+        assert np.array_equal(got, exp), coset
+    # best_lde (filtering_lde path, :355-368): in-place on the zero-padded vector
+    pad = np.zeros((n * factor, 4), dtype=np.uint64)
+    pad[:n] = coeffs
+    _, k, Omega = O.domain(n * factor)
+    exp = pad.copy()
+    O.serial_lde(exp, Omega, k, factor)              # src/fft/lde.rs:15-126
+    got = pad.copy()
+    ctx.lde(got, Omega, k, factor)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got, ctx.poly_lde(coeffs, factor))
+
+
+def test_lde_small_known_answer(gpu_ctxs):
+    """Tiny KAT from SURVEY.md Appendix A: NTT_4([1,2,3,4]) over the bn256.rs field."""
+    F, ctx = P.BN256, gpu_ctxs["bn256"]
+    a = ints_to_array([F.to_mont(v) for v in (1, 2, 3, 4)])
+    ctx.poly_fft(a)
+    got = [F.from_mont(v) for v in array_to_ints(a)]
+    assert got == [
+        0xA,
+        0x73EDA753299D7D4718963E6B1D9BCE637BB7A3FE13F85BFEFFFDFFFEFFFFFFFF,
+        0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFEFFFFFFFF,
+        0x11AA3999CEC0609A1D8060004EC0600000001FFFFFFFFFFFE,
+    ]
+
+
+# ---------------------------------------------------------------- Merkle / IOP
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 6, 9, 10, 11, 12, 13, 16])
+def test_iop_tree_matches_oracle(gpu_ctxs, oracles, field_name, log_n):
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n = 1 << log_n
+    leafs = O.random_elements(n, 900 + log_n)
+    exp = O.iop_create(leafs)                        # blake2s_trivial_iop.rs:131-219
+    got = ctx.iop_create(leafs)
+    assert np.array_equal(got, exp)
+    assert not got[0].any()                          # nodes[0] unused
+    root = bytes(got[1])
+    assert ctx.iop_challenge(root) == O.interpret_hash(root)
+    # make_small_iop (:390-409): every query verifies against the root
+    ints = array_to_ints(leafs)
+    for idx in ([0, 1, n - 1, n // 2] if n > 16 else range(n)):
+        path = ctx.iop_path(got, leafs, idx)
+        assert O.iop_verify(root, ints[idx], path, idx)
+        assert ctx.iop_verify(root, ints[idx], path, idx)
+
+
+def test_iop_tree_matches_hashlib(gpu_ctxs):
+    """Independent anchor: Python hashlib.blake2s(key, person) — SURVEY.md Appendix B values."""
+    F, ctx = P.BN256, gpu_ctxs["bn256"]
+    ones = ints_to_array([F.R] * 16)                 # make_small_tree (:377-387)
+    nodes = ctx.iop_create(ones)
+    assert bytes(nodes[1]).hex() == "661512723ab4cfa09bdd1aad0e9f1cc69356055f99a9528b016f35b8c5fe706b"
+    assert F.from_mont(ctx.iop_challenge(bytes(nodes[1]))) == \
+        0x261512723AB4CFA09BDD1AAD0E9F1CC69356055F99A9528B016F35B8C5FE706B
+    leafs = [F.to_mont(pow(5, i, F.p)) for i in range(64)]
+    nodes = ctx.iop_create(ints_to_array(leafs))
+    assert [bytes(x) for x in nodes[1:]] == P.iop_create(leafs)[1:]
+
+
+# ---------------------------------------------------------------- FRI commit phase
+@pytest.mark.parametrize("log_deg,lde_factor,out_deg", [(2, 4, 2), (3, 4, 1), (6, 8, 1), (8, 16, 2), (11, 8, 1), (13, 8, 4)])
+def test_fri_commit_matches_oracle(gpu_ctxs, oracles, field_name, log_deg, lde_factor, out_deg):
+    """proof_from_lde_by_values (src/fri/fri_on_values.rs:11-159): prototype equality field by field,
+    as test_one_fri_step asserts between its two CPU paths (src/fri/mod.rs:338-343)."""
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    coeffs = O.random_elements(1 << log_deg, 55 + log_deg)
+    lde = O.poly_lde(coeffs, lde_factor)
+    exp = O.fri_commit(lde, lde_factor, out_deg)
+    got = ctx.fri_commit(lde, lde_factor, out_deg)
+    assert got.num_steps == exp["num_steps"]
+    assert got.roots == exp["roots"]
+    assert got.challenges == exp["challenges"]
+    assert got.final_root == exp["final_root"]
+    assert np.array_equal(got.final_coeffs, exp["final_coeffs"])
+    assert got.serialized == exp["serialized"]       # "proof bytes identical to CPU"
+    n = len(lde)
+    for i in range(got.num_steps):
+        assert np.array_equal(got.intermediate_values(i, n >> (i + 1)), exp["inter_values"][i])
+    # through-coefficients cross-check (src/fri/mod.rs:194-203): final coefficients are the folded ones
+    F = PYF[field_name]
+    c = [F.from_mont(v) for v in array_to_ints(coeffs)]
+    for beta in exp["challenges"]:
+        c = P.fri_fold_coeffs(F, c, F.from_mont(beta))
+    assert [F.from_mont(v) for v in array_to_ints(got.final_coeffs)] == c[:out_deg]
+    got.free()
+
+
+def test_fri_commit_rejects_zero_steps(gpu_ctxs, oracles):
+    import hodor_amd
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    lde = O.poly_lde(O.random_elements(2, 1), 4)
+    with pytest.raises(hodor_amd.HodorError):
+        ctx.fri_commit(lde, 4, 2)                    # num_steps == 0: reference panics at roots.pop()
+
+
+# ---------------------------------------------------------------- device API at benchmark sizes
+def test_device_api_roundtrip_and_properties_2_24(gpu_ctxs, oracles):
+    """BASELINE config[1] size: properties that do not need a CPU transform of 2^24 points."""
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n = 24
+    n = 1 << log_n
+    host = O.random_elements(1 << 16, 1234)
+    a = torch.from_numpy(host.view(np.int64)).cuda().repeat(n >> 16, 1)      # periodic input
+    a[:, 0] += torch.arange(n, device="cuda", dtype=torch.int64) & 0xFFFF    # break the period (stays < p)
+    b = torch.empty_like(a)
+    c = torch.empty_like(a)
+    ctx.poly_fft_dev(a, b, log_n)
+    ctx.poly_ifft_dev(b, c, log_n)
+    ctx.synchronize()
+    assert torch.equal(a, c)                                                 # iNTT(NTT(x)) == x
+    # spot-check output points against direct evaluation X[k] = sum_i x[i] w^(ik) by the oracle
+    # (evaluate_at, src/polynomials/mod.rs:685-711) on a 2^20-point transform of the prefix
+    sub = 20
+    xs = a[: 1 << sub].cpu().numpy().view(np.uint64).copy()
+    bs = torch.empty((1 << sub, 4), dtype=torch.int64, device="cuda")
+    ctx.poly_fft_dev(a[: 1 << sub].contiguous(), bs, sub)
+    ctx.synchronize()
+    _, _, w = O.domain(1 << sub)
+    outs = bs.cpu().numpy().view(np.uint64)
+    for k in (0, 1, 12345, (1 << sub) - 1):
+        assert array_to_ints(outs[k:k + 1])[0] == O.evaluate_at(xs, O.pow(w, k))
+    # in-place call (src == dst) gives the same result as out-of-place
+    d = a.clone()
+    ctx.poly_fft_dev(d, d, log_n)
+    ctx.synchronize()
+    assert torch.equal(d, b)
+
+
+def test_device_lde_and_commit_consistency(gpu_ctxs, oracles):
+    """LDE x8 of 2^18 + Merkle on device == slice API == oracle root (scaled-down config[2])."""
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n, factor = 14, 8
+    n = 1 << log_n
+    coeffs = O.random_elements(n, 4242)
+    d_c = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    d_lde = torch.empty((n * factor, 4), dtype=torch.int64, device="cuda")
+    d_nodes = torch.empty((n * factor, 32), dtype=torch.uint8, device="cuda")
+    ctx.poly_lde_dev(d_c, d_lde, log_n, factor)
+    ctx.iop_create_dev(d_lde, n * factor, d_nodes)
+    ctx.synchronize()
+    lde = O.poly_lde(coeffs, factor)
+    assert np.array_equal(d_lde.cpu().numpy().view(np.uint64), lde)
+    assert np.array_equal(d_nodes.cpu().numpy(), O.iop_create(lde))

@@ -1,0 +1,159 @@
+"""CPU tests: pin the C oracle (oracle/hodor_oracle.c) against
+ (1) the committed golden vectors (tests/golden/hodor_golden.json — Python big-int + hashlib),
+ (2) the constants of SURVEY.md Appendix A/B,
+ (3) the reference's own differential identities, restated.
+Parity status: unpinned against the Rust binary (see oracle/hodor_oracle.h)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+from oracle.oracle import array_to_ints, ints_to_array
+
+PYF = {"bn256": P.BN256, "experiments": P.EXPERIMENTS}
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hodor_golden.json")))
+
+
+def h2i(xs):
+    return [int(x, 16) for x in xs]
+
+
+def mont_array(F, canon):
+    return ints_to_array([F.to_mont(v) for v in canon])
+
+
+def canon_list(F, arr):
+    return [F.from_mont(v) for v in array_to_ints(arr)]
+
+
+def test_field_constants_appendix_a(oracles):
+    O = oracles["bn256"]
+    assert O.one() == 0x1824B159ACC5056F998C4FEFECBC4FF55884B7FA0003480200000001FFFFFFFE
+    assert O.const("r2") == 0x0748D9D99F59FF1105D314967254398F2B6CEDCB87925C23C999E990F3F29C6D
+    assert O.f.pinv == 0xFFFFFFFEFFFFFFFF and O.f.s == 32
+    assert O.to_canonical(O.const("root_of_unity")) == \
+        0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B
+    assert O.to_canonical(O.domain(1 << 24)[2]) == \
+        0x291CF6D68823E6876E0BCD91EE76273072CF6A8029B7D7BC92CF4DEB77BD779C
+    assert O.to_canonical(O.domain(1 << 30)[2]) == \
+        0x2C6D4E4511657E1E1339A815DA8B398FED3A181FABB30ADC694341F608C9DD56
+    with pytest.raises(ValueError):
+        O.domain(1 << 33)                         # S = 32
+    E = oracles["experiments"]
+    assert E.one() == 0x07fffffffffffdf0ffffffffffffffffffffffffffffffffffffffffffffffe1
+    assert E.f.pinv == 0xFFFFFFFFFFFFFFFF and E.f.s == 192
+    assert E.to_canonical(E.const("root_of_unity")) == \
+        0x005282DB87529CFA3F0464519C8B0FA5AD187148E11A61616070024F42F8EF94
+
+
+def test_blake2s_against_hashlib(oracles):
+    import ctypes as C
+    O = oracles["bn256"]
+    for msg in (b"", b"abc", b"\x00" * 64, bytes(range(200))):
+        out = (C.c_uint8 * 32)()
+        O.L.o_blake2s(out, P.IOP_KEY, C.c_size_t(19), P.IOP_PERSONAL, C.c_size_t(7), msg, C.c_size_t(len(msg)))
+        assert bytes(out) == P.b2s(msg)
+    assert P.b2s(b"").hex() == GOLD["blake2s"]["h_empty"] == \
+        "a61dd261a9b23522c19ebdecc9b5755882c1b4f3940d3437029d99120ab1b437"   # Appendix B
+
+
+def test_make_small_tree_appendix_b(oracles):
+    for name, root, chal in (
+        ("bn256", "661512723ab4cfa09bdd1aad0e9f1cc69356055f99a9528b016f35b8c5fe706b",
+         0x261512723AB4CFA09BDD1AAD0E9F1CC69356055F99A9528B016F35B8C5FE706B),
+        ("experiments", "fdf489862b4402468d94f026c014e1ca0129f421a55ce5e1df838eab8eefbd22",
+         2693624083161027199676761339081382127720247941633710928972358601781283896610)):
+        O, F = oracles[name], PYF[name]
+        nodes = O.iop_create(ints_to_array([F.R] * 16))
+        assert bytes(nodes[1]).hex() == root == GOLD[name]["cases"]["make_small_tree"]["root"]
+        assert O.to_canonical(O.interpret_hash(bytes(nodes[1]))) == chal
+
+
+def test_oracle_vs_golden_transforms(oracles, field_name):
+    O, F, cases = oracles[field_name], PYF[field_name], GOLD[field_name]["cases"]
+    for key, c in cases.items():
+        if key.startswith("ntt_"):
+            a = mont_array(F, h2i(c["input"]))
+            for name in ("fft", "ifft", "coset_fft", "icoset_fft"):
+                b = a.copy()
+                getattr(O, "poly_" + name)(b)
+                assert canon_list(F, b) == h2i(c[name]), (key, name)
+        elif key.startswith("lde_"):
+            a = mont_array(F, h2i(c["input"]))
+            assert canon_list(F, O.poly_lde(a, c["factor"])) == h2i(c["lde"])
+            assert canon_list(F, O.poly_lde(a, c["factor"], coset=True)) == h2i(c["coset_lde"])
+
+
+def test_oracle_vs_golden_merkle_and_fri(oracles, field_name):
+    O, F, cases = oracles[field_name], PYF[field_name], GOLD[field_name]["cases"]
+    for key, c in cases.items():
+        if key.startswith("merkle_"):
+            leafs = ints_to_array(h2i(c["leafs_mont"]))
+            nodes = O.iop_create(leafs)
+            assert [bytes(x).hex() for x in nodes[1:]] == c["nodes"][1:]
+            assert O.to_canonical(O.interpret_hash(bytes(nodes[1]))) == int(c["challenge"], 16)
+            n = len(leafs)
+            assert [bytes(x).hex() for x in O.iop_path(nodes, leafs, 3 % n)] == c["path_3"]
+        elif key.startswith("fri_"):
+            coeffs = mont_array(F, h2i(c["coeffs"]))
+            lde = O.poly_lde(coeffs, c["lde_factor"])
+            r = O.fri_commit(lde, c["lde_factor"], c["out_deg_plus_one"])
+            assert r["serialized"].hex() == c["serialized"]
+            assert [x.hex() for x in r["roots"]] == c["roots"]
+            assert [O.to_canonical(x) for x in r["challenges"]] == h2i(c["challenges"])
+
+
+@pytest.mark.parametrize("log_n", [2, 4, 6, 10, 12])
+def test_reference_differential_identities(oracles, field_name, log_n):
+    """radix-2 == radix-4 == parallel == naive DFT (src/fft/mod.rs:66-184); thread-count independence
+    (test_worker_size :281-328); multi-coset LDE == filtering LDE == FFT of padded
+    (src/polynomials/mod.rs:988-1130)."""
+    O = oracles[field_name]
+    n = 1 << log_n
+    a = O.random_elements(n, log_n)
+    _, k, w = O.domain(n)
+    r2 = a.copy(); O.serial_fft(r2, w, k)
+    r4 = a.copy(); O.serial_fft_radix_4(r4, w, k)
+    assert np.array_equal(r2, r4)
+    for log_cpus in (1, 2):
+        pf = a.copy(); O.parallel_fft(pf, w, k, log_cpus)
+        assert np.array_equal(r2, pf)
+    for cpus in (1, 3, 16):
+        bf = a.copy(); O.best_fft(bf, w, k, cpus)
+        assert np.array_equal(r2, bf)
+    if log_n <= 6:
+        assert np.array_equal(r2, O.naive_dft(a, w))
+    inv = r2.copy(); O.poly_ifft(inv)
+    assert np.array_equal(inv, a)
+    for factor in (2, 8):
+        lde = O.poly_lde(a, factor)
+        pad = np.zeros((n * factor, 4), dtype=np.uint64); pad[:n] = a
+        _, K, W = O.domain(n * factor)
+        f1 = pad.copy(); O.serial_fft(f1, W, K)
+        f2 = pad.copy(); O.serial_lde(f2, W, K, factor)
+        assert np.array_equal(lde, f1) and np.array_equal(lde, f2)
+        # coset LDE evaluates at g * Omega^idx
+        clde = O.poly_lde(a, factor, coset=True)
+        g = O.const("generator")
+        for idx in (0, 1, n * factor - 1):
+            pt = O.mul(g, O.pow(W, idx))
+            assert array_to_ints(clde[idx:idx + 1])[0] == O.evaluate_at(a, pt)
+
+
+def test_fri_by_values_equals_through_coefficients(oracles, field_name):
+    """test_one_fri_step / test_fri_on_values_vs_on_coefficients (src/fri/mod.rs:252-361, :510-692):
+    every intermediate vector equals the LDE of the folded coefficients a_2i + beta*a_2i+1."""
+    O, F = oracles[field_name], PYF[field_name]
+    deg, f, outd = 64, 4, 2
+    coeffs = O.random_elements(deg, 99)
+    lde = O.poly_lde(coeffs, f)
+    r = O.fri_commit(lde, f, outd)
+    c = canon_list(F, coeffs)
+    for i, beta in enumerate(r["challenges"]):
+        c = P.fri_fold_coeffs(F, c, F.from_mont(beta))
+        nxt = O.poly_lde(mont_array(F, c), f)
+        assert np.array_equal(nxt, r["inter_values"][i])
+    assert canon_list(F, r["final_coeffs"]) == c[:outd]
+    assert r["final_root"] == r["roots"][-1]
