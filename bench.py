@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native hodor hot path.
+
+Metric (BASELINE.json): NTT field-elements/s on the 2^24 domain over the src/bn256.rs field
+(config[1]: "2^24-point NTT + iNTT on 1x MI355X"), with the LDE x8 + Merkle-commit GiB/s
+(config[2]) reported beside it in `extra`.
+
+A "step" = one forward NTT followed by one inverse NTT (Polynomial::fft + Polynomial::ifft,
+/root/reference/src/polynomials/mod.rs:611-624, :773-798) of a device-resident 2^24-element
+polynomial; inputs are resident in HBM before the timed region.  With N > 1 ranks every rank
+transforms its own polynomial (the prover holds one per register, src/prover/mod.rs:73-76): weak
+scaling, no data-path collective.  `value` = field elements transformed by all ranks / max-over-ranks
+time.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+LOG_N = 24                # BASELINE.json config[1]
+LDE_LOG_N, LDE_FACTOR = 22, 8   # BASELINE.json config[2]
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Reference CPU path (restated, oracle/hodor_oracle.c: best_fft -> parallel_fft,
+    /root/reference/src/fft/fft.rs:5-124) on the host cores: config[0], 2^20-point NTT."""
+    from oracle import pyref as P
+    from oracle.oracle import Oracle
+    O = Oracle(P.BN256.p, P.BN256.g)
+    log_n = 20
+    n = 1 << log_n
+    a = O.random_elements(n, 2024)
+    _, k, w = O.domain(n)
+    reps, total = 0, 0.0
+    while reps < 1 or (total < seconds_budget / 2 and reps < 8):
+        b = a.copy()
+        t = time.perf_counter()
+        O.best_fft(b, w, k)
+        total += time.perf_counter() - t
+        reps += 1
+    return {"value": n * reps / total, "unit": "field-elems/s", "cores": O.cpus, "kind": "port",
+            "sample": "%d x 2^20-point NTT (config[0]) via the restated Worker/parallel_fft schedule, %.1f s"
+                      % (reps, total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import hodor_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=local_rank)
+    log_n = args.log_n
+    n = 1 << log_n
+
+    # synthetic input: random field elements (Montgomery images), generated on the device
+    a = random_elements(torch, n, 0x484F444F52 + rank)
+    b = torch.empty_like(a)
+    c = torch.empty_like(a)
+    # a non-default stream: its handle is non-null, so the library launches on it (NULL would select
+    # the context's own stream) and the torch events below bracket exactly these kernels
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+
+    def step():
+        ctx.poly_fft_dev(a, b, log_n, stream=stream)
+        ctx.poly_ifft_dev(b, c, log_n, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if not torch.equal(a, c):
+        raise SystemExit("iNTT(NTT(x)) != x — refusing to report a number")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    elems = 2.0 * n * args.steps * world       # forward + inverse
+    result = {
+        "metric": "ntt_field_elems_per_sec",
+        "value": elems / dt,
+        "unit": "field-elems/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32x8 (256-bit Montgomery, integer)",
+        "data": "synthetic",
+        "config": {"workload": "2^%d-point NTT + iNTT over the src/bn256.rs Fr field, device-resident, "
+                               "bit-exact vs CPU oracle (BASELINE config[1])" % log_n,
+                   "log_n": log_n, "field": "bn256.rs Fr (255-bit, R=2^256)",
+                   "parallelism": "1 polynomial per GPU" if world > 1 else "1 GPU"},
+    }
+
+    if rank == 0:
+        # roofline of the dominant kernel (k_ntt_pass): one transform = `passes` launches and must
+        # move 2 x n x 32 B at least once; each launch is charged 1/passes of that.
+        passes = max(1, -(-log_n // 8)) if log_n > 11 else 1
+        launches = 2 * passes * args.steps
+        avg_launch_ms = kernel_ms / launches
+        alg_bytes_per_launch = 2.0 * n * 32 / passes
+        achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "kernel": "k_ntt_pass", "avg_launch_ms": avg_launch_ms,
+                              "launches_per_transform": passes,
+                              "alg_bytes_per_launch": alg_bytes_per_launch,
+                              "note": "integer-ALU-bound kernel (v_mad_u64_u32); HBM fraction reported as required"}
+        if not args.no_extra and world == 1:
+            result["extra"] = extra_lde_commit(ctx, torch, stream)
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def random_elements(torch, n, seed):
+    """n random elements of the src/bn256.rs field as (n, 4) int64 limbs on the current device:
+    three uniform 64-bit limbs and a top limb below floor(p / 2^224) * 2^32, hence value < p."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    out[:, :3] = torch.randint(-2**63, 2**63 - 1, (n, 3), dtype=torch.int64, device="cuda", generator=g)
+    out[:, 3] = torch.randint(0, 0x73EDA753 << 32, (n,), dtype=torch.int64, device="cuda", generator=g)
+    return out
+
+
+def extra_lde_commit(ctx, torch, stream):
+    """config[2]: LDE x8 of a 2^22-coefficient polynomial + IOP Merkle commit, device-resident."""
+    n = 1 << LDE_LOG_N
+    big = n * LDE_FACTOR
+    coeffs = random_elements(torch, n, 777)
+    lde = torch.empty((big, 4), dtype=torch.int64, device="cuda")
+    nodes = torch.empty((big, 32), dtype=torch.uint8, device="cuda")
+
+    def run():
+        ctx.poly_lde_dev(coeffs, lde, LDE_LOG_N, LDE_FACTOR, stream=stream)
+        ctx.iop_create_dev(lde, big, nodes, stream=stream)
+
+    run()
+    torch.cuda.synchronize()
+    reps = 5
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    lde_ms = commit_ms = 0.0
+    for _ in range(reps):
+        e0.record()
+        ctx.poly_lde_dev(coeffs, lde, LDE_LOG_N, LDE_FACTOR, stream=stream)
+        e1.record()
+        ctx.iop_create_dev(lde, big, nodes, stream=stream)
+        e2.record()
+        torch.cuda.synchronize()
+        lde_ms += e0.elapsed_time(e1)
+        commit_ms += e1.elapsed_time(e2)
+    lde_ms /= reps
+    commit_ms /= reps
+    alg_bytes = n * 32 + big * 32 + big * 32      # read coeffs + write LDE + write nodes
+    return {"workload": "LDE x8 of 2^22 + BLAKE2s Merkle commit (BASELINE config[2])",
+            "lde_ms": lde_ms, "commit_ms": commit_ms,
+            "lde_commit_gib_per_s": alg_bytes / 2**30 / ((lde_ms + commit_ms) * 1e-3),
+            "root": bytes(nodes[1].cpu().numpy()).hex()}
+
+
+if __name__ == "__main__":
+    main()

@@ -130,10 +130,12 @@ static int free_tables(hodor_ctx *ctx)
 }
 
 // base^e = lo[e & mask] * hi[e >> lo_bits] for e < 2^log_n
-static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out)
+static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out,
+                         uint32_t lo_bits = 0xffffffffu)
 {
+    if (lo_bits > log_n) lo_bits = (log_n + 1) / 2;
     for (auto &t : ctx->pow_tables)
-        if (t.log_n == log_n && t.base == base) {
+        if (t.log_n == log_n && t.lo_bits == lo_bits && t.base == base) {
             *out = TwoLevel{t.lo, t.hi, t.lo_bits};
             return HODOR_OK;
         }
@@ -141,7 +143,7 @@ static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLev
     PowTable t;
     t.base = base;
     t.log_n = log_n;
-    t.lo_bits = (log_n + 1) / 2;
+    t.lo_bits = lo_bits;
     uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
     HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * 32));
     HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * 32));
@@ -219,7 +221,14 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
 
     TwoLevel tw = {nullptr, nullptr, 0}, pre_t = {nullptr, nullptr, 0}, post_t = {nullptr, nullptr, 0};
     int rc;
-    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw))) return rc;
+    // Split the exponent so that the second pass (exponents are multiples of n/(R1*R2)) needs only the
+    // `hi` table — one multiplication per element instead of two — as long as `hi` stays L2-sized.
+    uint32_t tw_lo_bits = 0xffffffffu;
+    if (passes > 1) {
+        uint32_t shift2 = log_n - radices[0] - radices[1];
+        if (log_n - shift2 <= 17 && shift2 <= 16) tw_lo_bits = shift2;
+    }
+    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw, tw_lo_bits))) return rc;
     if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t))) return rc;
     if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t))) return rc;
 

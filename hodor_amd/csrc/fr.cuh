@@ -150,9 +150,62 @@ __device__ __forceinline__ Fr fr_halve(const Fr &a, const FrParams &P)
     return r;
 }
 
-// Montgomery product a*b*R^-1 mod p, canonical output.  CIOS over 32-bit limbs; every inner
-// step is one v_mad_u64_u32 (32x32 + 64-bit addend).
+// acc (64-bit column accumulator) += a * b;  cnt += carry-out.
+// One v_mad_u64_u32 (32x32 + 64-bit addend, carry-out to an SGPR pair) plus one v_addc that folds the
+// carry into a 32-bit overflow counter: two VALU instructions per limb product and no VCC-serialised
+// carry chain.  The `_vs` form takes the second factor from an SGPR (the modulus limbs).
+__device__ __forceinline__ void mac_vv(uint64_t &acc, uint32_t &cnt, uint32_t a, uint32_t b)
+{
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(c) : "v"(a), "v"(b));
+    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(cnt), "+s"(c));
+}
+__device__ __forceinline__ void mac_vs(uint64_t &acc, uint32_t &cnt, uint32_t a, uint32_t b_sgpr)
+{
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(c) : "v"(a), "s"(b_sgpr));
+    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(cnt), "+s"(c));
+}
+
+// Montgomery product a*b*R^-1 mod p, canonical output.
+// Finely-integrated product scanning (FIPS): column k sums a_j*b_(k-j) and m_j*p_(k-j) into a
+// 64-bit accumulator + overflow counter, derives m_k = lo32(acc) * (-p^-1) so that the column's low
+// word cancels, then shifts the accumulator down one limb.  128 v_mad_u64_u32 + 128 v_addc per
+// product; v_mad_u64_u32 issues at half the VALU rate on gfx950 (measured, bench/microbench.hip).
 __device__ __forceinline__ Fr fr_mul(const Fr &a, const Fr &b, const FrParams &P)
+{
+    uint32_t m[8], t[8];
+    uint64_t acc = 0;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int j = 0; j <= k; j++) mac_vv(acc, cnt, a.v[j], b.v[k - j]);
+#pragma unroll
+        for (int j = 0; j < k; j++) mac_vs(acc, cnt, m[j], P.p[k - j]);
+        m[k] = (uint32_t)acc * P.pinv;
+        mac_vs(acc, cnt, m[k], P.p[0]);
+        acc = (acc >> 32) | ((uint64_t)cnt << 32);
+        cnt = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+        for (int j = k - 7; j < 8; j++) mac_vv(acc, cnt, a.v[j], b.v[k - j]);
+#pragma unroll
+        for (int j = k - 7; j < 8; j++) mac_vs(acc, cnt, m[j], P.p[k - j]);
+        t[k - 8] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)cnt << 32);
+        cnt = 0;
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return fr_reduce_once(r, (uint32_t)acc, P);
+}
+
+// Reference formulation (CIOS in plain C++, compiler-scheduled) kept for A/B measurements.
+__device__ __forceinline__ Fr fr_mul_cios(const Fr &a, const Fr &b, const FrParams &P)
 {
     uint32_t t[10];
 #pragma unroll

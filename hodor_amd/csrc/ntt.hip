@@ -18,6 +18,8 @@
 //     ds_read_b128 / ds_write_b128 are conflict-free for both row-major and column-major access.
 //   * Inter-pass twiddles come from a two-level power table (L2-resident) instead of an n-entry
 //     table streamed from HBM.
+#include <cstdlib>
+
 #include "ntt.cuh"
 
 namespace hodor {
@@ -70,13 +72,13 @@ __device__ __forceinline__ Fr two_level_pow(const TwoLevel &t, uint64_t e, const
 //   twiddle       w_(L*R)^(i*p)        p = j mod L, L = product of earlier radices
 //   output index  (j - p)*R + p + c*L  c < R (sub-transform output)
 // ---------------------------------------------------------------------------------------------
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_MAX_THREADS = 512;
 
-__global__ void __launch_bounds__(NTT_THREADS)
+__global__ void __launch_bounds__(NTT_MAX_THREADS)
 k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t log_r = A.log_r, log_c = A.log_c;
     const uint32_t R = 1u << log_r, C = 1u << log_c;
     const uint32_t RS = (C == 1) ? 1u : C + 1;      // padded row stride (slots)
@@ -86,7 +88,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
     const uint32_t half_r = R >> 1;
 
     // stage omega_R^e (e < R/2) into LDS
-    for (uint32_t e = tid; e < half_r; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < half_r; e += nthreads) {
         tw[e] = A.rtw[2 * e];
         tw[half_r + e] = A.rtw[2 * e + 1];
     }
@@ -98,7 +100,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
     const uint32_t tile = R << log_c;
 
     // ---- load: global -> (pre-scale, inter-pass twiddle) -> LDS at bit-reversed row
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile; e += nthreads) {
         uint32_t c = e & (C - 1), i = e >> log_c;
         uint64_t j = j0 + c;
         uint64_t g = j + (uint64_t)i * n_over_r;
@@ -122,7 +124,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
     uint32_t log_m = 0;
     if (log_r & 1) {   // one plain radix-2 stage (all twiddles are 1)
         const uint32_t items = (R >> 1) << log_c;
-        for (uint32_t w = tid; w < items; w += NTT_THREADS) {
+        for (uint32_t w = tid; w < items; w += nthreads) {
             uint32_t c = w & (C - 1), q = w >> log_c;
             uint32_t s0 = (2 * q) * RS + c, s1 = s0 + RS;
             Fr x0 = lds_get(data, slots, s0), x1 = lds_get(data, slots, s1);
@@ -135,7 +137,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
-        for (uint32_t w = tid; w < items; w += NTT_THREADS) {
+        for (uint32_t w = tid; w < items; w += nthreads) {
             uint32_t c = w & (C - 1), q = w >> log_c;
             uint32_t jp = q & (m - 1);
             uint32_t k = (q >> log_m) << (log_m + 2);
@@ -173,7 +175,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
 
     // ---- store: LDS -> (scale, post-scale) -> global, Stockham output index
     const bool transposed = (A.log_l == 0);   // first pass: outputs of one sub-transform are contiguous
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile; e += nthreads) {
         uint32_t c, cc;
         if (transposed) { cc = e & (R - 1); c = e >> log_r; }
         else            { c = e & (C - 1);  cc = e >> log_c; }
@@ -211,7 +213,16 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr *scal
     Fr s = {};
     if (scale) s = *scale;
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c);
-    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid), dim3(NTT_THREADS), lds, stream, A, s,
+    // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
+    static int threads_override = -1;
+    if (threads_override < 0) {
+        const char *e = getenv("HODOR_NTT_THREADS");
+        threads_override = e ? atoi(e) : 0;
+    }
+    uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
+    unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
+    if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
+    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid), dim3(threads), lds, stream, A, s,
                        scale ? 1u : 0u, P);
     return hipGetLastError();
 }
