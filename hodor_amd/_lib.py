@@ -36,7 +36,7 @@ EXPORTS = [
     "hodor_fri_final_root", "hodor_fri_challenges", "hodor_fri_final_coefficients",
     "hodor_fri_intermediate_values", "hodor_fri_tree_nodes", "hodor_fri_serialize",
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
-    "hodor_fft_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
+    "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_distribute_powers_dev",
     "hodor_iop_create_dev", "hodor_fri_commit_dev",
 ]
@@ -320,6 +320,18 @@ class Context:
         w = _fr(omega)
         self._chk(self.L.hodor_fft_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst), C.c_uint32(log_n),
                                        C.byref(w)))
+
+    def fft_batch_dev(self, src, dst, log_n, batch, omega, stream=None):
+        w = _fr(omega)
+        self._chk(self.L.hodor_fft_batch_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                             C.c_uint32(log_n), C.c_size_t(batch), C.byref(w)))
+
+    def twiddle_mul_dev(self, a, rows, cols, row0, omega, log_order, scale=None, stream=None):
+        w = _fr(omega)
+        sc = _fr(scale) if scale is not None else None
+        self._chk(self.L.hodor_twiddle_mul_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(rows),
+                                               C.c_size_t(cols), C.c_uint64(row0), C.byref(w),
+                                               C.c_uint32(log_order), C.byref(sc) if sc is not None else None))
 
     def _poly_dev(self, name, src, dst, log_n, stream):
         self._chk(getattr(self.L, name)(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst), C.c_uint32(log_n)))

@@ -22,6 +22,8 @@ hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &m
                             uint32_t log_stride, uint64_t count, const FrParams &);
 hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
 hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
+hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
+                              const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
 hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &);
 hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &);
@@ -212,12 +214,13 @@ static void plan_radices(const hodor_ctx *ctx, uint32_t log_n, std::vector<uint3
 // dst[k] = post^k * scale * sum_i (pre^i * src[i]) omega^(ik),  src[i] = 0 for i >= nnz.
 // src may equal dst.  Caller holds ctx->mu.
 static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n,
-                    const HFr &omega, uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post)
+                    const HFr &omega, uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post,
+                    uint32_t batch = 1)
 {
     std::vector<uint32_t> radices;
     plan_radices(ctx, log_n, &radices);
     const size_t passes = radices.size();
-    const size_t bytes = (size_t)32 << log_n;
+    const size_t bytes = ((size_t)32 << log_n) * batch;
 
     TwoLevel tw = {nullptr, nullptr, 0}, pre_t = {nullptr, nullptr, 0}, post_t = {nullptr, nullptr, 0};
     int rc;
@@ -275,7 +278,7 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         A.log_c = log_c;
         A.log_l = log_l;
         A.apply_tw = (i == 0) ? 0 : 1;
-        A.tw_always = 0;
+        A.batch = batch;
         HIPCHK(ntt_launch_pass(stream, A, (scale && i + 1 == passes) ? &scale_d : nullptr, ctx->P));
         cur = outs[i];
         log_l += log_r;
@@ -502,7 +505,8 @@ extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *de
 
 static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
 {
-    return stream ? (hipStream_t)stream : ctx->stream;
+    (void)ctx;
+    return (hipStream_t)stream;   // NULL selects the HIP default (null) stream, as for any HIP API
 }
 
 extern "C" int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
@@ -550,6 +554,35 @@ extern "C" int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_f
     NEED_DEVICE();
     if (!a || !g) return HODOR_ERR_INVALID;
     HIPCHK(distribute_powers_launch(pick_stream(ctx, stream), (uint4 *)a, n, to_dev(to_h(g)), ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_fft_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                                   uint32_t log_n, size_t batch, const hodor_fr *omega)
+{
+    NEED_DEVICE();
+    if (!src || !dst || !omega) return HODOR_ERR_INVALID;
+    if (log_n > ctx->F.s || log_n > 40 || batch == 0 || batch > 65535) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, to_h(omega),
+                    1ull << log_n, nullptr, nullptr, nullptr, (uint32_t)batch);
+}
+
+extern "C" int hodor_twiddle_mul_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t rows, size_t cols,
+                                     uint64_t row0, const hodor_fr *omega, uint32_t log_order,
+                                     const hodor_fr *scale)
+{
+    NEED_DEVICE();
+    if (!a || !omega) return HODOR_ERR_INVALID;
+    if (log_order > 62) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TwoLevel t;
+    int rc = get_pow_table(ctx, to_h(omega), log_order, &t);
+    if (rc) return rc;
+    Fr sc = {};
+    if (scale) sc = to_dev(to_h(scale));
+    HIPCHK(twiddle_mul_launch(pick_stream(ctx, stream), (uint4 *)a, rows, cols, row0, t, log_order,
+                              scale ? &sc : nullptr, ctx->P));
     return HODOR_OK;
 }
 

@@ -1,0 +1,353 @@
+// hodor.hpp — C++ host-side mirror of the reference's L3 interface for the hot path, written on top
+// of the C ABI only (include/hodor_gpu.h).  Same names, argument meaning and error behaviour as the
+// Rust items they stand for, so host code (and tests) read like the reference's:
+//
+//   hodor::Field                    the `F: PrimeField` type parameter (one hodor_ctx)
+//   hodor::Domain                   src/domains/mod.rs:14-71
+//   hodor::Polynomial<Form>         src/polynomials/mod.rs:26-34, :139-712 (Coefficients), :715-955 (Values)
+//   hodor::Blake2sIopTree           src/iop/blake2s_trivial_iop.rs:106-280
+//   hodor::TrivialBlake2sIOP        src/iop/blake2s_trivial_iop.rs:282-339 (+ Query :341-375)
+//   hodor::NaiveFriIop              src/fri/mod.rs:63-117, src/fri/fri_on_values.rs:11-159
+//
+// Errors: SynthesisError::Error and the reference's asserts become hodor::SynthesisError exceptions
+// (thrown on this side of the ABI; the ABI itself returns status codes).
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/hodor_gpu.h"
+
+// equality on the C element type (global scope so that std::vector<hodor_fr> comparisons find it)
+inline bool operator==(const hodor_fr &a, const hodor_fr &b)
+{
+    return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3];
+}
+inline bool operator!=(const hodor_fr &a, const hodor_fr &b) { return !(a == b); }
+
+namespace hodor {
+
+struct SynthesisError : std::runtime_error {
+    int code;
+    SynthesisError(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+typedef hodor_fr Fr;
+
+// One prime field on one device: what `F: PrimeField` + `Worker` are to the reference.
+class Field {
+  public:
+    Field(const uint64_t modulus[4], uint64_t generator, int device = 0)
+    {
+        int rc = hodor_ctx_create(modulus, generator, device, &ctx_);
+        if (rc) throw SynthesisError(rc, "hodor_ctx_create failed");
+        hodor_ctx_field_info(ctx_, &info_);
+    }
+    ~Field() { hodor_ctx_destroy(ctx_); }
+    Field(const Field &) = delete;
+    Field &operator=(const Field &) = delete;
+
+    hodor_ctx *ctx() const { return ctx_; }
+    uint32_t S() const { return info_.s; }
+    uint32_t capacity() const { return info_.capacity; }
+    Fr one() const { return info_.one; }
+    Fr zero() const { return Fr{{0, 0, 0, 0}}; }
+    Fr multiplicative_generator() const { return info_.generator; }
+    Fr root_of_unity() const { return info_.root_of_unity; }
+
+    Fr mul(const Fr &a, const Fr &b) const { Fr r; hodor_fr_mul(ctx_, &a, &b, &r); return r; }
+    Fr add(const Fr &a, const Fr &b) const { Fr r; hodor_fr_add(ctx_, &a, &b, &r); return r; }
+    Fr sub(const Fr &a, const Fr &b) const { Fr r; hodor_fr_sub(ctx_, &a, &b, &r); return r; }
+    Fr pow(const Fr &a, uint64_t e) const { Fr r; hodor_fr_pow(ctx_, &a, e, &r); return r; }
+    Fr inverse(const Fr &a) const
+    {
+        Fr r;
+        if (hodor_fr_inverse(ctx_, &a, &r)) throw SynthesisError(HODOR_ERR_INVALID, "inverse of zero");
+        return r;
+    }
+    Fr from_u64(uint64_t v) const
+    {
+        uint64_t c[4] = {v, 0, 0, 0};
+        Fr r;
+        hodor_fr_from_repr(ctx_, c, &r);
+        return r;
+    }
+    void check(int rc, const char *what) const
+    {
+        if (rc) throw SynthesisError(rc, std::string(what) + ": " + hodor_last_error(ctx_));
+    }
+
+  private:
+    hodor_ctx *ctx_ = nullptr;
+    hodor_field_info info_;
+};
+
+// src/domains/mod.rs:14-71
+struct Domain {
+    uint64_t size;
+    uint64_t power_of_two;
+    Fr generator;
+
+    static Domain new_for_size(const Field &F, uint64_t size)
+    {
+        Domain d;
+        uint32_t k;
+        int rc = hodor_domain_new_for_size(F.ctx(), size, &d.size, &k, &d.generator);
+        if (rc) throw SynthesisError(rc, "Domain::new_for_size: size exceeds the field's 2-adicity");
+        d.power_of_two = k;
+        return d;
+    }
+    static std::vector<size_t> coset_for_natural_index_and_size(size_t natural_index, size_t domain_size)
+    {
+        size_t pair = (natural_index + domain_size / 2) % domain_size;
+        if (natural_index < pair) return {natural_index, pair};
+        return {pair, natural_index};
+    }
+    static std::pair<size_t, size_t> index_and_size_for_next_domain(size_t natural_index, size_t domain_size)
+    {
+        size_t next = domain_size / 2;
+        return {natural_index < next ? natural_index : natural_index - next, next};
+    }
+};
+
+struct Coefficients {};
+struct Values {};
+
+// src/polynomials/mod.rs:26-34
+template <class Form>
+class Polynomial {
+  public:
+    const Field *F;
+    std::vector<Fr> coeffs;
+    uint32_t exp;
+    Fr omega, omegainv, geninv, minv;
+
+    size_t size() const { return coeffs.size(); }
+    const std::vector<Fr> &as_ref() const { return coeffs; }
+    std::vector<Fr> into_coeffs() && { return std::move(coeffs); }
+
+    // from_coeffs / from_values: pad to a power of two and cache domain constants (:146-166, :722-742)
+    static Polynomial from_vec(const Field &F, std::vector<Fr> v)
+    {
+        Polynomial p;
+        p.F = &F;
+        Domain d = Domain::new_for_size(F, v.size());
+        v.resize(d.size, F.zero());
+        p.coeffs = std::move(v);
+        p.exp = (uint32_t)d.power_of_two;
+        p.omega = d.generator;
+        p.omegainv = F.inverse(d.generator);
+        p.geninv = F.inverse(F.multiplicative_generator());
+        p.minv = F.inverse(F.from_u64(d.size));
+        return p;
+    }
+
+    void distribute_powers(const Fr &g)   // :55-58 -> src/fft/mod.rs:110
+    {
+        F->check(hodor_distribute_powers(F->ctx(), coeffs.data(), coeffs.size(), &g), "distribute_powers");
+    }
+
+    template <class To>
+    Polynomial<To> retype() &&
+    {
+        Polynomial<To> q;
+        q.F = F; q.coeffs = std::move(coeffs); q.exp = exp; q.omega = omega; q.omegainv = omegainv;
+        q.geninv = geninv; q.minv = minv;
+        return q;
+    }
+};
+
+inline Polynomial<Coefficients> from_coeffs(const Field &F, std::vector<Fr> c)
+{
+    return Polynomial<Coefficients>::from_vec(F, std::move(c));
+}
+inline Polynomial<Values> from_values(const Field &F, std::vector<Fr> v)
+{
+    return Polynomial<Values>::from_vec(F, std::move(v));
+}
+
+// Polynomial<F, Coefficients>::fft / coset_fft (:611-631)
+inline Polynomial<Values> fft(Polynomial<Coefficients> p)
+{
+    p.F->check(hodor_fft(p.F->ctx(), p.coeffs.data(), p.coeffs.size(), &p.omega, p.exp), "fft");
+    return std::move(p).retype<Values>();
+}
+inline Polynomial<Values> coset_fft(Polynomial<Coefficients> p)
+{
+    p.F->check(hodor_poly_coset_fft(p.F->ctx(), p.coeffs.data(), p.coeffs.size()), "coset_fft");
+    return std::move(p).retype<Values>();
+}
+// Polynomial<F, Values>::ifft / icoset_fft (:773-807)
+inline Polynomial<Coefficients> ifft(Polynomial<Values> p)
+{
+    p.F->check(hodor_poly_ifft(p.F->ctx(), p.coeffs.data(), p.coeffs.size()), "ifft");
+    return std::move(p).retype<Coefficients>();
+}
+inline Polynomial<Coefficients> icoset_fft(Polynomial<Values> p)
+{
+    p.F->check(hodor_poly_icoset_fft(p.F->ctx(), p.coeffs.data(), p.coeffs.size()), "icoset_fft");
+    return std::move(p).retype<Coefficients>();
+}
+// lde / coset_lde (:343-349 -> :418-482, :544-609)
+inline Polynomial<Values> lde_impl(const Polynomial<Coefficients> &p, size_t factor, bool coset)
+{
+    if (factor == 0 || (factor & (factor - 1)))
+        throw SynthesisError(HODOR_ERR_SIZE, "lde factor must be a power of two");   // assert!(factor.is_power_of_two())
+    std::vector<Fr> out(p.coeffs.size() * factor);
+    int rc = coset ? hodor_poly_coset_lde(p.F->ctx(), p.coeffs.data(), p.coeffs.size(), factor, out.data())
+                   : hodor_poly_lde(p.F->ctx(), p.coeffs.data(), p.coeffs.size(), factor, out.data());
+    p.F->check(rc, "lde");
+    return from_values(*p.F, std::move(out));
+}
+inline Polynomial<Values> lde(const Polynomial<Coefficients> &p, size_t factor) { return lde_impl(p, factor, false); }
+inline Polynomial<Values> coset_lde(const Polynomial<Coefficients> &p, size_t factor) { return lde_impl(p, factor, true); }
+// filtering_lde (:355-368): zero-pad then best_lde
+inline Polynomial<Values> filtering_lde(const Polynomial<Coefficients> &p, size_t factor)
+{
+    std::vector<Fr> v = p.coeffs;
+    v.resize(p.coeffs.size() * factor, p.F->zero());
+    Domain d = Domain::new_for_size(*p.F, v.size());
+    p.F->check(hodor_lde(p.F->ctx(), v.data(), v.size(), &d.generator, (uint32_t)d.power_of_two, factor),
+               "best_lde");
+    return from_values(*p.F, std::move(v));
+}
+
+typedef std::vector<uint8_t> Hash32;   // [u8; 32]
+
+// src/iop/blake2s_trivial_iop.rs:106-280
+class Blake2sIopTree {
+  public:
+    const Field *F;
+    uint64_t size_;
+    std::vector<uint8_t> nodes;   // size * 32, heap layout, root at [32, 64)
+
+    static Blake2sIopTree create(const Field &F, const std::vector<Fr> &leafs)
+    {
+        Blake2sIopTree t;
+        t.F = &F;
+        t.size_ = leafs.size();
+        t.nodes.assign(leafs.size() * 32, 0);
+        F.check(hodor_iop_create(F.ctx(), leafs.data(), leafs.size(), t.nodes.data()), "IopTree::create");
+        return t;
+    }
+    uint64_t size() const { return size_; }
+    Hash32 get_root() const { return Hash32(nodes.begin() + 32, nodes.begin() + 64); }
+    static Fr encode_root_into_challenge(const Field &F, const Hash32 &root)
+    {
+        Fr r;
+        F.check(hodor_iop_challenge(F.ctx(), root.data(), &r), "interpret_hash");
+        return r;
+    }
+    Fr get_challenge_scalar_from_root() const { return encode_root_into_challenge(*F, get_root()); }
+    std::vector<Hash32> get_path(size_t tree_index, const std::vector<Fr> &leafs_values) const
+    {
+        std::vector<uint8_t> buf(32 * 64);
+        size_t cnt = 0;
+        F->check(hodor_iop_path(F->ctx(), nodes.data(), leafs_values.data(), leafs_values.size(), tree_index,
+                                buf.data(), &cnt), "get_path");
+        std::vector<Hash32> path;
+        for (size_t i = 0; i < cnt; i++) path.emplace_back(buf.begin() + 32 * i, buf.begin() + 32 * (i + 1));
+        return path;
+    }
+    static bool verify(const Field &F, const Hash32 &root, const Fr &leaf_value, const std::vector<Hash32> &path,
+                       size_t tree_index)
+    {
+        std::vector<uint8_t> flat;
+        for (auto &h : path) flat.insert(flat.end(), h.begin(), h.end());
+        int ok = 0;
+        F.check(hodor_iop_verify(F.ctx(), root.data(), &leaf_value, flat.data(), path.size(), tree_index, &ok),
+                "verify");
+        return ok != 0;
+    }
+};
+
+// src/iop/blake2s_trivial_iop.rs:341-375
+struct TrivialBlake2sIopQuery {
+    size_t index;
+    Fr value_;
+    std::vector<Hash32> path_;
+    size_t tree_index() const { return index; }
+    size_t natural_index() const { return index; }
+    const Fr &value() const { return value_; }
+    const std::vector<Hash32> &path() const { return path_; }
+};
+
+// src/iop/blake2s_trivial_iop.rs:282-339
+class TrivialBlake2sIOP {
+  public:
+    Blake2sIopTree tree;
+    static TrivialBlake2sIOP create(const Field &F, const std::vector<Fr> &leafs)
+    {
+        return TrivialBlake2sIOP{Blake2sIopTree::create(F, leafs)};
+    }
+    Hash32 get_root() const { return tree.get_root(); }
+    Fr get_challenge_scalar_from_root() const { return tree.get_challenge_scalar_from_root(); }
+    TrivialBlake2sIopQuery query(size_t natural_index, const std::vector<Fr> &leafs) const
+    {
+        if (natural_index >= tree.size() || natural_index >= leafs.size())
+            throw SynthesisError(HODOR_ERR_SIZE, "query index out of range");   // asserts :325-326
+        return TrivialBlake2sIopQuery{natural_index, leafs[natural_index], tree.get_path(natural_index, leafs)};
+    }
+    static bool verify_query(const Field &F, const TrivialBlake2sIopQuery &q, const Hash32 &root)
+    {
+        return Blake2sIopTree::verify(F, root, q.value(), q.path(), q.tree_index());
+    }
+    bool operator==(const TrivialBlake2sIOP &o) const { return get_root() == o.get_root(); }
+};
+
+// src/fri/mod.rs:106-117 — field for field
+struct FRIProofPrototype {
+    TrivialBlake2sIOP l0_commitment;
+    std::vector<TrivialBlake2sIOP> intermediate_commitments;
+    std::vector<Polynomial<Values>> intermediate_values;
+    std::vector<Fr> challenges;
+    Hash32 final_root;
+    std::vector<Fr> final_coefficients;
+    size_t initial_degree_plus_one, output_coeffs_at_degree_plus_one, lde_factor;
+
+    std::vector<Hash32> get_roots() const   // :120-128
+    {
+        std::vector<Hash32> r{l0_commitment.get_root()};
+        for (auto &c : intermediate_commitments) r.push_back(c.get_root());
+        return r;
+    }
+};
+
+// src/fri/mod.rs:63-104 + src/fri/fri_on_values.rs:11-159
+struct NaiveFriIop {
+    static FRIProofPrototype proof_from_lde(const Polynomial<Values> &lde_values, size_t lde_factor,
+                                            size_t output_coeffs_at_degree_plus_one)
+    {
+        const Field &F = *lde_values.F;
+        hodor_fri_proto *h = nullptr;
+        F.check(hodor_fri_commit(F.ctx(), lde_values.coeffs.data(), lde_values.size(), lde_factor,
+                                 output_coeffs_at_degree_plus_one, &h), "proof_from_lde_by_values");
+        size_t steps = hodor_fri_num_steps(h), n = lde_values.size();
+        auto tree_of = [&](int step, size_t sz) {
+            Blake2sIopTree t;
+            t.F = &F;
+            t.size_ = sz;
+            t.nodes.resize(sz * 32);
+            F.check(hodor_fri_tree_nodes(h, step, t.nodes.data()), "fri tree");
+            return TrivialBlake2sIOP{t};
+        };
+        FRIProofPrototype p{tree_of(-1, n), {}, {}, std::vector<Fr>(steps), Hash32(32),
+                            std::vector<Fr>(output_coeffs_at_degree_plus_one), n / lde_factor,
+                            output_coeffs_at_degree_plus_one, lde_factor};
+        for (size_t i = 0; i < steps; i++) {
+            size_t sz = n >> (i + 1);
+            p.intermediate_commitments.push_back(tree_of((int)i, sz));
+            std::vector<Fr> v(sz);
+            F.check(hodor_fri_intermediate_values(h, i, v.data()), "fri values");
+            p.intermediate_values.push_back(from_values(F, std::move(v)));
+        }
+        hodor_fri_challenges(h, p.challenges.data());
+        hodor_fri_final_root(h, p.final_root.data());
+        hodor_fri_final_coefficients(h, p.final_coefficients.data());
+        hodor_fri_free(h);
+        return p;
+    }
+};
+
+}  // namespace hodor

@@ -31,7 +31,7 @@ struct PassArgs {
     uint32_t log_c;          // tile columns (C consecutive sub-transforms per workgroup)
     uint32_t log_l;          // product of the radices of the previous passes (L = 2^log_l)
     uint32_t apply_tw;       // 0: no inter-pass twiddle (first pass)  1: lo*hi  2: hi only
-    uint32_t tw_always;      // 1: multiply even when the exponent is 0 (hi carries the iNTT scale)
+    uint32_t batch;          // number of independent size-n transforms (grid.y); arrays are n elements apart
 };
 
 }  // namespace hodor

@@ -93,6 +93,9 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
         tw[half_r + e] = A.rtw[2 * e + 1];
     }
 
+    // batched transforms: blockIdx.y selects one of `batch` independent size-n arrays
+    const uint4 *src_b = A.src + ((2ull * blockIdx.y) << A.log_n);
+    uint4 *dst_b = A.dst + ((2ull * blockIdx.y) << A.log_n);
     const uint64_t n_over_r = 1ull << (A.log_n - log_r);
     const uint64_t j0 = (uint64_t)blockIdx.x << log_c;
     const uint64_t Lmask = (1ull << A.log_l) - 1;
@@ -106,7 +109,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
         uint64_t g = j + (uint64_t)i * n_over_r;
         Fr x;
         if (g < A.nnz) {
-            x = fr_load(A.src + 2 * g);
+            x = fr_load(src_b + 2 * g);
             if (A.pre.lo != nullptr && g != 0) x = fr_mul(x, two_level_pow(A.pre, g, P), P);
             if (A.apply_tw) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
@@ -185,7 +188,7 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
         Fr x = lds_get(data, slots, cc * RS + c);
         if (has_scale) x = fr_mul(x, scale, P);
         if (A.post.lo != nullptr && o != 0) x = fr_mul(x, two_level_pow(A.post, o, P), P);
-        fr_store(A.dst + 2 * o, x);
+        fr_store(dst_b + 2 * o, x);
     }
 }
 
@@ -222,7 +225,7 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr *scal
     uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
     unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
-    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid), dim3(threads), lds, stream, A, s,
+    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid, A.batch ? A.batch : 1), dim3(threads), lds, stream, A, s,
                        scale ? 1u : 0u, P);
     return hipGetLastError();
 }

@@ -129,7 +129,7 @@ int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes);
 size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap);
 
 /* ================================ device API (device memory) ============================== */
-/* `stream` is a hipStream_t (NULL = the context's own stream).  All work is enqueued in stream
+/* `stream` is a hipStream_t (NULL = the HIP default stream, which is also PyTorch-ROCm's default).  All work is enqueued in stream
  * order; nothing synchronises with the host unless stated.  A context owns one scratch pool, so use
  * one context per concurrently active stream. */
 int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr);
@@ -140,6 +140,14 @@ int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *dev_src, size
 /* out-of-place natural->natural NTT of size 1<<log_n with an arbitrary omega (src == dst allowed) */
 int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n,
                   const hodor_fr *omega);
+/* `batch` independent transforms of size 1<<log_n stored back to back (the row/column transforms of
+ * the 6-step decomposition, cf. the P sub-FFTs of parallel_fft, src/fft/fft.rs:83-108) */
+int hodor_fft_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n,
+                        size_t batch, const hodor_fr *omega);
+/* 6-step twiddle step: a[r][c] *= omega^((row0 + r) * c) (* scale if non-NULL) for a rows x cols
+ * row-major block; omega has order 2^log_order (cf. the omega^(j*idx) factors at src/fft/fft.rs:92-103) */
+int hodor_twiddle_mul_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t rows, size_t cols,
+                          uint64_t row0, const hodor_fr *omega, uint32_t log_order, const hodor_fr *scale);
 /* Polynomial-level transforms on the canonical domain of size 1<<log_n */
 int hodor_poly_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
 int hodor_poly_ifft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);

@@ -1,0 +1,158 @@
+// C++ restatement of the reference's own inline tests for the hot path, written against the host
+// mirror (hodor_amd/csrc/host/hodor.hpp -> C ABI -> HIP kernels).  Each test names the Rust test it
+// follows.  Build: g++ -O2 -std=c++17 test_host.cpp -L<repo>/hodor_amd -lhodor_gpu
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../hodor_amd/csrc/host/hodor.hpp"
+
+using namespace hodor;
+
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) { fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } \
+    } while (0)
+
+// XorShiftRng::from_seed([0x3dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654]) — src/fft/mod.rs:71 —
+// and the Fr::rand rejection recipe of ff_derive (top limb shaved, value used as the Montgomery image).
+struct XorShiftRng {
+    uint32_t x = 0x3dbe6259, y = 0x8d313d76, z = 0x3237db17, w = 0xe5bc0654;
+    uint32_t next_u32() { uint32_t t = x ^ (x << 11); x = y; y = z; z = w; w = w ^ (w >> 19) ^ (t ^ (t >> 8)); return w; }
+    uint64_t next_u64() { uint64_t hi = next_u32(); return (hi << 32) | next_u32(); }
+};
+
+static Fr rand_fr(XorShiftRng &rng, const uint64_t p[4], int shave)
+{
+    for (;;) {
+        Fr r;
+        for (int i = 0; i < 4; i++) r.l[i] = rng.next_u64();
+        r.l[3] &= ~0ull >> shave;
+        bool lt = false;
+        for (int i = 3; i >= 0; i--) { if (r.l[i] < p[i]) { lt = true; break; } if (r.l[i] > p[i]) break; }
+        if (lt) return r;
+    }
+}
+
+static const uint64_t BN256_FR[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+
+// test_worker_size (src/fft/mod.rs:281-328): forward then inverse * n^-1 is the identity; omega^n == 1
+static void test_fft_inverse_identity(const Field &F)
+{
+    XorShiftRng rng;
+    const uint32_t LOG_N = 13;
+    std::vector<Fr> a(1u << LOG_N);
+    for (auto &v : a) v = rand_fr(rng, BN256_FR, 1);
+    Domain domain = Domain::new_for_size(F, a.size());
+    CHECK(F.pow(domain.generator, a.size()) == F.one());
+    auto values = fft(from_coeffs(F, a));
+    CHECK(values.coeffs != a);
+    auto back = ifft(std::move(values));
+    CHECK(back.coeffs == a);
+    auto cv = coset_fft(from_coeffs(F, a));
+    CHECK(icoset_fft(std::move(cv)).coeffs == a);
+}
+
+// test_lde_correctness / test_various_ldes (src/polynomials/mod.rs:988-1130):
+// multi-coset LDE == filtering LDE == FFT of the zero-padded coefficients
+static void test_lde_correctness(const Field &F)
+{
+    XorShiftRng rng;
+    const size_t N = 1u << 10, LDE_FACTOR = 16;
+    std::vector<Fr> coeffs(N);
+    for (auto &v : coeffs) v = rand_fr(rng, BN256_FR, 1);
+    auto poly = from_coeffs(F, coeffs);
+    auto multi = lde(poly, LDE_FACTOR);
+    auto filtering = filtering_lde(poly, LDE_FACTOR);
+    std::vector<Fr> padded = coeffs;
+    padded.resize(N * LDE_FACTOR, F.zero());
+    auto naive = fft(from_coeffs(F, padded));
+    CHECK(multi.coeffs == filtering.coeffs);
+    CHECK(multi.coeffs == naive.coeffs);
+    // coset variant evaluates on g * <Omega>: index 0 is P(g)
+    auto cl = coset_lde(poly, LDE_FACTOR);
+    Fr g = F.multiplicative_generator(), x = F.one(), acc = F.zero();
+    for (size_t i = 0; i < N; i++) { acc = F.add(acc, F.mul(coeffs[i], x)); x = F.mul(x, g); }
+    CHECK(cl.coeffs[0] == acc);
+    bool threw = false;
+    try { lde(poly, 3); } catch (const SynthesisError &) { threw = true; }
+    CHECK(threw);
+}
+
+// make_small_iop (src/iop/blake2s_trivial_iop.rs:390-409): 64 leaves 2^i, every query verifies
+static void test_make_small_iop(const Field &F)
+{
+    const size_t SIZE = 64;
+    std::vector<Fr> inputs;
+    Fr f = F.one();
+    for (size_t i = 0; i < SIZE; i++) { inputs.push_back(f); f = F.add(f, f); }
+    auto iop = TrivialBlake2sIOP::create(F, inputs);
+    auto root = iop.get_root();
+    for (size_t i = 0; i < SIZE; i++) {
+        auto query = iop.query(i, inputs);
+        CHECK(query.path().size() == 6);
+        CHECK(TrivialBlake2sIOP::verify_query(F, query, root));
+        auto bad = query;
+        bad.value_ = F.add(bad.value_, F.one());
+        CHECK(!TrivialBlake2sIOP::verify_query(F, bad, root));
+    }
+}
+
+// test_one_fri_step (src/fri/mod.rs:252-361): coefficients 1,2,4,8, lde 4, output degree+1 = 2
+static void test_one_fri_step(const Field &F)
+{
+    std::vector<Fr> lde_coeffs;
+    Fr f = F.one();
+    for (int i = 0; i < 4; i++) { lde_coeffs.push_back(f); f = F.add(f, f); }
+    const size_t lde_factor = 4, output_at_degree_plus_one = 2;
+    auto coeffs_poly = from_coeffs(F, lde_coeffs);
+    auto lde_values = lde(coeffs_poly, lde_factor);
+    auto proto = NaiveFriIop::proof_from_lde(lde_values, lde_factor, output_at_degree_plus_one);
+
+    const size_t coset_index = 3, coset_pair_index = coset_index + lde_factor * 2;
+    Fr divisor = F.pow(lde_values.omegainv, coset_index);
+    Fr two_inv = F.inverse(F.from_u64(2));
+    Fr challenge = proto.challenges[0];
+    Fr value_at_omega = lde_values.coeffs[coset_index], value_at_minus_omega = lde_values.coeffs[coset_pair_index];
+    Fr t0 = F.add(value_at_omega, value_at_minus_omega);
+    Fr t1 = F.mul(F.mul(F.sub(value_at_omega, value_at_minus_omega), divisor), challenge);
+    t0 = F.mul(F.add(t0, t1), two_inv);
+
+    std::vector<Fr> new_coeffs;
+    for (size_t i = 0; i < lde_coeffs.size(); i += 2)
+        new_coeffs.push_back(F.add(F.mul(lde_coeffs[i + 1], challenge), lde_coeffs[i]));
+    CHECK(proto.final_coefficients == new_coeffs);
+    auto next_lde = lde(from_coeffs(F, new_coeffs), lde_factor);
+    CHECK(next_lde.coeffs[coset_index] == t0);
+    CHECK(proto.intermediate_values.size() == 1);
+    CHECK(proto.intermediate_values[0].coeffs == next_lde.coeffs);
+    // commitments are the trees of the vectors they commit to; final_root is the last root
+    CHECK(proto.l0_commitment == TrivialBlake2sIOP::create(F, lde_values.coeffs));
+    CHECK(proto.intermediate_commitments[0] == TrivialBlake2sIOP::create(F, next_lde.coeffs));
+    CHECK(proto.final_root == proto.get_roots().back());
+    CHECK(proto.challenges[0] == proto.l0_commitment.get_challenge_scalar_from_root());
+}
+
+static void test_domain_errors(const Field &F)
+{
+    bool threw = false;
+    try { Domain::new_for_size(F, 1ull << 33); } catch (const SynthesisError &e) { threw = (e.code == HODOR_ERR_SIZE); }
+    CHECK(threw);   // S = 32: SynthesisError::Error (src/domains/mod.rs:30-32)
+    auto c = Domain::coset_for_natural_index_and_size(5, 16);
+    CHECK(c[0] == 5 && c[1] == 13);
+    auto nx = Domain::index_and_size_for_next_domain(13, 16);
+    CHECK(nx.first == 5 && nx.second == 8);
+}
+
+int main()
+{
+    Field F(BN256_FR, 7, 0);
+    CHECK(F.S() == 32 && F.capacity() == 254);
+    test_domain_errors(F);
+    test_fft_inverse_identity(F);
+    test_lde_correctness(F);
+    test_make_small_iop(F);
+    test_one_fri_step(F);
+    printf("host_cpp: all tests passed\n");
+    return 0;
+}

@@ -275,3 +275,52 @@ def test_device_lde_and_commit_consistency(gpu_ctxs, oracles):
     lde = O.poly_lde(coeffs, factor)
     assert np.array_equal(d_lde.cpu().numpy().view(np.uint64), lde)
     assert np.array_equal(d_nodes.cpu().numpy(), O.iop_create(lde))
+
+
+# ---------------------------------------------------------------- 6-step building blocks on device
+@pytest.mark.parametrize("log_len,batch", [(3, 5), (8, 16), (12, 8), (13, 3)])
+def test_batched_fft_dev(gpu_ctxs, oracles, log_len, batch):
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    L = 1 << log_len
+    a = O.random_elements(L * batch, 11 + log_len)
+    _, _, w = O.domain(L)
+    d = torch.from_numpy(a.view(np.int64)).cuda()
+    out = torch.empty_like(d)
+    ctx.fft_batch_dev(d, out, log_len, batch, w)
+    ctx.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        row = a[b * L:(b + 1) * L].copy()
+        O.serial_fft(row, w, log_len)
+        assert np.array_equal(got[b * L:(b + 1) * L], row), b
+    # in place
+    ctx.fft_batch_dev(d, d, log_len, batch, w)
+    ctx.synchronize()
+    assert torch.equal(d, out)
+
+
+@pytest.mark.parametrize("log_n", [6, 10, 16, 19])
+def test_sixstep_single_rank_on_device(gpu_ctxs, oracles, log_n):
+    """hodor_amd/sixstep.py with the HIP backend at world = 1 (the all-to-alls degenerate to copies):
+    column NTTs, twiddle step and row NTTs on device == single-device transform == oracle."""
+    import torch
+    from hodor_amd.sixstep import HipBackend, sixstep_intt, sixstep_ntt
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    a = O.random_elements(n, 2 + log_n)
+    _, k, w = O.domain(n)
+    d = torch.from_numpy(a.view(np.int64)).cuda()
+    be = HipBackend(ctx)
+    out = sixstep_ntt(be, d, log_n, w, 0, 1)
+    ref = torch.empty_like(d)
+    ctx.poly_fft_dev(d, ref, log_n)
+    ctx.synchronize()
+    assert torch.equal(out, ref)
+    if log_n <= 16:
+        exp = a.copy()
+        O.serial_fft(exp, w, k)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), exp)
+    back = sixstep_intt(be, out, log_n, w, 0, 1)
+    ctx.synchronize()
+    assert torch.equal(back, d)

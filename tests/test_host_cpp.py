@@ -1,0 +1,33 @@
+"""Builds and runs tests/host_cpp/test_host.cpp: the reference's own inline tests (test_worker_size,
+test_lde_correctness, make_small_iop, test_one_fri_step) restated in C++ against the host mirror of the
+Rust interface (hodor_amd/csrc/host/hodor.hpp), i.e. host C++ -> C ABI -> HIP kernels."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_cpp", "test_host.cpp")
+
+
+def _build(tmp_path):
+    import hodor_amd
+    hodor_amd.build()
+    exe = str(tmp_path / "test_host")
+    libdir = os.path.join(ROOT, "hodor_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", SRC, "-L" + libdir, "-lhodor_gpu",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_host_mirror_compiles_against_the_c_abi(tmp_path):
+    """CPU: the C++ host layer needs nothing but include/hodor_gpu.h and the shared library."""
+    assert os.path.exists(_build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_reference_tests_in_cpp(tmp_path):
+    exe = _build(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout

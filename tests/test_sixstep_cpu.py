@@ -1,0 +1,100 @@
+"""world_size-2 (and 4) gloo test of the distributed 6-step NTT schedule (hodor_amd/sixstep.py): the
+all-to-all transposes and index maps run for real on CPU tensors; the local column/row transforms go
+through the CPU oracle instead of the HIP kernels.  Result must equal the single-device transform."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pyref as P
+
+
+class OracleBackend:
+    def __init__(self):
+        from oracle.oracle import Oracle
+        self.O = Oracle(P.BN256.p, P.BN256.g)
+
+    def _np(self, t):
+        return t.numpy().view(np.uint64)
+
+    def batched_ntt(self, buf, batch, log_len, omega):
+        out = buf.clone()
+        arr = self._np(out)
+        L = 1 << log_len
+        for b in range(batch):
+            row = np.ascontiguousarray(arr[b * L:(b + 1) * L])
+            self.O.serial_fft(row, omega, log_len)
+            arr[b * L:(b + 1) * L] = row
+        return out
+
+    def twiddle(self, buf, rows, cols, row0, omega, log_order, scale=None):
+        from oracle.oracle import array_to_ints, ints_to_array
+        arr = self._np(buf)
+        vals = array_to_ints(arr)
+        mask = (1 << log_order) - 1
+        for r in range(rows):
+            for c in range(cols):
+                v = vals[r * cols + c]
+                e = ((row0 + r) * c) & mask
+                if e:
+                    v = self.O.mul(v, self.O.pow(omega, e))
+                if scale is not None:
+                    v = self.O.mul(v, scale)
+                vals[r * cols + c] = v
+        arr[:] = ints_to_array(vals)
+        return buf
+
+    def pow(self, a, e):
+        return self.O.pow(a, e)
+
+    def inverse(self, a):
+        return self.O.inverse(a)
+
+    def from_u64(self, v):
+        return self.O.from_canonical(v)
+
+
+def _worker(rank, world, port, log_n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hodor_amd.sixstep import sixstep_intt, sixstep_ntt
+        be = OracleBackend()
+        O = be.O
+        n = 1 << log_n
+        full = O.random_elements(n, 4321)                       # same seed on every rank
+        _, k, omega = O.domain(n)
+        blk = n // world
+        mine = torch.from_numpy(full[rank * blk:(rank + 1) * blk].copy().view(np.int64))
+        out = sixstep_ntt(be, mine, log_n, omega, rank, world)
+        exp = full.copy()
+        O.serial_fft(exp, omega, k)
+        ok_fwd = np.array_equal(out.numpy().view(np.uint64), exp[rank * blk:(rank + 1) * blk])
+        back = sixstep_intt(be, out, log_n, omega, rank, world)
+        ok_inv = np.array_equal(back.numpy().view(np.uint64), full[rank * blk:(rank + 1) * blk])
+        ret[rank] = (ok_fwd, ok_inv)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 6), (2, 9), (4, 8)])
+def test_sixstep_matches_single_device_transform(world, log_n):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), log_n, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r] == (True, True), (r, ret[r])
