@@ -1,0 +1,12 @@
+# Phase ablation of k_ntt_pass (profiling only; results are wrong by construction):
+# HODOR_DBG bits: 1 skip butterflies, 2 skip inter-pass twiddles, 4 skip global loads, 8 skip global stores
+run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', round(d['ms_per_step'],3))"; }
+run HODOR_DBG=0
+run HODOR_DBG=1
+run HODOR_DBG=2
+run HODOR_DBG=3
+run HODOR_DBG=4
+run HODOR_DBG=8
+run HODOR_DBG=12
+run HODOR_DBG=15
+run HODOR_DBG=14

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include "../hodor_amd/csrc/fr.cuh"
+#include "../hodor_amd/csrc/fr9.cuh"
 
 using namespace hodor;
 #define ITERS 2048
@@ -200,6 +200,41 @@ __global__ void k_frmul_cios(uint64_t *out, FrParams P, uint32_t seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+__global__ void k_fr9mul(uint64_t *out, Fr9Params Q, uint32_t seed)
+{
+    Fr9 x[2], w;
+    for (int i = 0; i < 9; i++) {
+        x[0].v[i] = (seed + i + threadIdx.x) & HODOR_M29; x[1].v[i] = (seed * 3 + i + blockIdx.x) & HODOR_M29;
+        w.v[i] = (seed * 7 + i) & HODOR_M29;
+    }
+    x[0].v[8] &= 0xfffff; x[1].v[8] &= 0xfffff; w.v[8] &= 0xfffff;
+    for (int it = 0; it < MUL_ITERS; it++) {
+        x[0] = fr9_mul(x[0], w, Q);
+        x[1] = fr9_mul(x[1], w, Q);
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 9; i++) s += x[0].v[i] + x[1].v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_fr9addsub(uint64_t *out, Fr9Params Q, uint32_t seed)
+{
+    Fr9 x[2], w;
+    for (int i = 0; i < 9; i++) {
+        x[0].v[i] = (seed + i + threadIdx.x) & HODOR_M29; x[1].v[i] = (seed * 3 + i + blockIdx.x) & HODOR_M29;
+        w.v[i] = (seed * 7 + i) & HODOR_M29;
+    }
+    for (int it = 0; it < MUL_ITERS; it++) {
+        x[0] = fr9_add(x[0], w);
+        x[1] = fr9_sub(x[1], w, Q);
+        fr9_normalize(x[0]);
+        fr9_normalize(x[1]);
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 9; i++) s += x[0].v[i] + x[1].v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_fraddsub(uint64_t *out, FrParams P, uint32_t seed)
 {
     Fr x[2], w;
@@ -279,6 +314,14 @@ int main()
         printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr_mul_cios", ms, muls / ms * 1e-6);
         ms = time_it([&] { hipLaunchKernelGGL(k_fraddsub, dim3(blocks), dim3(threads), 0, 0, out, P, 12345u); });
         printf("%-16s %8.3f ms  %8.2f Gop/s\n", "fr_add+fr_sub", ms, muls / ms * 1e-6);
+        Fr9Params Q;
+        const uint32_t p9[9] = {0x00000001, 0x1ffffff8, 0x1f96ffbf, 0x1b4805ff, 0x0c0a77b4, 0x0c0404d0, 0x11f52199, 0x1a94ce9d, 0x0073eda7};
+        for (int i = 0; i < 9; i++) { Q.p[i] = p9[i]; Q.c4p[i] = 0x20000000u + p9[i]; }
+        Q.pinv = 0x1fffffff; Q.mu = 2262;
+        ms = time_it([&] { hipLaunchKernelGGL(k_fr9mul, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
+        printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr9_mul (9x29)", ms, muls / ms * 1e-6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_fr9addsub, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
+        printf("%-16s %8.3f ms  %8.2f Gop/s (incl. normalize)\n", "fr9_add+sub", ms, muls / ms * 1e-6);
     }
     {
         size_t n = (size_t)1 << 26;   // 1 GiB of uint4

@@ -17,9 +17,9 @@
 namespace hodor {
 
 // kernels' host launchers (ntt.hip, pointwise.hip, merkle.hip, fri.hip)
-hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr *scale, const FrParams &);
+hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr9 *scale, const Fr9Params &);
 hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
-                            uint32_t log_stride, uint64_t count, const FrParams &);
+                            uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
 hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
 hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
@@ -41,10 +41,88 @@ static Fr to_dev(const HFr &a)
     return r;
 }
 
+// split a 256-bit integer (4 x u64) into 9 limbs of 29 bits
+static void split29(const uint64_t l[4], uint32_t out[9])
+{
+    for (int i = 0; i < 9; i++) {
+        int bit = 29 * i, w = bit >> 6, s = bit & 63;
+        uint64_t v = l[w] >> s;
+        if (s > 35 && w < 3) v |= l[w + 1] << (64 - s);
+        out[i] = (uint32_t)(v & 0x1fffffffu);
+    }
+}
+
+// R-form host element (x * 2^256) -> R'-form 9 x 29-bit multiplier operand (x * 2^261 mod p)
+static Fr9 to_dev9(const HostField &F, const HFr &a)
+{
+    HFr t = a;
+    for (int i = 0; i < 5; i++) t = F.add(t, t);
+    Fr9 r;
+    split29(t.l, r.v);
+    return r;
+}
+
+// constants of fr9.cuh for this modulus
+static void make_params9(const HostField &F, Fr9Params *Q)
+{
+    split29(F.p, Q->p);
+    uint32_t p0 = Q->p[0], inv = 1;               // p0 odd: Newton iteration mod 2^32, then mask
+    for (int i = 0; i < 5; i++) inv *= 2 - p0 * inv;
+    Q->pinv = (0u - inv) & 0x1fffffffu;
+    // 4p spread: limb i (< 8) borrows 2^29 from limb i+1 so that every low limb is >= 2^29 - 1
+    uint64_t p4[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        p4[i] |= F.p[i] << 2;
+        p4[i + 1] |= F.p[i] >> 62;
+    }
+    uint32_t q[9];
+    for (int i = 0; i < 9; i++) {
+        int bit = 29 * i, w = bit >> 6, s = bit & 63;
+        uint64_t v = p4[w] >> s;
+        if (s > 35) v |= p4[w + 1] << (64 - s);
+        q[i] = (uint32_t)(i < 8 ? (v & 0x1fffffffu) : v);
+    }
+    for (int i = 0; i < 9; i++) {
+        uint32_t c = q[i];
+        if (i < 8) c += 1u << 29;
+        if (i > 0) c -= 1;
+        Q->c4p[i] = c;
+    }
+    // mu = floor(2^266 / p) by binary long division (quotient has ~12 bits)
+    uint64_t rem[5] = {0, 0, 0, 0, 0};
+    uint32_t mu = 0;
+    for (int bit = 266; bit >= 0; bit--) {
+        for (int i = 4; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);   // rem <<= 1
+        rem[0] <<= 1;
+        if (bit == 266) rem[0] |= 1;
+        bool ge = rem[4] != 0;
+        if (!ge) {
+            ge = true;
+            for (int i = 3; i >= 0; i--) {
+                if (rem[i] > F.p[i]) break;
+                if (rem[i] < F.p[i]) { ge = false; break; }
+            }
+        }
+        mu <<= 1;
+        if (ge) {
+            uint64_t bw = 0;
+            for (int i = 0; i < 4; i++) {
+                u128_t d = (u128_t)rem[i] - F.p[i] - bw;
+                rem[i] = (uint64_t)d;
+                bw = (uint64_t)(d >> 64) & 1;
+            }
+            rem[4] -= bw;
+            mu |= 1;
+        }
+    }
+    Q->mu = mu;
+}
+
 struct PowTable {
     HFr base;
     uint32_t log_n;
     uint32_t lo_bits;
+    uint32_t fmt;          // 0: 32-byte R-form entries, 1: 48-byte 9 x 29-bit R'-form entries
     uint4 *lo, *hi;
 };
 
@@ -62,6 +140,7 @@ struct hodor_ctx {
     int device = -1;
     HostField F;
     FrParams P;
+    Fr9Params Q;
     B2Mid mid;
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -69,14 +148,18 @@ struct hodor_ctx {
     std::vector<RadixTable> radix_tables;
     void *scratch[2] = {nullptr, nullptr};
     size_t scratch_bytes[2] = {0, 0};
-    uint32_t max_log_r = 8;    // largest per-pass radix (2^max_log_r points)
-    uint32_t tile_log = 11;    // elements per workgroup tile = 2^tile_log
+    void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
+    size_t fri_slab_bytes = 0;
+    uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
+    uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
     std::string err;
 };
 
 struct hodor_fri_proto {
     hodor_ctx *ctx;
     size_t n, num_steps, lde_factor, out_deg, initial_degree_plus_one;
+    void *slab = nullptr;                     // one device allocation holding everything below
+    size_t slab_bytes = 0;
     void *l0_nodes = nullptr;                 // device, n*32
     std::vector<void *> inter_values;         // device
     std::vector<void *> inter_nodes;          // device
@@ -132,12 +215,13 @@ static int free_tables(hodor_ctx *ctx)
 }
 
 // base^e = lo[e & mask] * hi[e >> lo_bits] for e < 2^log_n
-static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out,
+// fmt 1 = 9 x 29-bit R'-form entries for k_ntt_pass, fmt 0 = 32-byte R-form entries (fold, twiddle_mul)
+static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
                          uint32_t lo_bits = 0xffffffffu)
 {
     if (lo_bits > log_n) lo_bits = (log_n + 1) / 2;
     for (auto &t : ctx->pow_tables)
-        if (t.log_n == log_n && t.lo_bits == lo_bits && t.base == base) {
+        if (t.log_n == log_n && t.lo_bits == lo_bits && t.fmt == fmt && t.base == base) {
             *out = TwoLevel{t.lo, t.hi, t.lo_bits};
             return HODOR_OK;
         }
@@ -146,12 +230,14 @@ static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLev
     t.base = base;
     t.log_n = log_n;
     t.lo_bits = lo_bits;
+    t.fmt = fmt;
+    const size_t esz = fmt ? 48 : 32;
     uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
-    HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * 32));
-    HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * 32));
+    HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * esz));
+    HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * esz));
     Fr b = to_dev(base), one = to_dev(ctx->F.one);
-    HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, ctx->P));
-    HIPCHK(pow_table_launch(ctx->stream, t.hi, b, one, t.lo_bits, hi_cnt, ctx->P));
+    HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, fmt, ctx->P));
+    HIPCHK(pow_table_launch(ctx->stream, t.hi, b, one, t.lo_bits, hi_cnt, fmt, ctx->P));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // tables are shared across streams afterwards
     ctx->pow_tables.push_back(t);
     *out = TwoLevel{t.lo, t.hi, t.lo_bits};
@@ -173,8 +259,8 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     t.log_n = log_n;
     t.log_r = log_r;
     uint64_t cnt = log_r ? (1ull << (log_r - 1)) : 1;
-    HIPCHK(hipMalloc((void **)&t.rtw, cnt * 32));
-    HIPCHK(pow_table_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt,
+    HIPCHK(hipMalloc((void **)&t.rtw, cnt * 48));
+    HIPCHK(pow_table_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt, 1,
                             ctx->P));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->radix_tables.push_back(t);
@@ -231,9 +317,9 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         uint32_t shift2 = log_n - radices[0] - radices[1];
         if (log_n - shift2 <= 17 && shift2 <= 16) tw_lo_bits = shift2;
     }
-    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw, tw_lo_bits))) return rc;
-    if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t))) return rc;
-    if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t))) return rc;
+    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw, 1, tw_lo_bits))) return rc;
+    if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t, 1))) return rc;
+    if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t, 1))) return rc;
 
     // ping-pong buffers: the last pass writes dst; a pass never runs in place unless it is the only
     // one (a single tile is fully staged in LDS before anything is written back).
@@ -259,8 +345,8 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
 
     uint32_t log_l = 0;
     const uint4 *cur = src;
-    Fr scale_d;
-    if (scale) scale_d = to_dev(*scale);
+    Fr9 scale_d = {};
+    if (scale) scale_d = to_dev9(ctx->F, *scale);
     for (size_t i = 0; i < passes; i++) {
         uint32_t log_r = radices[i];
         PassArgs A;
@@ -279,7 +365,13 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         A.log_l = log_l;
         A.apply_tw = (i == 0) ? 0 : 1;
         A.batch = batch;
-        HIPCHK(ntt_launch_pass(stream, A, (scale && i + 1 == passes) ? &scale_d : nullptr, ctx->P));
+        A.dbg = 0;
+        A.log_skip = 0;
+        if (i == 0 && nnz && nnz < (1ull << log_n) && !(nnz & (nnz - 1))) {
+            uint32_t s = log_n - log2u((size_t)nnz);
+            A.log_skip = s < log_r ? s : log_r;
+        }
+        HIPCHK(ntt_launch_pass(stream, A, (scale && i + 1 == passes) ? &scale_d : nullptr, ctx->Q));
         cur = outs[i];
         log_l += log_r;
     }
@@ -355,6 +447,7 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
     ctx->P.pinv = (uint32_t)ctx->F.pinv;
     Fr one = to_dev(ctx->F.one);
     for (int i = 0; i < 8; i++) ctx->P.one[i] = one.v[i];
+    make_params9(ctx->F, &ctx->Q);
     // BASE_BLAKE2S_PARAMS, src/iop/blake2s_trivial_iop.rs:8-16
     HostBlake2s::keyed_midstate(ctx->mid.h, (const uint8_t *)"Squeamish Ossifrage", 19,
                                 (const uint8_t *)"Shaftoe", 7);
@@ -387,6 +480,7 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
         for (int i = 0; i < 2; i++)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+        if (ctx->fri_slab) (void)hipFree(ctx->fri_slab);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -577,7 +671,7 @@ extern "C" int hodor_twiddle_mul_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, 
     if (log_order > 62) return HODOR_ERR_SIZE;
     std::lock_guard<std::mutex> lk(ctx->mu);
     TwoLevel t;
-    int rc = get_pow_table(ctx, to_h(omega), log_order, &t);
+    int rc = get_pow_table(ctx, to_h(omega), log_order, &t, 0);
     if (rc) return rc;
     Fr sc = {};
     if (scale) sc = to_dev(to_h(scale));
@@ -596,14 +690,26 @@ extern "C" int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr
     return HODOR_OK;
 }
 
+// The prototype's device buffers (l0 tree, every intermediate vector and tree, the small result block)
+// are carved from ONE slab; a freed slab is parked on the context and reused by the next commit of a
+// size that fits, so a prover committing polynomial after polynomial pays hipMalloc once.
 extern "C" void hodor_fri_free(hodor_fri_proto *p)
 {
     if (!p) return;
-    if (p->ctx && p->ctx->device >= 0) {
-        (void)hipSetDevice(p->ctx->device);
-        if (p->l0_nodes) (void)hipFree(p->l0_nodes);
-        for (void *q : p->inter_values) if (q) (void)hipFree(q);
-        for (void *q : p->inter_nodes) if (q) (void)hipFree(q);
+    hodor_ctx *ctx = p->ctx;
+    if (ctx && ctx->device >= 0 && p->slab) {
+        (void)hipSetDevice(ctx->device);
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->fri_slab) {
+            ctx->fri_slab = p->slab;
+            ctx->fri_slab_bytes = p->slab_bytes;
+        } else if (p->slab_bytes > ctx->fri_slab_bytes) {
+            (void)hipFree(ctx->fri_slab);
+            ctx->fri_slab = p->slab;
+            ctx->fri_slab_bytes = p->slab_bytes;
+        } else {
+            (void)hipFree(p->slab);
+        }
     }
     delete p;
 }
@@ -643,27 +749,48 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
         hipError_t e__ = (expr);                                                       \
         if (e__ != hipSuccess) {                                                       \
             ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);             \
-            hodor_fri_free(p);                                                         \
-            if (d_small) (void)hipFree(d_small);                                       \
+            fri_release(p);                                                            \
             return HODOR_ERR_DEVICE;                                                   \
         }                                                                              \
     } while (0)
 
-    // small device block: challenges [num_steps+1] | roots [num_steps+1] | final values/coeffs
-    uint8_t *d_small = nullptr;
+    // slab layout: l0 tree | per step: values, tree | small block (challenges, roots, final coeffs)
     size_t fin_n = n >> num_steps;
     size_t small_bytes = 32 * (num_steps + 1) * 2 + 32 * fin_n * 2;
-    FRICHK(hipMalloc((void **)&d_small, small_bytes));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t need = up(n * 32) + up(small_bytes);
+    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
+    auto fri_release = [&](hodor_fri_proto *q) {   // error path: the ctx mutex is already held
+        if (q->slab) (void)hipFree(q->slab);
+        delete q;
+    };
+    if (ctx->fri_slab && ctx->fri_slab_bytes >= need) {
+        p->slab = ctx->fri_slab;
+        p->slab_bytes = ctx->fri_slab_bytes;
+        ctx->fri_slab = nullptr;
+        ctx->fri_slab_bytes = 0;
+    } else {
+        FRICHK(hipMalloc(&p->slab, need));
+        p->slab_bytes = need;
+    }
+    uint8_t *cursor = (uint8_t *)p->slab;
+    auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
+    p->l0_nodes = carve(n * 32);
+    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) {
+        p->inter_values.push_back(carve(sz * 32));
+        p->inter_nodes.push_back(carve(sz * 32));
+        p->inter_sizes.push_back(sz);
+    }
+    uint8_t *d_small = (uint8_t *)carve(small_bytes);
     uint4 *d_chal = (uint4 *)d_small;
     uint4 *d_roots = (uint4 *)(d_small + 32 * (num_steps + 1));
     uint4 *d_fin = (uint4 *)(d_small + 64 * (num_steps + 1));
 
     TwoLevel winv;
-    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv))) { hodor_fri_free(p); (void)hipFree(d_small); return rc; }
+    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv, 0))) { fri_release(p); return rc; }
     uint32_t shave = 256 - ctx->F.capacity;
     Fr r2 = to_dev(ctx->F.r2);
 
-    FRICHK(hipMalloc(&p->l0_nodes, n * 32));
     FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
     FRICHK(challenge_launch(stream, (const uint4 *)p->l0_nodes, d_chal, r2, shave, ctx->P));             // :51
     FRICHK(hipMemcpyAsync(d_roots, (const uint8_t *)p->l0_nodes + 32, 32, hipMemcpyDeviceToDevice, stream));
@@ -671,12 +798,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     const uint4 *values = (const uint4 *)lde_values;
     size_t next_size = n / 2;
     for (size_t i = 0; i < num_steps; i++) {                                                             // :61
-        void *next = nullptr, *nodes = nullptr;
-        FRICHK(hipMalloc(&next, next_size * 32));
-        p->inter_values.push_back(next);
-        FRICHK(hipMalloc(&nodes, next_size * 32));
-        p->inter_nodes.push_back(nodes);
-        p->inter_sizes.push_back(next_size);
+        void *next = p->inter_values[i], *nodes = p->inter_nodes[i];
         FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv, (uint32_t)i, d_chal + 2 * i,
                                ctx->P));                                                                 // :70-104
         FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid));   // :106
@@ -688,7 +810,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     }
     // final: values -> ifft -> truncate (:130-145)
     rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
-    if (rc) { hodor_fri_free(p); (void)hipFree(d_small); return rc; }
+    if (rc) { fri_release(p); return rc; }
 
     p->roots.resize(32 * (num_steps + 1));
     p->challenges.resize(num_steps);
@@ -698,7 +820,6 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     FRICHK(hipMemcpyAsync(p->final_coeffs.data(), d_fin, 32 * out_deg, hipMemcpyDeviceToHost, stream));
     FRICHK(hipStreamSynchronize(stream));
     memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
-    (void)hipFree(d_small);
 #undef FRICHK
     *out = p;
     return HODOR_OK;

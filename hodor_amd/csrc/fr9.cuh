@@ -1,0 +1,205 @@
+// fr9.cuh — K1': carry-free field arithmetic for the NTT inner loops: 9 limbs of 29 bits.
+//
+// Why: on gfx950 every 32x32 multiply form issues at half the VALU rate and so does every
+// carry-in add (bench/microbench.hip), so a 32-bit-limb Montgomery product costs 128 mads PLUS 128
+// carry instructions and a field add/sub is a 16-deep VCC chain.  With 29-bit limbs the column sums
+// of a product (<= 18 terms of < 2^60) fit a 64-bit accumulator, so a product is 162
+// v_mad_u64_u32 and ~45 cheap ops with no carry handling at all, and add/sub are 9 independent
+// 32-bit adds.  Values are kept lazily reduced inside a kernel and brought back to the canonical
+// 8 x 32-bit Montgomery image (the reference's memory format, R = 2^256) when they leave it.
+//
+// Representation: value = sum v[i] * 2^(29 i).  "normalized" = every limb < 2^29.
+// Montgomery radix here is R' = 2^261.  Data stays in the reference's R-form (x * 2^256); every
+// multiplication in the transforms is data x table-constant, and the constants are stored in
+// R'-form (w * 2^261), so  (x 2^256)(w 2^261) / 2^261 = (x w) 2^256  — no conversion of the data.
+//
+// Bounds (p < 2^255):
+//   fr9_mul(a, b): a may be lazy (limbs < 2^31.5, value < 2^261), b normalized with value < 2p;
+//                  result normalized, value < a*b/2^261 + p  (< 1.5 p for a < 2^260, b < p).
+//   fr9_add: limb-wise, no reduction.   fr9_sub(a, b) = a + C - b with C = 4p spread so that every
+//                  low limb of C is >= 2^29 (b must be normalized, value < 4p).
+#pragma once
+#include "fr.cuh"
+
+namespace hodor {
+
+#define HODOR_M29 0x1fffffffu
+
+struct Fr9 {
+    uint32_t v[9];
+};
+
+struct Fr9Params {      // kernel argument -> SGPRs
+    uint32_t p[9];      // modulus, normalized 29-bit limbs
+    uint32_t pinv;      // -p^-1 mod 2^29
+    uint32_t c4p[9];    // 4p with limbs 0..7 in [2^29, 2^30): subtraction offset
+    uint32_t mu;        // floor(2^266 / p): quotient estimate for the partial reduction
+};
+
+// ---- format conversion: 8 x 32-bit words <-> 9 x 29-bit limbs (same integer) ----
+__device__ __forceinline__ Fr9 fr9_unpack(const Fr &a)
+{
+    Fr9 r;
+    r.v[0] = a.v[0] & HODOR_M29;
+    r.v[1] = ((a.v[0] >> 29) | (a.v[1] << 3)) & HODOR_M29;
+    r.v[2] = ((a.v[1] >> 26) | (a.v[2] << 6)) & HODOR_M29;
+    r.v[3] = ((a.v[2] >> 23) | (a.v[3] << 9)) & HODOR_M29;
+    r.v[4] = ((a.v[3] >> 20) | (a.v[4] << 12)) & HODOR_M29;
+    r.v[5] = ((a.v[4] >> 17) | (a.v[5] << 15)) & HODOR_M29;
+    r.v[6] = ((a.v[5] >> 14) | (a.v[6] << 18)) & HODOR_M29;
+    r.v[7] = ((a.v[6] >> 11) | (a.v[7] << 21)) & HODOR_M29;
+    r.v[8] = a.v[7] >> 8;
+    return r;
+}
+
+// requires normalized limbs and value < 2^256
+__device__ __forceinline__ Fr fr9_pack(const Fr9 &a)
+{
+    Fr r;
+    r.v[0] = a.v[0] | (a.v[1] << 29);
+    r.v[1] = (a.v[1] >> 3) | (a.v[2] << 26);
+    r.v[2] = (a.v[2] >> 6) | (a.v[3] << 23);
+    r.v[3] = (a.v[3] >> 9) | (a.v[4] << 20);
+    r.v[4] = (a.v[4] >> 12) | (a.v[5] << 17);
+    r.v[5] = (a.v[5] >> 15) | (a.v[6] << 14);
+    r.v[6] = (a.v[6] >> 18) | (a.v[7] << 11);
+    r.v[7] = (a.v[7] >> 21) | (a.v[8] << 8);
+    return r;
+}
+
+// carry propagation of lazy (unsigned, < 2^32) limbs
+__device__ __forceinline__ void fr9_normalize(Fr9 &a)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t c = a.v[i] >> 29;
+        a.v[i] &= HODOR_M29;
+        a.v[i + 1] += c;
+    }
+}
+
+// borrow/carry propagation when limbs are signed (after a limb-wise subtraction)
+__device__ __forceinline__ void fr9_normalize_signed(Fr9 &a)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t c = (int32_t)a.v[i] >> 29;
+        a.v[i] &= HODOR_M29;
+        a.v[i + 1] += (uint32_t)c;
+    }
+}
+
+__device__ __forceinline__ Fr9 fr9_add(const Fr9 &a, const Fr9 &b)
+{
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+
+// a - b + 4p, limb-wise non-negative when b is normalized and < 4p
+__device__ __forceinline__ Fr9 fr9_sub(const Fr9 &a, const Fr9 &b, const Fr9Params &P)
+{
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (P.c4p[i] - b.v[i]);
+    return r;
+}
+
+// Montgomery product a * b / 2^261 mod p (not fully reduced, see header).  Plain C++: the compiler
+// emits one v_mad_u64_u32 per limb product (162) and no carry instructions.
+__device__ __forceinline__ Fr9 fr9_mul(const Fr9 &a, const Fr9 &b, const Fr9Params &P)
+{
+    uint32_t m[9];
+    Fr9 t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int j = 0; j <= k; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+#pragma unroll
+        for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * P.p[k - j];
+        m[k] = ((uint32_t)acc * P.pinv) & HODOR_M29;
+        acc += (uint64_t)m[k] * P.p[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int j = k - 8; j < 9; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+#pragma unroll
+        for (int j = k - 8; j < 9; j++) acc += (uint64_t)m[j] * P.p[k - j];
+        t.v[k - 9] = (uint32_t)acc & HODOR_M29;
+        acc >>= 29;
+    }
+    t.v[8] = (uint32_t)acc;
+    return t;
+}
+
+// Bring a lazy value (limbs < 2^32, value < 2^261) below 2^250 + 2p < 2^256 by subtracting
+// q*p with q = floor(floor(x / 2^250) * mu / 2^16) <= floor(x / p); result normalized.
+__device__ __forceinline__ void fr9_reduce_partial(Fr9 &a, const Fr9Params &P)
+{
+    fr9_normalize(a);
+    // bits >= 250 : limb 8 holds bits 232.., so x >> 250 = v[8] >> 18
+    uint32_t q = ((a.v[8] >> 18) * P.mu) >> 16;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t s = (uint64_t)q * P.p[i] + carry;
+        a.v[i] -= (uint32_t)s & HODOR_M29;
+        carry = s >> 29;
+    }
+    a.v[8] -= (uint32_t)((uint64_t)q * P.p[8] + carry);   // q*p <= x, so this limb fits
+    fr9_normalize_signed(a);
+}
+
+// conditional subtraction: a in [0, 2^30 * ...) normalized; returns a - p if a >= p else a
+__device__ __forceinline__ void fr9_cond_sub_p(Fr9 &a, const Fr9Params &P)
+{
+    Fr9 d;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] = a.v[i] - P.p[i];
+    fr9_normalize_signed(d);
+    bool neg = (int32_t)d.v[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.v[i] = neg ? a.v[i] : d.v[i];
+}
+
+// lazy value -> canonical [0, p) in the 8 x 32-bit memory format
+__device__ __forceinline__ Fr fr9_to_canonical(Fr9 a, const Fr9Params &P)
+{
+    fr9_reduce_partial(a, P);      // < 2^250 + 2p  (< 3p)
+    fr9_cond_sub_p(a, P);
+    fr9_cond_sub_p(a, P);
+    return fr9_pack(a);
+}
+
+// lazy value -> some representative < 2^256 in the 8 x 32-bit memory format (between passes)
+__device__ __forceinline__ Fr fr9_to_packed(Fr9 a, const Fr9Params &P)
+{
+    fr9_reduce_partial(a, P);
+    return fr9_pack(a);
+}
+
+// ---- table entries: 9 limbs stored in 12 words (48 B = 3 x dwordx4) ----
+__device__ __forceinline__ Fr9 fr9_load48(const void *ptr)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(ptr);
+    uint4 a = q[0], b = q[1], c = q[2];
+    Fr9 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c.x;
+    return r;
+}
+
+__device__ __forceinline__ void fr9_store48(void *ptr, const Fr9 &a)
+{
+    uint4 *q = reinterpret_cast<uint4 *>(ptr);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    q[2] = make_uint4(a.v[8], 0, 0, 0);
+}
+
+}  // namespace hodor

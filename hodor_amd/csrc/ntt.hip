@@ -14,10 +14,17 @@
 //     global read and write is a run of C*32 contiguous bytes.
 //   * Inside the workgroup the R-point transform runs out of LDS (in-place DIT, two radix-2 stages
 //     fused per barrier = one radix-4 step), twiddles of the sub-transform staged in LDS.
-//   * Elements sit in LDS as two 16-byte halves (lo/hi arrays, rows padded by one slot) so that
-//     ds_read_b128 / ds_write_b128 are conflict-free for both row-major and column-major access.
+//   * Inside the kernel elements live in the carry-free 9 x 29-bit form of fr9.cuh (162 mads per
+//     product, add/sub = 9 plain adds, lazily reduced); HBM always holds the reference's 8 x 32-bit
+//     Montgomery image.  LDS keeps limbs 0-3 / 4-7 as two 16-byte arrays plus a 4-byte array for
+//     limb 8, rows padded by one slot.
 //   * Inter-pass twiddles come from a two-level power table (L2-resident) instead of an n-entry
 //     table streamed from HBM.
+//
+// Value bounds inside a pass (p < 2^255, R' = 2^261 > 64 p): loaded values are < 2.1 p (a packed
+// intermediate) or < 1.5 p (fresh product); each radix-4 step adds at most 8 p (two subtractions
+// with the 4 p offset), so after the <= 5 steps of a pass values stay < 45 p < 2^261, and every
+// subtrahend is a fresh product (< 2 p) except in the twiddle-free first step, handled explicitly.
 #include <cstdlib>
 
 #include "ntt.cuh"
@@ -27,46 +34,63 @@ namespace hodor {
 // ---------------------------------------------------------------------------------------------
 // K2: out[j] = mult * base^(j << log_stride)
 // (counterpart of PrecomputedOmegas::new_for_domain, src/precomputations/mod.rs:14-66)
+// fmt 0: 32-byte R-form entries (fri.hip, pointwise.hip); fmt 1: 48-byte 9 x 29-bit entries in
+// R' = 2^261 form (value * 2^5), the multiplier operand of fr9_mul.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_pow_table(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, FrParams P)
+k_pow_table(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, uint32_t fmt, FrParams P)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fr w = fr_pow(base, j << log_stride, P);
     w = fr_mul(w, mult, P);
-    fr_store(out + 2 * j, w);
+    if (fmt == 0) {
+        fr_store(out + 2 * j, w);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; i++) w = fr_add(w, w, P);   // * 2^5: R-form -> R'-form
+        fr9_store48(out + 3 * j, fr9_unpack(w));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS element accessors: lo halves at [0, slots), hi halves at [slots, 2*slots)
+// LDS element accessors: limbs 0-3 at a4[s], limbs 4-7 at b4[s], limb 8 at c1[s]
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ Fr lds_get(const uint4 *base, uint32_t slots, uint32_t s)
+struct LdsView {
+    uint4 *a4;
+    uint4 *b4;
+    uint32_t *c1;
+};
+
+__device__ __forceinline__ Fr9 lds_get(const LdsView &L, uint32_t s)
 {
-    uint4 lo = base[s], hi = base[slots + s];
-    Fr r;
+    uint4 lo = L.a4[s], hi = L.b4[s];
+    Fr9 r;
     r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
     r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    r.v[8] = L.c1[s];
     return r;
 }
 
-__device__ __forceinline__ void lds_put(uint4 *base, uint32_t slots, uint32_t s, const Fr &a)
+__device__ __forceinline__ void lds_put(const LdsView &L, uint32_t s, const Fr9 &a)
 {
-    base[s] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
-    base[slots + s] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    L.a4[s] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    L.b4[s] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    L.c1[s] = a.v[8];
 }
 
-__device__ __forceinline__ Fr two_level_pow(const TwoLevel &t, uint64_t e, const FrParams &P)
+// base^e from the two-level table (R'-form, normalized, < 2p)
+__device__ __forceinline__ Fr9 two_level_pow9(const TwoLevel &t, uint64_t e, const Fr9Params &Q)
 {
     uint64_t lo_i = e & ((1ull << t.lo_bits) - 1), hi_i = e >> t.lo_bits;
-    Fr h = fr_load(t.hi + 2 * hi_i);
+    Fr9 h = fr9_load48(t.hi + 3 * hi_i);
     if (lo_i == 0) return h;
-    Fr l = fr_load(t.lo + 2 * lo_i);
-    return fr_mul(h, l, P);
+    Fr9 l = fr9_load48(t.lo + 3 * lo_i);
+    return fr9_mul(h, l, Q);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: one Stockham pass.  grid = n / (R*C) workgroups of 256 threads.
+// K3: one Stockham pass.  grid = (n / (R*C), batch) workgroups.
 //
 //   input  index  j + i * (n/R)        i < R (sub-transform input), j < n/R
 //   twiddle       w_(L*R)^(i*p)        p = j mod L, L = product of earlier radices
@@ -75,23 +99,29 @@ __device__ __forceinline__ Fr two_level_pow(const TwoLevel &t, uint64_t e, const
 constexpr int NTT_MAX_THREADS = 512;
 
 __global__ void __launch_bounds__(NTT_MAX_THREADS)
-k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
+k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t log_r = A.log_r, log_c = A.log_c;
     const uint32_t R = 1u << log_r, C = 1u << log_c;
-    const uint32_t RS = (C == 1) ? 1u : C + 1;      // padded row stride (slots)
-    const uint32_t slots = R * RS;
-    uint4 *data = smem;                              // 2 * slots
-    uint4 *tw = smem + 2 * slots;                    // 2 * (R/2): sub-transform twiddles
-    const uint32_t half_r = R >> 1;
+    // element (row, c) sits at slot row*C + (c ^ (row & (C-1))): the XOR swizzle spreads a column over
+    // all C 16-byte bank groups without the 1/C padding (two workgroups must fit the 160 KiB of a CU)
+    const uint32_t Cm = C - 1;
+#define SLOT(row, c) ((((uint32_t)(row)) << log_c) + (((uint32_t)(c)) ^ (((uint32_t)(row)) & Cm)))
+    const uint32_t slots = R << log_c;
+    const uint32_t half_r = (R >> 1) ? (R >> 1) : 1;
+    // carve: data a4 | data b4 | tw a4 | tw b4 | data c1 | tw c1   (16-byte arrays first)
+    LdsView D, T;
+    D.a4 = smem;
+    D.b4 = smem + slots;
+    T.a4 = smem + 2 * slots;
+    T.b4 = smem + 2 * slots + half_r;
+    D.c1 = reinterpret_cast<uint32_t *>(smem + 2 * slots + 2 * half_r);
+    T.c1 = D.c1 + slots;
 
     // stage omega_R^e (e < R/2) into LDS
-    for (uint32_t e = tid; e < half_r; e += nthreads) {
-        tw[e] = A.rtw[2 * e];
-        tw[half_r + e] = A.rtw[2 * e + 1];
-    }
+    for (uint32_t e = tid; e < (R >> 1); e += nthreads) lds_put(T, e, fr9_load48(A.rtw + 3 * e));
 
     // batched transforms: blockIdx.y selects one of `batch` independent size-n arrays
     const uint4 *src_b = A.src + ((2ull * blockIdx.y) << A.log_n);
@@ -103,40 +133,61 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
     const uint32_t tile = R << log_c;
 
     // ---- load: global -> (pre-scale, inter-pass twiddle) -> LDS at bit-reversed row
-    for (uint32_t e = tid; e < tile; e += nthreads) {
+    // Zero padding (LDE, src/fft/lde.rs:28-31 `is_non_zero`): when only the first n >> s inputs are
+    // non-zero, only sub-transform inputs i < R >> s are, they land on rows that are multiples of 2^s,
+    // and the first s radix-2 stages merely copy each of them to the 2^s rows of its group — so load
+    // 1/2^s of the tile, replicate, and start the butterflies at stage s.
+    const uint32_t log_skip = A.log_skip;
+    for (uint32_t e = tid; e < (tile >> log_skip); e += nthreads) {
         uint32_t c = e & (C - 1), i = e >> log_c;
         uint64_t j = j0 + c;
         uint64_t g = j + (uint64_t)i * n_over_r;
-        Fr x;
+        Fr9 x;
         if (g < A.nnz) {
-            x = fr_load(src_b + 2 * g);
-            if (A.pre.lo != nullptr && g != 0) x = fr_mul(x, two_level_pow(A.pre, g, P), P);
-            if (A.apply_tw) {
+            if (A.dbg & 4) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) x.v[k] = (uint32_t)g + k;
+            } else {
+                x = fr9_unpack(fr_load(src_b + 2 * g));
+            }
+            if (A.pre.lo != nullptr && g != 0) x = fr9_mul(x, two_level_pow9(A.pre, g, Q), Q);
+            if (A.apply_tw && !(A.dbg & 2)) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
-                if (ex != 0) x = fr_mul(x, two_level_pow(A.tw, ex, P), P);
+                if (ex != 0) x = fr9_mul(x, two_level_pow9(A.tw, ex, Q), Q);
             }
         } else {
-            x = fr_zero();
+#pragma unroll
+            for (int k = 0; k < 9; k++) x.v[k] = 0;
         }
         uint32_t row = log_r ? (__brev(i) >> (32 - log_r)) : 0u;
-        lds_put(data, slots, row * RS + c, x);
+        for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, SLOT(row + d, c), x);
     }
     __syncthreads();
 
-    // ---- R-point DIT in LDS
-    uint32_t log_m = 0;
-    if (log_r & 1) {   // one plain radix-2 stage (all twiddles are 1)
+    // ---- R-point DIT in LDS (values lazily reduced: limbs re-normalized once per step)
+    uint32_t log_m = log_skip;
+    if ((log_r - log_m) & 1) {   // odd number of stages left: one radix-2 stage at half-size m
+        const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 1) << log_c;
         for (uint32_t w = tid; w < items; w += nthreads) {
             uint32_t c = w & (C - 1), q = w >> log_c;
-            uint32_t s0 = (2 * q) * RS + c, s1 = s0 + RS;
-            Fr x0 = lds_get(data, slots, s0), x1 = lds_get(data, slots, s1);
-            lds_put(data, slots, s0, fr_add(x0, x1, P));
-            lds_put(data, slots, s1, fr_sub(x0, x1, P));
+            uint32_t jp = q & (m - 1);
+            uint32_t r0 = ((q >> log_m) << (log_m + 1)) + jp;
+            uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c);
+            Fr9 x0 = lds_get(D, s0), x1 = lds_get(D, s1);
+            // m == 1: twiddle 1 and x1 is a stored value (normalized, < 2.1p), a valid subtrahend
+            if (m > 1) x1 = fr9_mul(x1, lds_get(T, jp << (log_r - log_m - 1)), Q);
+            Fr9 y0 = fr9_add(x0, x1), y1 = fr9_sub(x0, x1, Q);
+            fr9_normalize(y0);
+            fr9_normalize(y1);
+            lds_put(D, s0, y0);
+            lds_put(D, s1, y1);
         }
-        log_m = 1;
+        log_m += 1;
         __syncthreads();
     }
+    bool first = true;
+    if (A.dbg & 1) log_m = log_r;
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
@@ -144,40 +195,52 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
             uint32_t c = w & (C - 1), q = w >> log_c;
             uint32_t jp = q & (m - 1);
             uint32_t k = (q >> log_m) << (log_m + 2);
-            uint32_t s0 = (k + jp) * RS + c;
-            uint32_t st = m * RS;
-            Fr x0 = lds_get(data, slots, s0);
-            Fr x1 = lds_get(data, slots, s0 + st);
-            Fr x2 = lds_get(data, slots, s0 + 2 * st);
-            Fr x3 = lds_get(data, slots, s0 + 3 * st);
-            Fr t;
+            const uint32_t r0 = k + jp;
+            const uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c), s2 = SLOT(r0 + 2 * m, c),
+                           s3 = SLOT(r0 + 3 * m, c);
+            Fr9 x0 = lds_get(D, s0);
+            Fr9 x1 = lds_get(D, s1);
+            Fr9 x2 = lds_get(D, s2);
+            Fr9 x3 = lds_get(D, s3);
+            Fr9 t;
             if (m > 1) {
-                Fr wa = lds_get(tw, half_r, jp << (log_r - log_m - 1));
-                t = fr_mul(x1, wa, P);
-                x1 = fr_sub(x0, t, P); x0 = fr_add(x0, t, P);
-                t = fr_mul(x3, wa, P);
-                x3 = fr_sub(x2, t, P); x2 = fr_add(x2, t, P);
-                Fr wb0 = lds_get(tw, half_r, jp << (log_r - log_m - 2));
-                t = fr_mul(x2, wb0, P);
-                x2 = fr_sub(x0, t, P); x0 = fr_add(x0, t, P);
+                Fr9 wa = lds_get(T, jp << (log_r - log_m - 1));
+                t = fr9_mul(x1, wa, Q);
+                x1 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
+                t = fr9_mul(x3, wa, Q);
+                x3 = fr9_sub(x2, t, Q); x2 = fr9_add(x2, t);
+                Fr9 wb0 = lds_get(T, jp << (log_r - log_m - 2));
+                t = fr9_mul(x2, wb0, Q);
+                x2 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
             } else {
-                t = x1; x1 = fr_sub(x0, t, P); x0 = fr_add(x0, t, P);
-                t = x3; x3 = fr_sub(x2, t, P); x2 = fr_add(x2, t, P);
-                t = x2; x2 = fr_sub(x0, t, P); x0 = fr_add(x0, t, P);
+                // twiddles are 1: subtrahends are stored values (normalized, < 2.1p), except the
+                // stage-B one, a lazy sum that is first brought back under 2.1p
+                t = x1; x1 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
+                t = x3; x3 = fr9_sub(x2, t, Q); x2 = fr9_add(x2, t);
+                t = x2;
+                fr9_reduce_partial(t, Q);
+                x2 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
             }
-            Fr wb1 = lds_get(tw, half_r, (jp + m) << (log_r - log_m - 2));
-            t = fr_mul(x3, wb1, P);
-            x3 = fr_sub(x1, t, P); x1 = fr_add(x1, t, P);
-            lds_put(data, slots, s0, x0);
-            lds_put(data, slots, s0 + st, x1);
-            lds_put(data, slots, s0 + 2 * st, x2);
-            lds_put(data, slots, s0 + 3 * st, x3);
+            Fr9 wb1 = lds_get(T, (jp + m) << (log_r - log_m - 2));
+            t = fr9_mul(x3, wb1, Q);
+            x3 = fr9_sub(x1, t, Q); x1 = fr9_add(x1, t);
+            fr9_normalize(x0);
+            fr9_normalize(x1);
+            fr9_normalize(x2);
+            fr9_normalize(x3);
+            lds_put(D, s0, x0);
+            lds_put(D, s1, x1);
+            lds_put(D, s2, x2);
+            lds_put(D, s3, x3);
         }
+        first = false;
         __syncthreads();
     }
+    (void)first;
 
-    // ---- store: LDS -> (scale, post-scale) -> global, Stockham output index
+    // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
     const bool transposed = (A.log_l == 0);   // first pass: outputs of one sub-transform are contiguous
+    const bool last = (A.log_l + log_r == A.log_n);
     for (uint32_t e = tid; e < tile; e += nthreads) {
         uint32_t c, cc;
         if (transposed) { cc = e & (R - 1); c = e >> log_r; }
@@ -185,10 +248,12 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
         uint64_t j = j0 + c;
         uint64_t p = j & Lmask;
         uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << A.log_l);
-        Fr x = lds_get(data, slots, cc * RS + c);
-        if (has_scale) x = fr_mul(x, scale, P);
-        if (A.post.lo != nullptr && o != 0) x = fr_mul(x, two_level_pow(A.post, o, P), P);
-        fr_store(dst_b + 2 * o, x);
+        Fr9 x = lds_get(D, SLOT(cc, c));
+        if (has_scale) x = fr9_mul(x, scale, Q);
+        if (A.post.lo != nullptr && o != 0) x = fr9_mul(x, two_level_pow9(A.post, o, Q), Q);
+        Fr y = last ? fr9_to_canonical(x, Q) : fr9_to_packed(x, Q);
+        if ((A.dbg & 8) && y.v[0] != 0x12345u) continue;
+        fr_store(dst_b + 2 * o, y);
     }
 }
 
@@ -198,11 +263,11 @@ k_ntt_pass(PassArgs A, Fr scale, uint32_t has_scale, FrParams P)
 size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c)
 {
     size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c;
-    size_t RS = (C == 1) ? 1 : C + 1;
-    return (2 * R * RS + 2 * (R / 2 ? R / 2 : 1)) * 16;
+    size_t half_r = (R / 2) ? R / 2 : 1;
+    return (R * C + half_r) * 36;
 }
 
-hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr *scale, const FrParams &P)
+hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *scale, const Fr9Params &Q)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -213,7 +278,7 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr *scal
     }
     uint64_t n = 1ull << A.log_n;
     uint64_t grid = n >> (A.log_r + A.log_c);
-    Fr s = {};
+    Fr9 s = {};
     if (scale) s = *scale;
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c);
     // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
@@ -222,20 +287,27 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr *scal
         const char *e = getenv("HODOR_NTT_THREADS");
         threads_override = e ? atoi(e) : 0;
     }
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char *e = getenv("HODOR_DBG");
+        dbg = e ? atoi(e) : 0;
+    }
+    PassArgs B = A;
+    B.dbg = (uint32_t)dbg;
     uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
     unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
-    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid, A.batch ? A.batch : 1), dim3(threads), lds, stream, A, s,
-                       scale ? 1u : 0u, P);
+    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid, A.batch ? A.batch : 1), dim3(threads), lds, stream, B,
+                       s, scale ? 1u : 0u, Q);
     return hipGetLastError();
 }
 
 hipError_t pow_table_launch(hipStream_t stream, uint4 *out, const Fr &base, const Fr &mult,
-                            uint32_t log_stride, uint64_t count, const FrParams &P)
+                            uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &P)
 {
     unsigned grid = (unsigned)((count + 255) / 256);
-    hipLaunchKernelGGL(k_pow_table, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride,
-                       count, P);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride, count, fmt,
+                       P);
     return hipGetLastError();
 }
 
