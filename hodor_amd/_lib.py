@@ -38,7 +38,7 @@ EXPORTS = [
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_distribute_powers_dev",
-    "hodor_iop_create_dev", "hodor_fri_commit_dev",
+    "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         _lib.hodor_last_error.restype = C.c_char_p
         _lib.hodor_fri_num_steps.restype = C.c_size_t
         _lib.hodor_fri_serialize.restype = C.c_size_t
+        _lib.hodor_fri_produce_proof.restype = C.c_size_t
         _lib.hodor_ctx_destroy.restype = None
         _lib.hodor_fri_free.restype = None
     return _lib
@@ -158,6 +159,44 @@ class FriPrototype:
         out = np.zeros((size, 32), dtype=np.uint8)
         self.ctx._chk(self.ctx.L.hodor_fri_tree_nodes(self.h, C.c_int(step), out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def produce_proof(self, lde_values_dev, natural_index):
+        """FRIProofPrototype::produce_proof -> dict(queries=[(index, value_int, [path])], roots, final_coeffs)."""
+        L = self.ctx.L
+        need = L.hodor_fri_produce_proof(self.h, _dptr(lde_values_dev), C.c_size_t(natural_index), None, C.c_size_t(0))
+        if need == 0:
+            raise HodorError(ERR_INVALID, "hodor_fri_produce_proof")
+        buf = (C.c_uint8 * need)()
+        got = L.hodor_fri_produce_proof(self.h, _dptr(lde_values_dev), C.c_size_t(natural_index), buf, C.c_size_t(need))
+        if got != need:
+            raise HodorError(ERR_DEVICE, "hodor_fri_produce_proof")
+        raw = bytes(buf)
+        o = 0
+
+        def u64():
+            nonlocal o
+            v = int.from_bytes(raw[o:o + 8], "little")
+            o += 8
+            return v
+        queries = []
+        for _ in range(u64()):
+            idx = u64()
+            value = int.from_bytes(raw[o:o + 32], "little")
+            o += 32
+            plen = u64()
+            path = [raw[o + 32 * k:o + 32 * (k + 1)] for k in range(plen)]
+            o += 32 * plen
+            queries.append((idx, value, path))
+        roots = []
+        for _ in range(u64()):
+            roots.append(raw[o:o + 32])
+            o += 32
+        nf = u64()
+        final = [int.from_bytes(raw[o + 32 * k:o + 32 * (k + 1)], "little") for k in range(nf)]
+        o += 32 * nf
+        meta = (u64(), u64(), u64())
+        return dict(queries=queries, roots=roots, final_coeffs=final, initial_degree_plus_one=meta[0],
+                    output_coeffs_at_degree_plus_one=meta[1], lde_factor=meta[2], raw=raw)
 
     def free(self):
         if self.h:
@@ -358,6 +397,14 @@ class Context:
 
     def iop_create_dev(self, leafs, n, nodes, stream=None):
         self._chk(self.L.hodor_iop_create_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n), _dptr(nodes)))
+
+    def iop_query_dev(self, leafs, nodes, n, natural_index, stream=None):
+        value, cnt = _Fr(), C.c_size_t()
+        path = np.zeros((max(1, n.bit_length() - 1), 32), dtype=np.uint8)
+        self._chk(self.L.hodor_iop_query_dev(self.h, C.c_void_p(stream), _dptr(leafs), _dptr(nodes), C.c_size_t(n),
+                                             C.c_size_t(natural_index), C.byref(value),
+                                             path.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return _to_int(value.l), path[:cnt.value]
 
     def fri_commit_dev(self, lde_values, n, lde_factor, out_deg_plus_one, stream=None):
         h = C.c_void_p()

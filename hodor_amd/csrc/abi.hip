@@ -25,6 +25,8 @@ hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const Fr
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
                               const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
 hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &);
+hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
+                            uint64_t index, uint4 *out, const B2Mid &);
 hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &);
 hipError_t fri_fold_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half,
@@ -201,6 +203,13 @@ static inline uint32_t log2u(size_t n)
     return r;
 }
 
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 // tables
 // ------------------------------------------------------------------------------------------------
@@ -211,6 +220,14 @@ static int free_tables(hodor_ctx *ctx)
     for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
     ctx->pow_tables.clear();
     ctx->radix_tables.clear();
+    return HODOR_OK;
+}
+
+// Cache eviction happens only here, at the start of an operation and before it has looked up any
+// table: evicting later would free tables the same operation already holds pointers to.
+static int trim_table_cache(hodor_ctx *ctx)
+{
+    if (ctx->pow_tables.size() > 40 || ctx->radix_tables.size() > 80) return free_tables(ctx);
     return HODOR_OK;
 }
 
@@ -225,7 +242,6 @@ static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLev
             *out = TwoLevel{t.lo, t.hi, t.lo_bits};
             return HODOR_OK;
         }
-    if (ctx->pow_tables.size() >= 48) { int rc = free_tables(ctx); if (rc) return rc; }
     PowTable t;
     t.base = base;
     t.log_n = log_n;
@@ -253,7 +269,6 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
             *out = t.rtw;
             return HODOR_OK;
         }
-    if (ctx->radix_tables.size() >= 96) { int rc = free_tables(ctx); if (rc) return rc; }
     RadixTable t;
     t.omega = omega;
     t.log_n = log_n;
@@ -307,9 +322,10 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
     plan_radices(ctx, log_n, &radices);
     const size_t passes = radices.size();
     const size_t bytes = ((size_t)32 << log_n) * batch;
+    int rc = trim_table_cache(ctx);
+    if (rc) return rc;
 
     TwoLevel tw = {nullptr, nullptr, 0}, pre_t = {nullptr, nullptr, 0}, post_t = {nullptr, nullptr, 0};
-    int rc;
     // Split the exponent so that the second pass (exponents are multiples of n/(R1*R2)) needs only the
     // `hi` table — one multiplication per element instead of two — as long as `hi` stays L2-sized.
     uint32_t tw_lo_bits = 0xffffffffu;
@@ -671,7 +687,9 @@ extern "C" int hodor_twiddle_mul_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, 
     if (log_order > 62) return HODOR_ERR_SIZE;
     std::lock_guard<std::mutex> lk(ctx->mu);
     TwoLevel t;
-    int rc = get_pow_table(ctx, to_h(omega), log_order, &t, 0);
+    int rc = trim_table_cache(ctx);
+    if (rc) return rc;
+    rc = get_pow_table(ctx, to_h(omega), log_order, &t, 0);
     if (rc) return rc;
     Fr sc = {};
     if (scale) sc = to_dev(to_h(scale));
@@ -828,12 +846,6 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
 // ------------------------------------------------------------------------------------------------
 // slice API: host memory in, host memory out
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-}  // namespace
 
 // run `op` on a device copy of a[0..n_in) producing n_out elements back into `out`
 template <class Op>
@@ -1015,6 +1027,98 @@ extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size
     HIPCHK(hipMalloc(&dv.p, n * 32));
     HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
     return hodor_fri_commit_dev(ctx, nullptr, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
+}
+
+// IOP::query on device-resident leaves and tree (src/iop/blake2s_trivial_iop.rs:324-338)
+extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *leafs, const uint8_t *nodes,
+                                   size_t n, size_t natural_index, hodor_fr *value, uint8_t *path,
+                                   size_t *path_len)
+{
+    NEED_DEVICE();
+    if (!leafs || !nodes || !value || !path || !path_len) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2 || natural_index >= n) return HODOR_ERR_SIZE;   // asserts at :325-326
+    hipStream_t stream = pick_stream(ctx, stream_);
+    size_t entries = log2u(n) + 1;
+    DevBuf stage;
+    HIPCHK(hipMalloc(&stage.p, entries * 32));
+    HIPCHK(iop_query_launch(stream, (const uint4 *)(leafs + (natural_index & ~(size_t)1)), (const uint4 *)nodes, n,
+                            natural_index, (uint4 *)stage.p, ctx->mid));
+    std::vector<uint8_t> host(entries * 32);
+    HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    memcpy(value, host.data(), 32);
+    memcpy(path, host.data() + 32, (entries - 1) * 32);
+    *path_len = entries - 1;
+    return HODOR_OK;
+}
+
+// FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53): for the l0 oracle and every
+// intermediate oracle, the two queries of the coset {idx, idx + size/2} (sorted), idx halving as the
+// domain does (Domain::index_and_size_for_next_domain).  Serialised FRIProof (src/fri/mod.rs:139-147):
+//   u64 num_queries | per query: u64 natural_index, value (32 B), u64 path_len, path |
+//   u64 num_roots | roots | u64 n_final | final_coefficients |
+//   u64 initial_degree_plus_one | u64 output_coeffs_at_degree_plus_one | u64 lde_factor
+extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
+                                          size_t natural_first_element_index, uint8_t *buf, size_t cap)
+{
+    if (!p || !lde_values_dev) return 0;
+    hodor_ctx *ctx = p->ctx;
+    if (!ctx || ctx->device < 0 || natural_first_element_index >= p->n) return 0;
+    const size_t rounds = p->num_steps + 1;
+    size_t need = 8, stage_bytes = 0;
+    for (size_t r = 0, sz = p->n; r < rounds; r++, sz >>= 1) {
+        size_t entries = log2u(sz) + 1;
+        need += 2 * (8 + 32 + 8 + (entries - 1) * 32);
+        stage_bytes += 2 * entries * 32;
+    }
+    need += 8 + rounds * 32 + 8 + p->out_deg * 32 + 24;
+    if (!buf || cap < need) return need;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DevBuf stage;
+    if (hipMalloc(&stage.p, stage_bytes) != hipSuccess) return 0;
+    std::vector<size_t> q_index, q_entries;
+    size_t domain_size = p->n, domain_idx = natural_first_element_index, off = 0;
+    for (size_t r = 0; r < rounds; r++) {
+        const hodor_fr *leafs = r == 0 ? lde_values_dev : (const hodor_fr *)p->inter_values[r - 1];
+        const uint4 *nodes = (const uint4 *)(r == 0 ? p->l0_nodes : p->inter_nodes[r - 1]);
+        size_t pair = (domain_idx + domain_size / 2) % domain_size;
+        size_t coset[2] = {domain_idx < pair ? domain_idx : pair, domain_idx < pair ? pair : domain_idx};
+        size_t entries = log2u(domain_size) + 1;
+        for (int k = 0; k < 2; k++) {
+            if (iop_query_launch(ctx->stream, (const uint4 *)(leafs + (coset[k] & ~(size_t)1)), nodes, domain_size,
+                                 coset[k], (uint4 *)((uint8_t *)stage.p + off), ctx->mid) != hipSuccess)
+                return 0;
+            q_index.push_back(coset[k]);
+            q_entries.push_back(entries);
+            off += entries * 32;
+        }
+        size_t next = domain_size / 2;                       // index_and_size_for_next_domain
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+    }
+    std::vector<uint8_t> host(stage_bytes);
+    if (hipMemcpyAsync(host.data(), stage.p, stage_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return 0;
+    size_t o = 0, h = 0;
+    auto put64 = [&](uint64_t v) { memcpy(buf + o, &v, 8); o += 8; };
+    put64(q_index.size());
+    for (size_t q = 0; q < q_index.size(); q++) {
+        put64(q_index[q]);
+        memcpy(buf + o, host.data() + h, 32); o += 32;
+        put64(q_entries[q] - 1);
+        memcpy(buf + o, host.data() + h + 32, (q_entries[q] - 1) * 32); o += (q_entries[q] - 1) * 32;
+        h += q_entries[q] * 32;
+    }
+    put64(rounds);
+    memcpy(buf + o, p->roots.data(), rounds * 32); o += rounds * 32;
+    put64(p->out_deg);
+    memcpy(buf + o, p->final_coeffs.data(), p->out_deg * 32); o += p->out_deg * 32;
+    put64(p->initial_degree_plus_one);
+    put64(p->out_deg);
+    put64(p->lde_factor);
+    return o;
 }
 
 extern "C" size_t hodor_fri_num_steps(const hodor_fri_proto *p) { return p ? p->num_steps : 0; }

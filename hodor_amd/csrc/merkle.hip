@@ -176,10 +176,45 @@ __global__ void k_challenge(const uint4 *nodes, uint4 *out, Fr r2, uint32_t shav
     fr_store(out, m);
 }
 
+// Query phase on device-resident oracles: IOP::query + IopTree::get_path
+// (src/iop/blake2s_trivial_iop.rs:251-279, 324-338).  out[0] = the queried leaf value,
+// out[1] = hash of its sibling leaf, out[1 + k] = sibling node at tree level log2(n) - 1 - k.
+// `leaf_pair` points at the even leaf of the pair {index & ~1, index | 1}.
+__global__ void k_iop_query(const uint4 *leaf_pair, const uint4 *nodes, uint64_t n, uint64_t index,
+                            uint4 *out, B2Mid mid)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t levels = 0;
+    for (uint64_t w = n >> 1; w >= 2; w >>= 1) levels++;   // log2(n) - 1 node levels on the path
+    if (lane == 0) {
+        const uint4 *me = leaf_pair + 2 * (index & 1), *sib = leaf_pair + 2 * ((index & 1) ^ 1);
+        out[0] = me[0];
+        out[1] = me[1];
+        uint32_t h[8];
+        b2s_leaf(mid, sib[0], sib[1], h);
+        out[2] = make_uint4(h[0], h[1], h[2], h[3]);
+        out[3] = make_uint4(h[4], h[5], h[6], h[7]);
+    } else if (lane <= levels) {
+        uint32_t k = lane - 1;                       // k-th node level from the bottom
+        uint64_t width = n >> (k + 1);               // level stored at nodes[width .. 2*width)
+        uint64_t idx = (index >> (k + 1)) ^ 1;
+        const uint4 *src = nodes + 2 * (width + idx);
+        out[2 * (lane + 1)] = src[0];
+        out[2 * (lane + 1) + 1] = src[1];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 constexpr uint64_t TREE_TOP_WIDTH = 512;   // k_tree_top computes levels of width <= this
+
+hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
+                            uint64_t index, uint4 *out, const B2Mid &mid)
+{
+    hipLaunchKernelGGL(k_iop_query, dim3(1), dim3(64), 0, s, leaf_pair, nodes, n, index, out, mid);
+    return hipGetLastError();
+}
 
 hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,
                                const B2Mid &mid)

@@ -159,6 +159,16 @@ int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_
 int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
 /* Merkle tree over n device-resident leaves into n*32 device bytes */
 int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, uint8_t *nodes);
+/* IOP::query (src/iop/blake2s_trivial_iop.rs:324-338) on device-resident leaves and tree: the leaf
+ * value and its authentication path (log2 n digests) are copied to the host buffers. */
+int hodor_iop_query_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, const uint8_t *nodes, size_t n,
+                        size_t natural_index, hodor_fr *value, uint8_t *path, size_t *path_len);
+/* FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53) against the device-resident
+ * prototype: the serialised FRIProof (src/fri/mod.rs:139-147; layout documented in csrc/abi.hip).
+ * `lde_values_dev` is the codeword the prototype was committed from (device pointer).  Returns the
+ * byte count; writes only when buf != NULL and cap is large enough; 0 on error. */
+size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
+                               size_t natural_first_element_index, uint8_t *buf, size_t cap);
 /* FRI commit over a device-resident codeword; the prototype keeps its vectors/trees on the device */
 int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
                          size_t lde_factor, size_t output_coeffs_at_degree_plus_one,

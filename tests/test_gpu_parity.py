@@ -324,3 +324,92 @@ def test_sixstep_single_rank_on_device(gpu_ctxs, oracles, log_n):
     back = sixstep_intt(be, out, log_n, w, 0, 1)
     ctx.synchronize()
     assert torch.equal(back, d)
+
+
+# ---------------------------------------------------------------- extreme inputs (lazy-reduction bounds)
+@pytest.mark.parametrize("log_n", [4, 9, 10, 13, 16])
+def test_transforms_on_extreme_inputs(gpu_ctxs, oracles, field_name, log_n):
+    """The kernels keep values lazily reduced (9 x 29-bit limbs, up to ~45 p inside a pass); inputs at
+    the edges of the representation — every memory image equal to p-1, zeros, a single spike,
+    alternating 0 / p-1 — maximise that growth and must still come out canonical and bit-exact."""
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n = 1 << log_n
+    pm1 = O.modulus - 1
+    patterns = {
+        "all_pm1": [pm1] * n,
+        "zeros": [0] * n,
+        "spike": [pm1] + [0] * (n - 1),
+        "alternating": [pm1 if i & 1 else 0 for i in range(n)],
+        "ramp_top": [pm1 - i for i in range(n)],
+    }
+    for name, vals in patterns.items():
+        a = ints_to_array(vals)
+        for op in ("poly_fft", "poly_ifft", "poly_coset_fft", "poly_icoset_fft"):
+            exp, got = a.copy(), a.copy()
+            getattr(O, op)(exp)
+            getattr(ctx, op)(got)
+            assert np.array_equal(got, exp), (name, op)
+        if log_n <= 13:
+            assert np.array_equal(ctx.poly_lde(a, 8), O.poly_lde(a, 8)), name
+            assert np.array_equal(ctx.poly_lde(a, 2, coset=True), O.poly_lde(a, 2, coset=True)), name
+
+
+# ---------------------------------------------------------------- query phase (src/fri/query_producer.rs)
+def test_iop_query_dev_matches_oracle(gpu_ctxs, oracles):
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    for log_n in (1, 2, 5, 12):
+        n = 1 << log_n
+        leafs = O.random_elements(n, 60 + log_n)
+        nodes = O.iop_create(leafs)
+        d_l = torch.from_numpy(leafs.view(np.int64)).cuda()
+        d_n = torch.from_numpy(nodes).cuda()
+        ints = array_to_ints(leafs)
+        for idx in sorted({0, 1, n - 1, n // 2, (n * 3) // 7}):
+            value, path = ctx.iop_query_dev(d_l, d_n, n, idx)
+            assert value == ints[idx]
+            assert np.array_equal(path, O.iop_path(nodes, leafs, idx))
+            assert O.iop_verify(bytes(nodes[1]), value, path, idx)
+
+
+@pytest.mark.parametrize("log_deg,lde_factor,out_deg,index", [(3, 4, 1, 5), (8, 8, 2, 777), (12, 8, 1, 31000)])
+def test_fri_produce_proof(gpu_ctxs, oracles, log_deg, lde_factor, out_deg, index):
+    """produce_proof on the device-resident prototype: per round the two coset queries, each verifying
+    against that round's root (verify_proof_queries, src/fri/verifier.rs:131-289, first half), values
+    consistent with the folding relation, indices halving as index_and_size_for_next_domain says."""
+    import torch
+    ctx, O, F = gpu_ctxs["bn256"], oracles["bn256"], P.BN256
+    coeffs = O.random_elements(1 << log_deg, 9 + log_deg)
+    lde = O.poly_lde(coeffs, lde_factor)
+    n = len(lde)
+    d_lde = torch.from_numpy(lde.view(np.int64)).cuda()
+    proto = ctx.fri_commit_dev(d_lde, n, lde_factor, out_deg)
+    ref = O.fri_commit(lde, lde_factor, out_deg)
+    proof = proto.produce_proof(d_lde, index)
+    assert proof["roots"] == ref["roots"]
+    assert proof["final_coeffs"] == array_to_ints(ref["final_coeffs"])
+    assert (proof["initial_degree_plus_one"], proof["output_coeffs_at_degree_plus_one"], proof["lde_factor"]) == \
+        (n // lde_factor, out_deg, lde_factor)
+    assert len(proof["queries"]) == 2 * (ref["num_steps"] + 1)
+    vectors = [lde] + ref["inter_values"]
+    size, idx = n, index
+    omega_inv = F.from_mont(O.inverse(O.domain(n)[2]))
+    for r, vec in enumerate(vectors):
+        coset = sorted([idx, (idx + size // 2) % size])
+        trees = O.iop_create(vec)
+        ints = array_to_ints(vec)
+        for k in range(2):
+            qi, qv, qp = proof["queries"][2 * r + k]
+            assert qi == coset[k] and qv == ints[qi]
+            assert [bytes(x) for x in O.iop_path(trees, vec, qi)] == qp
+            assert O.iop_verify(proof["roots"][r], qv, np.frombuffer(b"".join(qp), dtype=np.uint8).reshape(-1, 32), qi)
+        if r + 1 < len(vectors):   # folding relation between consecutive rounds (fri_on_values.rs:77-100)
+            lo, hi = coset
+            a, b = F.from_mont(ints[lo]), F.from_mont(ints[hi])
+            beta = F.from_mont(ref["challenges"][r])
+            w = pow(omega_inv, lo << r, F.p)
+            nxt = ((a + b) + beta * (a - b) * w) * pow(2, -1, F.p) % F.p
+            assert F.from_mont(array_to_ints(vectors[r + 1][lo:lo + 1])[0]) == nxt
+        idx = idx if idx < size // 2 else idx - size // 2
+        size //= 2
+    proto.free()
