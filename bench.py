@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--mode", choices=["replicas", "sixstep"], default="replicas",
+                    help="N > 1: 'replicas' = one independent 2^log_n polynomial per GPU (default); "
+                         "'sixstep' = ONE transform of 2^log_n * N points split over the ranks, transposes as "
+                         "RCCL all-to-alls (hodor_amd/sixstep.py, BASELINE config[4] shape)")
     args = ap.parse_args()
 
     import torch
@@ -73,7 +77,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=local_rank)
@@ -91,13 +95,27 @@ def main():
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
 
-    def step():
-        ctx.poly_fft_dev(a, b, log_n, stream=stream)
-        ctx.poly_ifft_dev(b, c, log_n, stream=stream)
+    if args.mode == "sixstep":
+        from hodor_amd.sixstep import HipBackend, sixstep_intt, sixstep_ntt
+        log_total = log_n + (world.bit_length() - 1)
+        assert 1 << (world.bit_length() - 1) == world, "sixstep needs a power-of-two world size"
+        omega = ctx.domain(1 << log_total)[2]
+        be = HipBackend(ctx, stream=stream)
+        holder = {}
+
+        def step():
+            y = sixstep_ntt(be, a, log_total, omega, rank, world)
+            holder["c"] = sixstep_intt(be, y, log_total, omega, rank, world)
+    else:
+        def step():
+            ctx.poly_fft_dev(a, b, log_n, stream=stream)
+            ctx.poly_ifft_dev(b, c, log_n, stream=stream)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.mode == "sixstep":
+        c = holder["c"]
     if not torch.equal(a, c) and not os.environ.get("HODOR_DBG"):   # HODOR_DBG: profiling ablations only
         raise SystemExit("iNTT(NTT(x)) != x — refusing to report a number")
 
@@ -139,7 +157,9 @@ def main():
         "config": {"workload": "2^%d-point NTT + iNTT over the src/bn256.rs Fr field, device-resident, "
                                "bit-exact vs CPU oracle (BASELINE config[1])" % log_n,
                    "log_n": log_n, "field": "bn256.rs Fr (255-bit, R=2^256)",
-                   "parallelism": "1 polynomial per GPU" if world > 1 else "1 GPU"},
+                   "parallelism": ("6-step, 2^%d points over %d GPUs, RCCL all-to-all transposes"
+                                   % (log_n + world.bit_length() - 1, world)) if args.mode == "sixstep"
+                   else ("1 polynomial per GPU" if world > 1 else "1 GPU")},
     }
 
     if rank == 0:
@@ -161,7 +181,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
