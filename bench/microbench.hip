@@ -171,6 +171,114 @@ __global__ void k_fma32(uint64_t *out, uint32_t a, uint32_t b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint64_t)s;
 }
 
+__global__ void k_alignbit(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_alignbit_b32 %0, %1, %1, 12" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_xor(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_add3(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_add3_u32 %0, %1, %2, %1" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_perm(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_perm_b32 %0, %1, %1, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_lshrrev64x(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_alignbit2(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_alignbit_b32 %0, %1, %2, 7" : "=v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 #define MUL_ITERS 256
 __global__ void k_frmul(uint64_t *out, FrParams P, uint32_t seed)
 {
@@ -301,6 +409,12 @@ int main()
     RUN("v_lshl_add_u64", k_lshladd64)
     RUN("v_fma_f64", k_fma64)
     RUN("v_fma_f32", k_fma32)
+    RUN("v_alignbit_b32", k_alignbit)
+    RUN("v_xor_b32", k_xor)
+    RUN("v_add3_u32", k_add3)
+    RUN("v_perm_b32", k_perm)
+    RUN("v_and_b32", k_lshrrev64x)
+    RUN("v_alignbit_b32", k_alignbit2)
     FrParams P;
     // BLS12-381 Fr (the field in src/bn256.rs)
     const uint32_t p[8] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753};

@@ -29,9 +29,10 @@ hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *no
                             uint64_t index, uint4 *out, const B2Mid &);
 hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &);
-hipError_t fri_fold_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half,
-                           const TwoLevel &winv, uint32_t log_stride, const uint4 *challenge,
-                           const FrParams &);
+hipError_t fri_round_table_launch(hipStream_t, const uint4 *hi, uint4 *hi_out, uint64_t count,
+                                  const uint4 *challenge, const Fr9 &c16, const Fr9Params &);
+hipError_t fri_fold_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo,
+                           const uint4 *hi_beta, uint32_t lo_bits, uint32_t log_stride, const Fr9Params &);
 
 static Fr to_dev(const HFr &a)
 {
@@ -775,6 +776,9 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     // slab layout: l0 tree | per step: values, tree | small block (challenges, roots, final coeffs)
     size_t fin_n = n >> num_steps;
     size_t small_bytes = 32 * (num_steps + 1) * 2 + 32 * fin_n * 2;
+    const uint32_t winv_lo_bits = (log_n + 1) / 2;
+    const size_t hi_cnt = (size_t)1 << (log_n - winv_lo_bits);
+    small_bytes += 48 * hi_cnt;   // per-round copy of the w^-1 `hi` table scaled by beta/2
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t need = up(n * 32) + up(small_bytes);
     for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
@@ -803,9 +807,11 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     uint4 *d_chal = (uint4 *)d_small;
     uint4 *d_roots = (uint4 *)(d_small + 32 * (num_steps + 1));
     uint4 *d_fin = (uint4 *)(d_small + 64 * (num_steps + 1));
+    uint4 *d_hi_beta = (uint4 *)(d_small + 64 * (num_steps + 1) + 64 * fin_n);
+    const Fr9 c16 = to_dev9(ctx->F, ctx->F.from_u64(16));
 
     TwoLevel winv;
-    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv, 0))) { fri_release(p); return rc; }
+    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv, 1, winv_lo_bits))) { fri_release(p); return rc; }
     uint32_t shave = 256 - ctx->F.capacity;
     Fr r2 = to_dev(ctx->F.r2);
 
@@ -817,8 +823,9 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     size_t next_size = n / 2;
     for (size_t i = 0; i < num_steps; i++) {                                                             // :61
         void *next = p->inter_values[i], *nodes = p->inter_nodes[i];
-        FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv, (uint32_t)i, d_chal + 2 * i,
-                               ctx->P));                                                                 // :70-104
+        FRICHK(fri_round_table_launch(stream, winv.hi, d_hi_beta, hi_cnt, d_chal + 2 * i, c16, ctx->Q));
+        FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits,
+                               (uint32_t)i, ctx->Q));                                                    // :70-104
         FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid));   // :106
         FRICHK(challenge_launch(stream, (const uint4 *)nodes, d_chal + 2 * (i + 1), r2, shave, ctx->P));
         FRICHK(hipMemcpyAsync((uint8_t *)d_roots + 32 * (i + 1), (const uint8_t *)nodes + 32, 32,

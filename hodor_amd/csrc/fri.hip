@@ -4,45 +4,79 @@
 // (/root/reference/src/fri/fri_on_values.rs:70-104):
 //     next[i] = ((f[i] + f[i+half]) + beta * (f[i] - f[i+half]) * w^-(i*stride)) * 2^-1
 // The reference tabulates all n/2 powers of w^-1 (:24-40, n/2 x 32 B streamed from memory every
-// round); here they come from the two-level table of the initial domain's w^-1 (L2-resident) and
-// the final halving is an exact shift (add p if odd, >> 1) instead of a multiplication by 2^-1.
-// beta is read from device memory, so the round chain never synchronises with the host.
+// round) and spends three multiplications per output.  Here:
+//   * w^-e comes from the two-level table of the initial domain's w^-1 (L2-resident);
+//   * beta/2 is folded into the table's `hi` half once per round (k_fri_round_table, a few thousand
+//     products), so an output costs one product to combine lo*hi' (none when the low exponent bits
+//     are zero, i.e. in every round >= lo_bits) and one to apply it;
+//   * (f[i] + f[i+half]) / 2 is an exact halving, not a multiplication;
+//   * arithmetic is the carry-free 9 x 29-bit form (fr9.cuh); beta is read from device memory, so
+//     the 23-round chain at 2^26 never synchronises with the host.
 #include "ntt.cuh"
 
 namespace hodor {
 
-__device__ __forceinline__ Fr tl_pow(const TwoLevel &t, uint64_t e, const FrParams &P)
+// hi'[j] = hi[j] * beta / 2   (all R'-form, normalized).  `c16` = 16 in R'-form: the product of the
+// R-form challenge with an R'-form entry is R-form, i.e. short by 2^5; 2^5 / 2 = 16.
+__global__ void __launch_bounds__(256)
+k_fri_round_table(const uint4 *hi, uint4 *hi_out, uint64_t count, const uint4 *challenge, Fr9 c16,
+                  Fr9Params Q)
 {
-    uint64_t lo_i = e & ((1ull << t.lo_bits) - 1), hi_i = e >> t.lo_bits;
-    Fr h = fr_load(t.hi + 2 * hi_i);
-    if (lo_i == 0) return h;
-    return fr_mul(h, fr_load(t.lo + 2 * lo_i), P);
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fr9 beta = fr9_unpack(fr_load(challenge));
+    Fr9 b16 = fr9_mul(beta, c16, Q);                       // beta * 16, R-form, normalized, < 2p
+    Fr9 h = fr9_mul(b16, fr9_load48(hi + 3 * j), Q);       // beta * 16 * h_j * 2^256 = (beta h_j / 2) 2^261
+    fr9_store48(hi_out + 3 * j, h);
+}
+
+// exact halving of a lazy value: add p when odd, shift right one bit across the 29-bit limbs
+__device__ __forceinline__ Fr9 fr9_halve(Fr9 a, const Fr9Params &Q)
+{
+    fr9_normalize(a);
+    uint32_t odd = a.v[0] & 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.v[i] += odd ? Q.p[i] : 0u;
+    fr9_normalize(a);
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (a.v[i] >> 1) | ((a.v[i + 1] & 1) << 28);
+    r.v[8] = a.v[8] >> 1;
+    return r;
 }
 
 __global__ void __launch_bounds__(256)
-k_fri_fold(const uint4 *src, uint4 *dst, uint64_t half, TwoLevel winv, uint32_t log_stride,
-           const uint4 *challenge, FrParams P)
+k_fri_fold(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo, const uint4 *hi_beta,
+           uint32_t lo_bits, uint32_t log_stride, Fr9Params Q)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    Fr beta = fr_load(challenge);
+    const uint64_t lo_mask = (1ull << lo_bits) - 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
-        Fr a = fr_load(src + 2 * i), b = fr_load(src + 2 * (i + half));
-        Fr even = fr_add(a, b, P);
-        Fr odd = fr_sub(a, b, P);
-        if (i != 0) odd = fr_mul(odd, tl_pow(winv, i << log_stride, P), P);
-        Fr t = fr_add(fr_mul(odd, beta, P), even, P);
-        fr_store(dst + 2 * i, fr_halve(t, P));
+        Fr9 a = fr9_unpack(fr_load(src + 2 * i)), b = fr9_unpack(fr_load(src + 2 * (i + half)));
+        uint64_t e = i << log_stride;
+        Fr9 tw = fr9_load48(hi_beta + 3 * (e >> lo_bits));
+        if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(lo + 3 * (e & lo_mask)), Q);
+        Fr9 odd = fr9_mul(fr9_sub(a, b, Q), tw, Q);          // (a - b) * beta * w^-e / 2
+        Fr9 even = fr9_halve(fr9_add(a, b), Q);              // (a + b) / 2
+        fr_store(dst + 2 * i, fr9_to_canonical(fr9_add(even, odd), Q));
     }
 }
 
-hipError_t fri_fold_launch(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t half,
-                           const TwoLevel &winv, uint32_t log_stride, const uint4 *challenge,
-                           const FrParams &P)
+hipError_t fri_round_table_launch(hipStream_t s, const uint4 *hi, uint4 *hi_out, uint64_t count,
+                                  const uint4 *challenge, const Fr9 &c16, const Fr9Params &Q)
+{
+    hipLaunchKernelGGL(k_fri_round_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, hi, hi_out,
+                       count, challenge, c16, Q);
+    return hipGetLastError();
+}
+
+hipError_t fri_fold_launch(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo,
+                           const uint4 *hi_beta, uint32_t lo_bits, uint32_t log_stride, const Fr9Params &Q)
 {
     uint64_t blocks = (half + 255) / 256;
     unsigned grid = (unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
-    hipLaunchKernelGGL(k_fri_fold, dim3(grid), dim3(256), 0, s, src, dst, half, winv, log_stride,
-                       challenge, P);
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid), dim3(256), 0, s, src, dst, half, lo, hi_beta, lo_bits,
+                       log_stride, Q);
     return hipGetLastError();
 }
 

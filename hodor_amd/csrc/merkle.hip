@@ -88,74 +88,67 @@ __device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_leaf_level: thread g hashes leaves 2g, 2g+1 and their parent -> nodes[n/2 + g].
-// Lane g reads 64 contiguous bytes; a wave reads 4 KiB contiguous.
+// k_merkle_subtree: one workgroup builds the complete subtree over a chunk of CH = 2^log_ch inputs
+// (leaves when LEAF, digests of tree level `m` otherwise): every level of the chunk is written to its
+// place in the heap array and handed to the next level through LDS, so each leaf / digest is read
+// from HBM once and a 2^25-leaf tree takes 3 launches instead of 17.
+//
+//   level k of the chunk (k = 1 .. log_ch) has CH >> k nodes at nodes[(m >> k) + chunk*(CH >> k) ..)
+//
+// Phase 0 pairs two adjacent inputs per lane (64 contiguous bytes; a wave reads 4 KiB contiguous);
+// later levels re-map the surviving nodes densely onto the lanes, so the waves stay full until the
+// level is narrower than the workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_leaf_level(const uint4 *leafs, uint4 *nodes, uint64_t n, B2Mid mid)
-{
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t half = n >> 1;
-    if (g >= half) return;
-    const uint4 *p = leafs + 4 * g;
-    uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-    uint32_t hl[8], hr[8], out[8];
-    b2s_leaf(mid, a0, a1, hl);
-    b2s_leaf(mid, b0, b1, hr);
-    b2s_node(mid, hl, hr, out);
-    uint4 *o = nodes + 2 * (half + g);
-    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
-    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
-}
+constexpr uint32_t MERKLE_LOG_CH = 11;   // 2048 inputs per workgroup: 32 KiB + 16 KiB of LDS
 
-// k_node_level: nodes[width + g] = H(nodes[2*(width+g)] || nodes[2*(width+g)+1]),  g < width
+template <bool LEAF>
 __global__ void __launch_bounds__(256)
-k_node_level(uint4 *nodes, uint64_t width, B2Mid mid)
+k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, B2Mid mid)
 {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= width) return;
-    const uint4 *p = nodes + 4 * (width + g);
-    uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-    uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    uint32_t out[8];
-    b2s_node(mid, l, r, out);
-    uint4 *o = nodes + 2 * (width + g);
-    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
-    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
-}
-
-// k_tree_top: one workgroup finishes the tree from level `width` (<= 1024 nodes already written)
-// down to the root, level by level through global memory within the same workgroup (the data is
-// tiny; the point is to avoid ~10 dependent kernel launches).  Also zeroes nodes[0].
-__global__ void __launch_bounds__(256)
-k_tree_top(uint4 *nodes, uint32_t width, B2Mid mid)
-{
-    __shared__ uint4 lvl[2 * 2048];   // digests of the current level (<= 2048), 32 B each
+    __shared__ uint4 buf_a[2 * (1u << (MERKLE_LOG_CH - 1))];   // up to 1024 digests
+    __shared__ uint4 buf_b[2 * (1u << (MERKLE_LOG_CH - 2))];   // up to 512 digests
     const uint32_t tid = threadIdx.x;
-    // load level `2*width` (the children of the first level we compute)
-    uint32_t cw = 2 * width;
-    for (uint32_t i = tid; i < 2 * cw; i += 256) lvl[i] = nodes[2 * cw + i];
-    if (tid == 0) { nodes[0] = make_uint4(0, 0, 0, 0); nodes[1] = make_uint4(0, 0, 0, 0); }
+    const uint32_t ch = 1u << log_ch;
+    const uint64_t chunk = blockIdx.x;
+
+    // level 1: pairs of inputs
+    const uint4 *in = LEAF ? leafs + 2 * (chunk << log_ch) : nodes + 2 * (m + (chunk << log_ch));
+    uint4 *lvl_out = nodes + 2 * ((m >> 1) + chunk * (ch >> 1));
+    for (uint32_t p = tid; p < (ch >> 1); p += 256) {
+        const uint4 *q = in + 4 * p;
+        uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
+        uint32_t l[8], r[8], out[8];
+        if (LEAF) {
+            b2s_leaf(mid, a0, a1, l);
+            b2s_leaf(mid, b0, b1, r);
+        } else {
+            l[0] = a0.x; l[1] = a0.y; l[2] = a0.z; l[3] = a0.w; l[4] = a1.x; l[5] = a1.y; l[6] = a1.z; l[7] = a1.w;
+            r[0] = b0.x; r[1] = b0.y; r[2] = b0.z; r[3] = b0.w; r[4] = b1.x; r[5] = b1.y; r[6] = b1.z; r[7] = b1.w;
+        }
+        b2s_node(mid, l, r, out);
+        uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
+        lvl_out[2 * p] = o0; lvl_out[2 * p + 1] = o1;
+        buf_a[2 * p] = o0; buf_a[2 * p + 1] = o1;
+    }
     __syncthreads();
-    for (uint32_t w = width; w >= 1; w >>= 1) {
-        uint32_t outs[4][8];
-        int cnt = 0;
-        for (uint32_t g = tid; g < w; g += 256, cnt++) {
-            uint4 a0 = lvl[4 * g], a1 = lvl[4 * g + 1], b0 = lvl[4 * g + 2], b1 = lvl[4 * g + 3];
+
+    // levels 2 .. log_ch: ping-pong between the two LDS buffers
+    uint4 *src = buf_a, *dst = buf_b;
+    for (uint32_t k = 2; k <= log_ch; k++) {
+        const uint32_t w = ch >> k;
+        lvl_out = nodes + 2 * ((m >> k) + chunk * w);
+        for (uint32_t g = tid; g < w; g += 256) {
+            uint4 a0 = src[4 * g], a1 = src[4 * g + 1], b0 = src[4 * g + 2], b1 = src[4 * g + 3];
             uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            b2s_node(mid, l, r, outs[cnt]);
+            uint32_t out[8];
+            b2s_node(mid, l, r, out);
+            uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
+            lvl_out[2 * g] = o0; lvl_out[2 * g + 1] = o1;
+            dst[2 * g] = o0; dst[2 * g + 1] = o1;
         }
         __syncthreads();
-        cnt = 0;
-        for (uint32_t g = tid; g < w; g += 256, cnt++) {
-            uint4 o0 = make_uint4(outs[cnt][0], outs[cnt][1], outs[cnt][2], outs[cnt][3]);
-            uint4 o1 = make_uint4(outs[cnt][4], outs[cnt][5], outs[cnt][6], outs[cnt][7]);
-            lvl[2 * g] = o0; lvl[2 * g + 1] = o1;
-            nodes[2 * (w + g)] = o0; nodes[2 * (w + g) + 1] = o1;
-        }
-        __syncthreads();
+        uint4 *t = src; src = dst; dst = t;
     }
 }
 
@@ -207,8 +200,6 @@ __global__ void k_iop_query(const uint4 *leaf_pair, const uint4 *nodes, uint64_t
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-constexpr uint64_t TREE_TOP_WIDTH = 512;   // k_tree_top computes levels of width <= this
-
 hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &mid)
 {
@@ -220,19 +211,22 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
                                const B2Mid &mid)
 {
     // n >= 2, power of two (checked by the caller)
-    uint64_t half = n >> 1;
-    hipLaunchKernelGGL(k_leaf_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, leafs,
-                       nodes, n, mid);
-    uint64_t w = half >> 1;
-    for (; w > TREE_TOP_WIDTH; w >>= 1)
-        hipLaunchKernelGGL(k_node_level, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, s, nodes, w,
-                           mid);
-    if (w >= 1) {
-        hipLaunchKernelGGL(k_tree_top, dim3(1), dim3(256), 0, s, nodes, (uint32_t)w, mid);
-    } else {
-        // n == 2: the leaf level already wrote the root at nodes[1]; zero nodes[0]
-        hipError_t e = hipMemsetAsync(nodes, 0, 32, s);
-        if (e != hipSuccess) return e;
+    hipError_t e = hipMemsetAsync(nodes, 0, 32, s);   // nodes[0] is unused by the layout
+    if (e != hipSuccess) return e;
+    uint64_t m = n;
+    bool first = true;
+    while (m > 1) {
+        uint32_t log_ch = 0;
+        while ((1ull << (log_ch + 1)) <= m && log_ch + 1 <= MERKLE_LOG_CH) log_ch++;
+        uint64_t chunks = m >> log_ch;
+        if (first)
+            hipLaunchKernelGGL(k_merkle_subtree<true>, dim3((unsigned)chunks), dim3(256), 0, s, leafs, nodes, m,
+                               log_ch, mid);
+        else
+            hipLaunchKernelGGL(k_merkle_subtree<false>, dim3((unsigned)chunks), dim3(256), 0, s, leafs, nodes, m,
+                               log_ch, mid);
+        m >>= log_ch;
+        first = false;
     }
     return hipGetLastError();
 }
