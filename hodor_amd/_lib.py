@@ -38,6 +38,8 @@ EXPORTS = [
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_distribute_powers_dev",
+    "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
+    "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev",
 ]
 
@@ -394,6 +396,30 @@ class Context:
     def distribute_powers_dev(self, a, n, g, stream=None):
         gg = _fr(g)
         self._chk(self.L.hodor_distribute_powers_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.byref(gg)))
+
+    def poly_binary_dev(self, a, b, n, op, stream=None):
+        self._chk(self.L.hodor_poly_binary_dev(self.h, C.c_void_p(stream), _dptr(a), _dptr(b), C.c_size_t(n),
+                                               C.c_int({"add": 0, "sub": 1, "mul": 2}[op])))
+
+    def poly_add_scaled_dev(self, a, b, n, scaling, stream=None):
+        sc = _fr(scaling)
+        self._chk(self.L.hodor_poly_add_scaled_dev(self.h, C.c_void_p(stream), _dptr(a), _dptr(b), C.c_size_t(n),
+                                                   C.byref(sc)))
+
+    def poly_unary_dev(self, a, n, op, c=None, e=0, stream=None):
+        code = {"negate": 0, "square": 1, "pow": 2, "scale": 3, "add_constant": 4, "sub_constant": 5}[op]
+        cc = _fr(c) if c is not None else None
+        self._chk(self.L.hodor_poly_unary_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.c_int(code),
+                                              C.byref(cc) if cc is not None else None, C.c_uint64(e)))
+
+    def poly_batch_inversion_dev(self, a, n, stream=None):
+        self._chk(self.L.hodor_poly_batch_inversion_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n)))
+
+    def poly_evaluate_at_dev(self, coeffs, n, g, stream=None):
+        out, gg = _Fr(), _fr(g)
+        self._chk(self.L.hodor_poly_evaluate_at_dev(self.h, C.c_void_p(stream), _dptr(coeffs), C.c_size_t(n),
+                                                    C.byref(gg), C.byref(out)))
+        return _to_int(out.l)
 
     def iop_create_dev(self, leafs, n, nodes, stream=None):
         self._chk(self.L.hodor_iop_create_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n), _dptr(nodes)))

@@ -22,6 +22,13 @@ hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &m
                             uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
 hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
 hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
+hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
+hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
+hipError_t unary_launch(hipStream_t, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &);
+hipError_t batchinv_products_launch(hipStream_t, const uint4 *a, uint64_t n, uint32_t *zero_flag, const FrParams &);
+hipError_t batchinv_apply_launch(hipStream_t, uint4 *a, uint4 *prefix, uint64_t n, const FrParams &);
+hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
+                              uint32_t *ticket, uint4 *out, const FrParams &);
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
                               const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
 hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &);
@@ -696,6 +703,79 @@ extern "C" int hodor_twiddle_mul_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, 
     if (scale) sc = to_dev(to_h(scale));
     HIPCHK(twiddle_mul_launch(pick_stream(ctx, stream), (uint4 *)a, rows, cols, row0, t, log_order,
                               scale ? &sc : nullptr, ctx->P));
+    return HODOR_OK;
+}
+
+// ---- value-form polynomial arithmetic on device ----
+extern "C" int hodor_poly_binary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, const hodor_fr *b, size_t n, int op)
+{
+    NEED_DEVICE();
+    if (!a || !b) return HODOR_ERR_INVALID;
+    if (op < 0 || op > 2) return HODOR_ERR_INVALID;
+    HIPCHK(binary_launch(pick_stream(ctx, stream), (uint4 *)a, (const uint4 *)b, n, op, ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_poly_add_scaled_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, const hodor_fr *b, size_t n,
+                                         const hodor_fr *scaling)
+{
+    NEED_DEVICE();
+    if (!a || !b || !scaling) return HODOR_ERR_INVALID;
+    HIPCHK(add_scaled_launch(pick_stream(ctx, stream), (uint4 *)a, (const uint4 *)b, n, to_dev(to_h(scaling)), ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_poly_unary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, int op, const hodor_fr *c,
+                                    uint64_t e)
+{
+    NEED_DEVICE();
+    if (!a || op < 0 || op > 5 || (op >= 3 && !c)) return HODOR_ERR_INVALID;
+    Fr cd = {};
+    if (c) cd = to_dev(to_h(c));
+    if (op == 2 && e == 2) op = 1;   // pow(2) is square (src/polynomials/mod.rs:746-748)
+    HIPCHK(unary_launch(pick_stream(ctx, stream), (uint4 *)a, n, op, cd, e, ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hodor_fr *a, size_t n)
+{
+    NEED_DEVICE();
+    if (!a) return HODOR_ERR_INVALID;
+    if (n == 0) return HODOR_OK;
+    hipStream_t stream = pick_stream(ctx, stream_);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_scratch(ctx, 0, n * 32 + 256);
+    if (rc) return rc;
+    uint32_t *flag = (uint32_t *)((uint8_t *)ctx->scratch[0] + n * 32);
+    HIPCHK(hipMemsetAsync(flag, 0, 4, stream));
+    HIPCHK(batchinv_products_launch(stream, (const uint4 *)a, n, flag, ctx->P));
+    uint32_t host_flag = 0;
+    HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (host_flag) {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
+        ctx->err = "batch_inversion: zero element";
+        return HODOR_ERR_INVALID;
+    }
+    HIPCHK(batchinv_apply_launch(stream, (uint4 *)a, (uint4 *)ctx->scratch[0], n, ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *coeffs, size_t n,
+                                          const hodor_fr *g, hodor_fr *out)
+{
+    NEED_DEVICE();
+    if (!coeffs || !g || !out) return HODOR_ERR_INVALID;
+    hipStream_t stream = pick_stream(ctx, stream_);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_scratch(ctx, 0, 32 * 258 + 64);
+    if (rc) return rc;
+    uint4 *partials = (uint4 *)ctx->scratch[0];
+    uint4 *res = partials + 2 * 256;
+    uint32_t *ticket = (uint32_t *)(res + 2);
+    HIPCHK(hipMemsetAsync(ticket, 0, 4, stream));
+    HIPCHK(evaluate_at_launch(stream, (const uint4 *)coeffs, n, to_dev(to_h(g)), partials, ticket, res, ctx->P));
+    HIPCHK(hipMemcpyAsync(out, res, 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
     return HODOR_OK;
 }
 

@@ -3,6 +3,8 @@
 //   k_distribute_powers   a[i] *= g^i          /root/reference/src/fft/mod.rs:110-123
 //   k_scale               a[i] *= s            /root/reference/src/polynomials/mod.rs:60-72
 //   k_binary              a[i] (+,-,*)= b[i]   /root/reference/src/polynomials/mod.rs:817-887
+//   k_add_scaled / k_unary / k_batchinv_* / k_evaluate_at : the rest of the value-form API that sits
+//                         either side of every LDE in ALI (src/polynomials/mod.rs:657-711, 744-954)
 //
 // HBM-streaming kernels: grid-stride over 32-byte elements, one element per lane per iteration so a
 // wave touches 2 KiB of contiguous memory; powers are a per-thread running product (one
@@ -72,6 +74,145 @@ k_twiddle_mul(uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0, TwoLevel t,
     }
 }
 
+// a[i] += s * b[i]   (Polynomial<Coefficients>::add_assign_scaled, src/polynomials/mod.rs:657-671)
+__global__ void __launch_bounds__(256)
+k_add_scaled(uint4 *a, const uint4 *b, uint64_t n, Fr s, FrParams P)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        fr_store(a + 2 * i, fr_add(fr_load(a + 2 * i), fr_mul(fr_load(b + 2 * i), s, P), P));
+}
+
+// unary ops of Polynomial<F, Values> (src/polynomials/mod.rs:60-83, 744-771, 817-841):
+// 0 negate, 1 square, 2 pow(e), 3 scale(c), 4 add_constant(c), 5 sub_constant(c)
+__global__ void __launch_bounds__(256)
+k_unary(uint4 *a, uint64_t n, int op, Fr c, uint64_t e, FrParams P)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fr x = fr_load(a + 2 * i), r;
+        switch (op) {
+        case 0: r = fr_is_zero(x) ? x : fr_neg(x, P); break;
+        case 1: r = fr_sqr(x, P); break;
+        case 2: r = fr_pow(x, e, P); break;
+        case 3: r = fr_mul(x, c, P); break;
+        case 4: r = fr_add(x, c, P); break;
+        default: r = fr_sub(x, c, P); break;
+        }
+        fr_store(a + 2 * i, r);
+    }
+}
+
+// base^(p-2) by square-and-multiply over the 256-bit exponent held in SGPRs
+__device__ inline Fr fr_inverse_fermat(const Fr &a, const FrParams &P)
+{
+    // exponent = p - 2, with the borrow propagated (p[0] is 1 for both reference fields)
+    uint32_t e[8];
+    uint64_t borrow = 2;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t d = (uint64_t)P.p[k] - borrow;
+        e[k] = (uint32_t)d;
+        borrow = (d >> 63) & 1;
+    }
+    Fr r = fr_one(P);
+    for (int i = 255; i >= 0; i--) {
+        r = fr_sqr(r, P);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = fr_mul(r, a, P);
+    }
+    return r;
+}
+
+// Polynomial<F, Values>::batch_inversion (src/polynomials/mod.rs:889-954).  Each thread owns the
+// strided subsequence a[t], a[t+T], ... (coalesced across lanes) the way a CPU worker owns a chunk:
+// pass 1 (k_batchinv_products): products only, and a flag if any element is zero — the reference
+// errors out before touching the data (:909).  Pass 2 (k_batchinv_apply): prefix products to
+// scratch, ONE Fermat inversion per thread, backward substitution (3 products per element).
+__global__ void __launch_bounds__(256)
+k_batchinv_products(const uint4 *a, uint64_t n, uint32_t *zero_flag, FrParams P)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool zero = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        zero |= fr_is_zero(fr_load(a + 2 * i));
+    if (zero) atomicOr(zero_flag, 1u);
+}
+
+__global__ void __launch_bounds__(256)
+k_batchinv_apply(uint4 *a, uint4 *prefix, uint64_t n, FrParams P)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fr run = fr_one(P);
+    uint64_t last = t;
+    for (uint64_t i = t; i < n; i += stride) {     // prefix[i] = product of this thread's elements before i
+        fr_store(prefix + 2 * i, run);
+        run = fr_mul(run, fr_load(a + 2 * i), P);
+        last = i;
+    }
+    Fr inv = fr_inverse_fermat(run, P);             // (product of the whole subsequence)^-1
+    for (uint64_t i = last;; i -= stride) {
+        Fr x = fr_load(a + 2 * i);
+        fr_store(a + 2 * i, fr_mul(inv, fr_load(prefix + 2 * i), P));
+        inv = fr_mul(inv, x, P);
+        if (i < stride + t || i == t) break;
+    }
+}
+
+// Polynomial<F, Coefficients>::evaluate_at (src/polynomials/mod.rs:685-711): sum a[i] g^i.
+// Per-thread strided partial sums with a running power, then a workgroup tree in LDS; one partial
+// per workgroup goes to `partials`, the last workgroup to finish (ticket) folds them into out[0].
+__global__ void __launch_bounds__(256)
+k_evaluate_at(const uint4 *a, uint64_t n, Fr g, uint4 *partials, uint32_t *ticket, uint4 *out, FrParams P)
+{
+    __shared__ uint4 red[2 * 256];
+    __shared__ bool is_last;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr acc = fr_zero();
+    if (i < n) {
+        Fr u = fr_pow(g, i, P), step = fr_pow(g, stride, P);
+        for (; i < n; i += stride) {
+            acc = fr_add(acc, fr_mul(fr_load(a + 2 * i), u, P), P);
+            u = fr_mul(u, step, P);
+        }
+    }
+    fr_store(red + 2 * threadIdx.x, acc);
+    __syncthreads();
+    for (uint32_t w = 128; w >= 1; w >>= 1) {
+        if (threadIdx.x < w)
+            fr_store(red + 2 * threadIdx.x,
+                     fr_add(fr_load(red + 2 * threadIdx.x), fr_load(red + 2 * (threadIdx.x + w)), P));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        fr_store(partials + 2 * blockIdx.x, fr_load(red));
+        __threadfence();                                   // publish the partial before taking a ticket
+        is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    Fr s = fr_zero();
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
+        const volatile uint32_t *q = reinterpret_cast<const volatile uint32_t *>(partials + 2 * b);
+        Fr x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x.v[k] = q[k];         // bypass a possibly stale L1 line
+        s = fr_add(s, x, P);
+    }
+    fr_store(red + 2 * threadIdx.x, s);
+    __syncthreads();
+    for (uint32_t w = 128; w >= 1; w >>= 1) {
+        if (threadIdx.x < w)
+            fr_store(red + 2 * threadIdx.x,
+                     fr_add(fr_load(red + 2 * threadIdx.x), fr_load(red + 2 * (threadIdx.x + w)), P));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fr_store(out, fr_load(red));
+}
+
 static unsigned stream_grid(uint64_t n)
 {
     uint64_t blocks = (n + 255) / 256;
@@ -89,6 +230,53 @@ hipError_t scale_launch(hipStream_t s, uint4 *a, uint64_t n, const Fr &f, const 
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scale, dim3(stream_grid(n)), dim3(256), 0, s, a, n, f, P);
+    return hipGetLastError();
+}
+
+hipError_t add_scaled_launch(hipStream_t s, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &P)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_scaled, dim3(stream_grid(n)), dim3(256), 0, s, a, b, n, f, P);
+    return hipGetLastError();
+}
+
+hipError_t unary_launch(hipStream_t s, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &P)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unary, dim3(stream_grid(n)), dim3(256), 0, s, a, n, op, c, e, P);
+    return hipGetLastError();
+}
+
+// batch inversion: threads = min(n, 2^16) so that one Fermat inversion is amortised over >= 256
+// elements at 2^24
+unsigned batchinv_threads(uint64_t n)
+{
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    return (unsigned)(blocks ? blocks : 1);
+}
+
+hipError_t batchinv_products_launch(hipStream_t s, const uint4 *a, uint64_t n, uint32_t *zero_flag,
+                                    const FrParams &P)
+{
+    hipLaunchKernelGGL(k_batchinv_products, dim3(stream_grid(n)), dim3(256), 0, s, a, n, zero_flag, P);
+    return hipGetLastError();
+}
+
+hipError_t batchinv_apply_launch(hipStream_t s, uint4 *a, uint4 *prefix, uint64_t n, const FrParams &P)
+{
+    hipLaunchKernelGGL(k_batchinv_apply, dim3(batchinv_threads(n)), dim3(256), 0, s, a, prefix, n, P);
+    return hipGetLastError();
+}
+
+// `work` must hold 32 * 256 + 4 bytes (partials + ticket, ticket zeroed by the caller)
+hipError_t evaluate_at_launch(hipStream_t s, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
+                              uint32_t *ticket, uint4 *out, const FrParams &P)
+{
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_evaluate_at, dim3((unsigned)blocks), dim3(256), 0, s, a, n, g, partials, ticket, out, P);
     return hipGetLastError();
 }
 

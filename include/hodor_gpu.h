@@ -157,6 +157,25 @@ int hodor_poly_icoset_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src,
 int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                        uint32_t log_n, size_t factor, int coset);
 int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
+/* ---- value-form polynomial arithmetic on device-resident buffers (the pointwise steps either side of
+ * every LDE in ALI: src/polynomials/mod.rs:60-83, 640-683, 744-771, 817-954) ---- */
+enum { HODOR_OP_ADD = 0, HODOR_OP_SUB = 1, HODOR_OP_MUL = 2 };
+enum { HODOR_UN_NEGATE = 0, HODOR_UN_SQUARE = 1, HODOR_UN_POW = 2, HODOR_UN_SCALE = 3,
+       HODOR_UN_ADD_CONSTANT = 4, HODOR_UN_SUB_CONSTANT = 5 };
+/* add_assign / sub_assign / mul_assign: a[i] op= b[i] */
+int hodor_poly_binary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, const hodor_fr *b, size_t n, int op);
+/* add_assign_scaled: a[i] += scaling * b[i] */
+int hodor_poly_add_scaled_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, const hodor_fr *b, size_t n,
+                              const hodor_fr *scaling);
+/* negate / square / pow(e) / scale(c) / add_constant(c) / sub_constant(c) */
+int hodor_poly_unary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, int op, const hodor_fr *c,
+                         uint64_t e);
+/* batch_inversion: a[i] = a[i]^-1; HODOR_ERR_INVALID (data untouched) if any element is zero
+ * (SynthesisError::Error, src/polynomials/mod.rs:909).  Synchronises the stream. */
+int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n);
+/* evaluate_at: *out (host) = sum coeffs[i] g^i.  Synchronises the stream. */
+int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream, const hodor_fr *coeffs, size_t n, const hodor_fr *g,
+                               hodor_fr *out);
 /* Merkle tree over n device-resident leaves into n*32 device bytes */
 int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, uint8_t *nodes);
 /* IOP::query (src/iop/blake2s_trivial_iop.rs:324-338) on device-resident leaves and tree: the leaf

@@ -625,6 +625,60 @@ int o_poly_lde(const ofield *f, const ofr *coeffs, size_t n, size_t factor, int 
     return 0;
 }
 
+/* add_assign / sub_assign / mul_assign — src/polynomials/mod.rs:817-887 */
+void o_poly_binary(const ofield *f, ofr *a, const ofr *b, size_t n, int op)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (op == 0) ofr_add(f, &a[i], &b[i]);
+        else if (op == 1) ofr_sub(f, &a[i], &b[i]);
+        else ofr_mul(f, &a[i], &b[i]);
+    }
+}
+
+/* add_assign_scaled — :657-671 */
+void o_poly_add_scaled(const ofield *f, ofr *a, const ofr *b, size_t n, const ofr *scaling)
+{
+    for (size_t i = 0; i < n; i++) {
+        ofr t = b[i];
+        ofr_mul(f, &t, scaling);
+        ofr_add(f, &a[i], &t);
+    }
+}
+
+/* negate :73-83, square :758-771, pow :744-756, scale :60-72, add_constant / sub_constant */
+void o_poly_unary(const ofield *f, ofr *a, size_t n, int op, const ofr *c, uint64_t e)
+{
+    for (size_t i = 0; i < n; i++) {
+        switch (op) {
+        case 0: ofr_neg(f, &a[i]); break;
+        case 1: ofr_sqr(f, &a[i]); break;
+        case 2: { ofr t; ofr_pow(f, &t, &a[i], e); a[i] = t; break; }
+        case 3: ofr_mul(f, &a[i], c); break;
+        case 4: ofr_add(f, &a[i], c); break;
+        default: ofr_sub(f, &a[i], c); break;
+        }
+    }
+}
+
+/* batch_inversion — :889-954 (Montgomery's trick over one chunk) */
+int o_poly_batch_inversion(const ofield *f, ofr *a, size_t n)
+{
+    if (n == 0) return 0;
+    ofr *grand = (ofr *)malloc(n * sizeof(ofr));
+    ofr s = f->r;
+    for (size_t i = 0; i < n; i++) { ofr_mul(f, &s, &a[i]); grand[i] = s; }
+    ofr inv;
+    if (ofr_inverse(f, &inv, &s)) { free(grand); return -1; }   /* SynthesisError::Error */
+    for (size_t i = n; i-- > 0;) {
+        ofr tmp = a[i];
+        a[i] = i ? grand[i - 1] : f->r;
+        ofr_mul(f, &a[i], &inv);
+        ofr_mul(f, &inv, &tmp);
+    }
+    free(grand);
+    return 0;
+}
+
 void o_poly_evaluate_at(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out)
 {
     ofr x = f->r, acc = {{0, 0, 0, 0}};

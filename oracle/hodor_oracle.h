@@ -85,6 +85,12 @@ int o_poly_icoset_fft(const ofield *f, ofr *a, size_t n, uint32_t cpus);   /* :8
  * out has n*factor elements. */
 int o_poly_lde(const ofield *f, const ofr *coeffs, size_t n, size_t factor, int coset,
                ofr *out, uint32_t cpus);
+/* value-form ops (src/polynomials/mod.rs:60-83, 657-671, 744-771, 817-954); op codes as in
+ * include/hodor_gpu.h (binary: 0 add 1 sub 2 mul; unary: 0 negate 1 square 2 pow 3 scale 4 add_constant 5 sub_constant) */
+void o_poly_binary(const ofield *f, ofr *a, const ofr *b, size_t n, int op);
+void o_poly_add_scaled(const ofield *f, ofr *a, const ofr *b, size_t n, const ofr *scaling);
+void o_poly_unary(const ofield *f, ofr *a, size_t n, int op, const ofr *c, uint64_t e);
+int  o_poly_batch_inversion(const ofield *f, ofr *a, size_t n);   /* -1 (a untouched) if any zero, :909 */
 void o_poly_evaluate_at(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out);  /* :685-711 */
 
 /* ---- BLAKE2s IOP (src/iop/blake2s_trivial_iop.rs) ---- */

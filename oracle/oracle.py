@@ -234,6 +234,23 @@ class Oracle:
             raise ValueError("o_poly_lde failed")
         return out
 
+    def poly_binary(self, a, b, op):
+        self.L.o_poly_binary(C.byref(self.f), _ptr(a), _ptr(b), C.c_size_t(len(a)),
+                             C.c_int({"add": 0, "sub": 1, "mul": 2}[op]))
+
+    def poly_add_scaled(self, a, b, scaling):
+        sc = self.fr(scaling)
+        self.L.o_poly_add_scaled(C.byref(self.f), _ptr(a), _ptr(b), C.c_size_t(len(a)), C.byref(sc))
+
+    def poly_unary(self, a, op, c=0, e=0):
+        code = {"negate": 0, "square": 1, "pow": 2, "scale": 3, "add_constant": 4, "sub_constant": 5}[op]
+        cc = self.fr(c)
+        self.L.o_poly_unary(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.c_int(code), C.byref(cc), C.c_uint64(e))
+
+    def poly_batch_inversion(self, a):
+        if self.L.o_poly_batch_inversion(C.byref(self.f), _ptr(a), C.c_size_t(len(a))) != 0:
+            raise ValueError("SynthesisError::Error")
+
     def evaluate_at(self, coeffs, g):
         gg, out = self.fr(g), OFr()
         self.L.o_poly_evaluate_at(C.byref(self.f), _ptr(coeffs), C.c_size_t(len(coeffs)),

@@ -413,3 +413,91 @@ def test_fri_produce_proof(gpu_ctxs, oracles, log_deg, lde_factor, out_deg, inde
         idx = idx if idx < size // 2 else idx - size // 2
         size //= 2
     proto.free()
+
+
+# ---------------------------------------------------------------- re-entrancy
+def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
+    """The reference calls best_fft concurrently from scoped threads (src/arp/per_register/mod.rs:43-49,
+    src/polynomials/mod.rs:446-460); the ABI must be re-entrant on one context (ctypes drops the GIL)."""
+    import threading
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n = 13
+    n = 1 << log_n
+    _, _, w = O.domain(n)
+    inputs = [O.random_elements(n, 500 + t) for t in range(8)]
+    expected = []
+    for a in inputs:
+        e = a.copy()
+        O.serial_fft(e, w, log_n)
+        expected.append(e)
+    results = [None] * len(inputs)
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                b = inputs[t].copy()
+                if t % 2:
+                    ctx.fft(b, w, log_n)
+                else:
+                    ctx.poly_fft(b)
+                results[t] = b
+                nodes = ctx.iop_create(b)
+                assert nodes.shape == (n, 32)
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(len(inputs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(len(inputs)):
+        assert np.array_equal(results[t], expected[t]), t
+
+
+# ---------------------------------------------------------------- value-form polynomial ops (§8 f.1)
+@pytest.mark.parametrize("n", [1, 5, 1 << 10, (1 << 16) + 3, 1 << 18])
+def test_value_form_ops_dev(gpu_ctxs, oracles, field_name, n):
+    import torch
+    import hodor_amd
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    a, b = O.random_elements(n, 70), O.random_elements(n, 71)
+    d_b = torch.from_numpy(b.view(np.int64)).cuda()
+    s = O.random_elements(1, 72)
+    s = array_to_ints(s)[0]
+
+    def dev(x):
+        return torch.from_numpy(x.view(np.int64).copy()).cuda()
+
+    def host(t):
+        return t.cpu().numpy().view(np.uint64)
+
+    for op in ("add", "sub", "mul"):
+        exp = a.copy(); O.poly_binary(exp, b, op)
+        d = dev(a); ctx.poly_binary_dev(d, d_b, n, op)
+        assert np.array_equal(host(d), exp), op
+    exp = a.copy(); O.poly_add_scaled(exp, b, s)
+    d = dev(a); ctx.poly_add_scaled_dev(d, d_b, n, s)
+    assert np.array_equal(host(d), exp)
+    for op in ("negate", "square", "pow", "scale", "add_constant", "sub_constant"):
+        exp = a.copy(); O.poly_unary(exp, op, c=s, e=11)
+        d = dev(a); ctx.poly_unary_dev(d, n, op, c=s, e=11)
+        assert np.array_equal(host(d), exp), op
+    # batch_inversion == per-element inverse (test_batch_inversion, src/polynomials/mod.rs:959-985)
+    exp = a.copy(); O.poly_batch_inversion(exp)
+    d = dev(a); ctx.poly_batch_inversion_dev(d, n)
+    assert np.array_equal(host(d), exp)
+    chk = dev(a); ctx.poly_binary_dev(chk, d, n, "mul")
+    one = np.array(ints_to_array([O.one()]))[0]
+    assert (host(chk) == one).all()
+    z = a.copy(); z[n // 2] = 0
+    d = dev(z)
+    with pytest.raises(hodor_amd.HodorError) as e:
+        ctx.poly_batch_inversion_dev(d, n)              # SynthesisError::Error, :909
+    assert e.value.code == 2 and np.array_equal(host(d), z)
+    # evaluate_at
+    g = O.const("generator")
+    assert ctx.poly_evaluate_at_dev(dev(a), n, g) == O.evaluate_at(a, g)
+    assert ctx.poly_evaluate_at_dev(dev(a), n, s) == O.evaluate_at(a, s)

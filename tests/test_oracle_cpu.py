@@ -157,3 +157,32 @@ def test_fri_by_values_equals_through_coefficients(oracles, field_name):
         assert np.array_equal(nxt, r["inter_values"][i])
     assert canon_list(F, r["final_coeffs"]) == c[:outd]
     assert r["final_root"] == r["roots"][-1]
+
+
+def test_value_form_ops_against_bigint(oracles, field_name):
+    """test_batch_inversion (src/polynomials/mod.rs:959-985): batch inverse == per-element inverse;
+    pointwise ops against Python big-int arithmetic."""
+    O, F = oracles[field_name], PYF[field_name]
+    n = 257
+    a, b = O.random_elements(n, 1), O.random_elements(n, 2)
+    ca, cb = canon_list(F, a), canon_list(F, b)
+    for op, fn in (("add", lambda x, y: (x + y) % F.p), ("sub", lambda x, y: (x - y) % F.p),
+                   ("mul", lambda x, y: x * y % F.p)):
+        r = a.copy()
+        O.poly_binary(r, b, op)
+        assert canon_list(F, r) == [fn(x, y) for x, y in zip(ca, cb)], op
+    s = F.to_mont(12345)
+    r = a.copy(); O.poly_add_scaled(r, b, s)
+    assert canon_list(F, r) == [(x + 12345 * y) % F.p for x, y in zip(ca, cb)]
+    for op, fn in (("negate", lambda x: -x % F.p), ("square", lambda x: x * x % F.p),
+                   ("pow", lambda x: pow(x, 5, F.p)), ("scale", lambda x: x * 12345 % F.p),
+                   ("add_constant", lambda x: (x + 12345) % F.p), ("sub_constant", lambda x: (x - 12345) % F.p)):
+        r = a.copy(); O.poly_unary(r, op, c=s, e=5)
+        assert canon_list(F, r) == [fn(x) for x in ca], op
+    r = a.copy(); O.poly_batch_inversion(r)
+    assert canon_list(F, r) == [pow(x, -1, F.p) for x in ca]
+    z = a.copy(); z[100] = 0
+    before = z.copy()
+    with pytest.raises(ValueError):
+        O.poly_batch_inversion(z)
+    assert np.array_equal(z, before)
