@@ -501,3 +501,53 @@ def test_value_form_ops_dev(gpu_ctxs, oracles, field_name, n):
     g = O.const("generator")
     assert ctx.poly_evaluate_at_dev(dev(a), n, g) == O.evaluate_at(a, g)
     assert ctx.poly_evaluate_at_dev(dev(a), n, s) == O.evaluate_at(a, s)
+
+
+# ---------------------------------------------------------------- full BASELINE sizes
+def test_ntt_2_24_output_points_against_cpu_oracle(gpu_ctxs, oracles):
+    """BASELINE config[1] size.  A CPU transform of 2^24 points is out of reach for the test budget, but
+    single output points are not: X[k] = sum_i x[i] w^(ik) (evaluate_at, src/polynomials/mod.rs:685-711)
+    by the CPU oracle for a few k, plus the device-side evaluate_at (32-bit-limb arithmetic, a code path
+    independent of the 9x29-limb NTT kernels) for many more."""
+    import torch
+    from bench import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n = 24
+    n = 1 << log_n
+    a = random_elements(torch, n, 99)
+    b = torch.empty_like(a)
+    ctx.poly_fft_dev(a, b, log_n)
+    ctx.synchronize()
+    _, _, w = O.domain(n)
+    host_in = a.cpu().numpy().view(np.uint64)
+    ks_cpu = [1, n - 1]
+    ks_dev = [0, 2, 12345, n // 2, n // 3, (1 << 23) + 77, n - 2]
+    out = b.cpu().numpy().view(np.uint64)
+    for k in ks_cpu:
+        assert array_to_ints(out[k:k + 1])[0] == O.evaluate_at(host_in, O.pow(w, k)), k
+    for k in ks_dev + ks_cpu:
+        assert array_to_ints(out[k:k + 1])[0] == ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)), k
+    # inverse brings the input back, bit for bit
+    c = torch.empty_like(a)
+    ctx.poly_ifft_dev(b, c, log_n)
+    ctx.synchronize()
+    assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("log_n", [25, 26, 27])
+def test_large_transforms_roundtrip_and_points(gpu_ctxs, oracles, log_n):
+    """Sizes beyond the benchmark (FRI works on 2^26): 3- and 4-pass plans, 64-bit indexing."""
+    import torch
+    from bench import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    a = random_elements(torch, n, 5 + log_n)
+    b = torch.empty_like(a)
+    ctx.poly_fft_dev(a, b, log_n)
+    _, _, w = O.domain(n)
+    for k in (0, 1, n - 1, (n // 7) * 3):
+        got = array_to_ints(b[k:k + 1].cpu().numpy().view(np.uint64))[0]
+        assert got == ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)), k
+    ctx.poly_ifft_dev(b, b, log_n)            # in place
+    ctx.synchronize()
+    assert torch.equal(a, b)
