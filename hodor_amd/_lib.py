@@ -35,6 +35,9 @@ EXPORTS = [
     "hodor_fri_commit", "hodor_fri_free", "hodor_fri_num_steps", "hodor_fri_roots",
     "hodor_fri_final_root", "hodor_fri_challenges", "hodor_fri_final_coefficients",
     "hodor_fri_intermediate_values", "hodor_fri_tree_nodes", "hodor_fri_serialize",
+    "hodor_transcript_new", "hodor_transcript_free", "hodor_transcript_commit_bytes",
+    "hodor_transcript_commit_field_element", "hodor_transcript_get_challenge_bytes",
+    "hodor_transcript_get_challenge", "hodor_bytes_to_challenge_index",
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_distribute_powers_dev",
@@ -97,6 +100,8 @@ def lib():
         _lib.hodor_fri_num_steps.restype = C.c_size_t
         _lib.hodor_fri_serialize.restype = C.c_size_t
         _lib.hodor_fri_produce_proof.restype = C.c_size_t
+        _lib.hodor_bytes_to_challenge_index.restype = C.c_size_t
+        _lib.hodor_transcript_free.restype = None
         _lib.hodor_ctx_destroy.restype = None
         _lib.hodor_fri_free.restype = None
     return _lib
@@ -212,6 +217,39 @@ class FriPrototype:
             pass
 
 
+class Transcript:
+    """Blake2sTranscript (src/transcript/mod.rs:26-80)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.h = ctx, C.c_void_p()
+        ctx._chk(ctx.L.hodor_transcript_new(ctx.h, C.byref(self.h)))
+
+    def commit_bytes(self, b):
+        self.ctx._chk(self.ctx.L.hodor_transcript_commit_bytes(self.h, bytes(b), C.c_size_t(len(b))))
+
+    def commit_field_element(self, mont):
+        x = _fr(mont)
+        self.ctx._chk(self.ctx.L.hodor_transcript_commit_field_element(self.h, C.byref(x)))
+
+    def get_challenge_bytes(self):
+        out = (C.c_uint8 * 32)()
+        self.ctx._chk(self.ctx.L.hodor_transcript_get_challenge_bytes(self.h, out))
+        return bytes(out)
+
+    def get_challenge(self):
+        out = _Fr()
+        self.ctx._chk(self.ctx.L.hodor_transcript_get_challenge(self.h, C.byref(out)))
+        return _to_int(out.l)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.L.hodor_transcript_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class Context:
     """hodor_ctx: one prime field + one device (device=-1: host-only helpers, no compute)."""
 
@@ -284,6 +322,10 @@ class Context:
         c, x = (C.c_uint64 * 4)(), _fr(mont)
         self._chk(self.L.hodor_fr_into_repr(self.h, C.byref(x), c))
         return _to_int(c)
+
+    def bytes_to_challenge_index(self, b, lde_size, lde_factor):
+        return int(self.L.hodor_bytes_to_challenge_index(bytes(b), C.c_size_t(len(b)), C.c_size_t(lde_size),
+                                                         C.c_size_t(lde_factor)))
 
     def domain(self, size):
         """Domain::new_for_size -> (size, log_n, generator)"""

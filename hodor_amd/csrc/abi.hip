@@ -1208,6 +1208,66 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     return o;
 }
 
+// ---- Blake2sTranscript (src/transcript/mod.rs:10-80): host-side, sequential, O(#roots) ----
+struct hodor_transcript {
+    const hodor_ctx *ctx;
+    HostBlake2sStream state;
+    hodor_transcript(const hodor_ctx *c)
+        : ctx(c), state((const uint8_t *)"Squeamish Ossifrage", 19, (const uint8_t *)"Shaftoe", 7) {}
+};
+
+extern "C" int hodor_transcript_new(const hodor_ctx *ctx, hodor_transcript **out)
+{
+    if (!ctx || !out) return HODOR_ERR_INVALID;
+    if (ctx->F.num_bits >= 256) return HODOR_ERR_INVALID;   // assert!(F::NUM_BITS < 256), :41
+    *out = new (std::nothrow) hodor_transcript(ctx);
+    return *out ? HODOR_OK : HODOR_ERR_INVALID;
+}
+extern "C" void hodor_transcript_free(hodor_transcript *t) { delete t; }
+extern "C" int hodor_transcript_commit_bytes(hodor_transcript *t, const uint8_t *bytes, size_t len)
+{
+    if (!t || (!bytes && len)) return HODOR_ERR_INVALID;
+    t->state.update(bytes, len);
+    return HODOR_OK;
+}
+extern "C" int hodor_transcript_commit_field_element(hodor_transcript *t, const hodor_fr *e)
+{
+    if (!t || !e) return HODOR_ERR_INVALID;
+    uint64_t repr[4];
+    t->ctx->F.into_repr(to_h(e), repr);                    // into_repr(): canonical, then write_be (:52-57)
+    uint8_t be[32];
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) be[8 * i + b] = (uint8_t)(repr[3 - i] >> (56 - 8 * b));
+    t->state.update(be, 32);
+    return HODOR_OK;
+}
+extern "C" int hodor_transcript_get_challenge_bytes(hodor_transcript *t, uint8_t out[32])
+{
+    if (!t || !out) return HODOR_ERR_INVALID;
+    t->state.finalize(out);
+    t->state.update(out, 32);                               // the digest is re-absorbed (:61-62)
+    return HODOR_OK;
+}
+extern "C" int hodor_transcript_get_challenge(hodor_transcript *t, hodor_fr *out)
+{
+    if (!t || !out) return HODOR_ERR_INVALID;
+    uint8_t v[32];
+    t->state.finalize(v);
+    t->state.update(v, 32);
+    return hodor_iop_challenge(t->ctx, v, out);             // same read_be + shave + from_repr as interpret_hash
+}
+// Verifier::bytes_to_challenge_index (src/verifier/mod.rs:246-263)
+extern "C" size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t lde_size, size_t lde_factor)
+{
+    if (!bytes || len < 8 || !lde_size || !lde_factor) return 0;
+    uint64_t x = 0;
+    for (size_t i = len - 8; i < len; i++) x = (x << 8) | bytes[i];   // BigEndian::read_u64 of the last 8 bytes
+    size_t idx = (size_t)x % lde_size;
+    if (idx % lde_factor == 0) idx = (idx + 1) % lde_size;
+    if (idx % 2 == 0) idx = (idx + 1) % lde_size;
+    return idx;
+}
+
 extern "C" size_t hodor_fri_num_steps(const hodor_fri_proto *p) { return p ? p->num_steps : 0; }
 
 extern "C" int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots)

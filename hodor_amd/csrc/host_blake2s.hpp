@@ -93,4 +93,63 @@ struct HostBlake2s {
     }
 };
 
+// Streaming keyed BLAKE2s with a NON-destructive finalize, as blake2s_simd::State behaves
+// ("finalize is idempotent and the state can keep absorbing"): the transcript of
+// /root/reference/src/transcript/mod.rs:39-80 relies on exactly that.
+class HostBlake2sStream {
+  public:
+    HostBlake2sStream(const uint8_t *key, size_t keylen, const uint8_t *personal, size_t plen)
+    {
+        uint8_t param[32];
+        memset(param, 0, 32);
+        param[0] = 32;
+        param[1] = (uint8_t)keylen;
+        param[2] = 1;
+        param[3] = 1;
+        memcpy(param + 24, personal, plen > 8 ? 8 : plen);
+        for (int i = 0; i < 8; i++) {
+            uint32_t w;
+            memcpy(&w, param + 4 * i, 4);
+            h_[i] = HostBlake2s::IV[i] ^ w;
+        }
+        memset(buf_, 0, 64);
+        if (keylen) {   // the zero-padded key is the first block; it stays buffered until more data arrives
+            memcpy(buf_, key, keylen);
+            buflen_ = 64;
+        }
+    }
+    void update(const uint8_t *data, size_t len)
+    {
+        while (len) {
+            if (buflen_ == 64) {   // more input follows, so the buffered block is not the last one
+                t_ += 64;
+                HostBlake2s::compress(h_, buf_, t_, false);
+                buflen_ = 0;
+            }
+            size_t take = 64 - buflen_;
+            if (take > len) take = len;
+            memcpy(buf_ + buflen_, data, take);
+            buflen_ += take;
+            data += take;
+            len -= take;
+        }
+    }
+    void finalize(uint8_t out[32]) const
+    {
+        uint32_t h[8];
+        memcpy(h, h_, 32);
+        uint8_t block[64];
+        memset(block, 0, 64);
+        memcpy(block, buf_, buflen_);
+        HostBlake2s::compress(h, block, t_ + buflen_, true);
+        memcpy(out, h, 32);
+    }
+
+  private:
+    uint32_t h_[8];
+    uint8_t buf_[64];
+    size_t buflen_ = 0;
+    uint64_t t_ = 0;
+};
+
 }  // namespace hodor

@@ -128,6 +128,18 @@ int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes);
  * Returns the byte count; writes only when buf != NULL and cap is large enough. */
 size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap);
 
+/* Blake2sTranscript (src/transcript/mod.rs:10-80) and Verifier::bytes_to_challenge_index
+ * (src/verifier/mod.rs:246-263): host-side Fiat-Shamir glue, one running keyed BLAKE2s stream whose
+ * finalize is non-destructive and whose digest is re-absorbed after every challenge. */
+typedef struct hodor_transcript hodor_transcript;
+int  hodor_transcript_new(const hodor_ctx *ctx, hodor_transcript **out);
+void hodor_transcript_free(hodor_transcript *t);
+int  hodor_transcript_commit_bytes(hodor_transcript *t, const uint8_t *bytes, size_t len);
+int  hodor_transcript_commit_field_element(hodor_transcript *t, const hodor_fr *element);
+int  hodor_transcript_get_challenge_bytes(hodor_transcript *t, uint8_t out[32]);
+int  hodor_transcript_get_challenge(hodor_transcript *t, hodor_fr *out);
+size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t lde_size, size_t lde_factor);
+
 /* ================================ device API (device memory) ============================== */
 /* `stream` is a hipStream_t (NULL = the HIP default stream, which is also PyTorch-ROCm's default).  All work is enqueued in stream
  * order; nothing synchronises with the host unless stated.  A context owns one scratch pool, so use

@@ -258,3 +258,37 @@ def fri_serialize(F, proto):
     for c in proto["final_coeffs"]:
         out += mont_to_bytes(F.to_mont(c))
     return out
+
+
+# ------------------------------------------------------------------ transcript (src/transcript/mod.rs:26-80)
+class Transcript:
+    """Blake2sTranscript restated on hashlib: one running keyed stream; finalize is non-destructive
+    (hashlib's .digest() is too) and every challenge digest is re-absorbed."""
+
+    def __init__(self, F):
+        self.F = F
+        self.state = hashlib.blake2s(digest_size=32, key=IOP_KEY, person=IOP_PERSONAL)
+
+    def commit_bytes(self, b):
+        self.state.update(bytes(b))
+
+    def commit_field_element(self, canonical):
+        self.state.update(int(canonical).to_bytes(32, "big"))      # into_repr().write_be, :52-57
+
+    def get_challenge_bytes(self):
+        v = self.state.digest()
+        self.state.update(v)
+        return v
+
+    def get_challenge(self):
+        return interpret_hash(self.F, self.get_challenge_bytes())
+
+
+def bytes_to_challenge_index(b, lde_size, lde_factor):
+    """Verifier::bytes_to_challenge_index, src/verifier/mod.rs:246-263"""
+    idx = int.from_bytes(b[-8:], "big") % lde_size
+    if idx % lde_factor == 0:
+        idx = (idx + 1) % lde_size
+    if idx % 2 == 0:
+        idx = (idx + 1) % lde_size
+    return idx

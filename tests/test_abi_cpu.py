@@ -85,3 +85,30 @@ def test_no_cpu_fallback_without_device():
             call()
         assert e.value.code == _lib.ERR_DEVICE
     ctx.close()
+
+
+@pytest.mark.parametrize("F", [P.BN256, P.EXPERIMENTS], ids=["bn256", "experiments"])
+def test_transcript_matches_hashlib_restatement(F):
+    """Blake2sTranscript (src/transcript/mod.rs:26-80): running keyed stream, non-destructive
+    finalize, digest re-absorbed; challenge = interpret_hash of the digest."""
+    ctx = hodor_amd.Context(F.p, F.g, device=-1)
+    t, ref = _lib.Transcript(ctx), P.Transcript(F)
+    root = bytes(range(32))
+    for step in range(5):
+        t.commit_bytes(root); ref.commit_bytes(root)
+        e = pow(7, 1000 + step, F.p)
+        t.commit_field_element(F.to_mont(e)); ref.commit_field_element(e)
+        assert F.from_mont(t.get_challenge()) == ref.get_challenge()
+        b = t.get_challenge_bytes()
+        assert b == ref.get_challenge_bytes()
+        root = b
+        long = bytes((i * 7 + step) & 255 for i in range(200 + 17 * step))     # spans block boundaries
+        t.commit_bytes(long); ref.commit_bytes(long)
+    assert t.get_challenge_bytes() == ref.get_challenge_bytes()
+    fresh, fresh_ref = _lib.Transcript(ctx), P.Transcript(F)          # challenge of the empty transcript
+    assert fresh.get_challenge_bytes() == fresh_ref.get_challenge_bytes() == P.b2s(b"")
+    for lde_size, f in ((1 << 10, 8), (64, 16), (1 << 20, 16)):
+        for k in range(40):
+            b = bytes((k * 37 + i * 11) & 255 for i in range(32))
+            assert ctx.bytes_to_challenge_index(b, lde_size, f) == P.bytes_to_challenge_index(b, lde_size, f)
+    ctx.close()
