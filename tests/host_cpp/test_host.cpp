@@ -133,6 +133,26 @@ static void test_one_fri_step(const Field &F)
     CHECK(proto.challenges[0] == proto.l0_commitment.get_challenge_scalar_from_root());
 }
 
+// from_coeffs pads ragged input to the next power of two with zeros (src/polynomials/mod.rs:146-166);
+// an empty vector becomes the size-1 zero polynomial (Domain::new_for_size(0) -> 1)
+static void test_ragged_and_empty_inputs(const Field &F)
+{
+    XorShiftRng rng;
+    std::vector<Fr> five(5);
+    for (auto &v : five) v = rand_fr(rng, BN256_FR, 1);
+    auto p = from_coeffs(F, five);
+    CHECK(p.size() == 8 && p.exp == 3);
+    CHECK(p.coeffs[5] == F.zero() && p.coeffs[7] == F.zero());
+    std::vector<Fr> padded = five;
+    padded.resize(8, F.zero());
+    CHECK(fft(p).coeffs == fft(from_coeffs(F, padded)).coeffs);
+    auto e = from_coeffs(F, {});
+    CHECK(e.size() == 1 && e.coeffs[0] == F.zero());
+    CHECK(fft(e).coeffs[0] == F.zero());                       // a 1-point transform is the identity
+    auto one = from_coeffs(F, std::vector<Fr>{five[0]});
+    CHECK(lde(one, 4).coeffs == std::vector<Fr>(4, five[0]));  // constant polynomial
+}
+
 static void test_domain_errors(const Field &F)
 {
     bool threw = false;
@@ -149,6 +169,7 @@ int main()
     Field F(BN256_FR, 7, 0);
     CHECK(F.S() == 32 && F.capacity() == 254);
     test_domain_errors(F);
+    test_ragged_and_empty_inputs(F);
     test_fft_inverse_identity(F);
     test_lde_correctness(F);
     test_make_small_iop(F);

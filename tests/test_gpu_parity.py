@@ -551,3 +551,30 @@ def test_large_transforms_roundtrip_and_points(gpu_ctxs, oracles, log_n):
     ctx.poly_ifft_dev(b, b, log_n)            # in place
     ctx.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("log_n", [28, 30])
+def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
+    """2^30 is BASELINE config[4]'s size and two doublings short of the field's 2-adicity (S = 32);
+    at 32 B per element it is 32 GiB per buffer — it fits one MI355X (288 GB) with its ping-pong
+    scratch.  Checks a 4-pass plan with > 2^31-byte offsets: output points by direct evaluation
+    (device evaluate_at, independent arithmetic) and the inverse round trip."""
+    import torch
+    from bench import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3.4 * n * 32:
+        pytest.skip("not enough free HBM for 2^%d" % log_n)
+    a = random_elements(torch, n, 1000 + log_n)
+    b = torch.empty_like(a)
+    ctx.poly_fft_dev(a, b, log_n)
+    _, _, w = O.domain(n)
+    for k in (1, n - 1, (n // 5) * 2 + 1):
+        got = array_to_ints(b[k:k + 1].cpu().numpy().view(np.uint64))[0]
+        assert got == ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)), k
+    ctx.poly_ifft_dev(b, b, log_n)
+    ctx.synchronize()
+    assert torch.equal(a, b)
+    del a, b
+    torch.cuda.empty_cache()
