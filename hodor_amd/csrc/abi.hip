@@ -133,6 +133,7 @@ struct PowTable {
     uint32_t log_n;
     uint32_t lo_bits;
     uint32_t fmt;          // 0: 32-byte R-form entries, 1: 48-byte 9 x 29-bit R'-form entries
+    HFr hi_mult;           // every `hi` entry is multiplied by this (one, or n^-1 for the last iNTT pass)
     uint4 *lo, *hi;
 };
 
@@ -242,11 +243,12 @@ static int trim_table_cache(hodor_ctx *ctx)
 // base^e = lo[e & mask] * hi[e >> lo_bits] for e < 2^log_n
 // fmt 1 = 9 x 29-bit R'-form entries for k_ntt_pass, fmt 0 = 32-byte R-form entries (fold, twiddle_mul)
 static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
-                         uint32_t lo_bits = 0xffffffffu)
+                         uint32_t lo_bits = 0xffffffffu, const HFr *hi_mult_p = nullptr)
 {
     if (lo_bits > log_n) lo_bits = (log_n + 1) / 2;
+    const HFr hi_mult = hi_mult_p ? *hi_mult_p : ctx->F.one;
     for (auto &t : ctx->pow_tables)
-        if (t.log_n == log_n && t.lo_bits == lo_bits && t.fmt == fmt && t.base == base) {
+        if (t.log_n == log_n && t.lo_bits == lo_bits && t.fmt == fmt && t.base == base && t.hi_mult == hi_mult) {
             *out = TwoLevel{t.lo, t.hi, t.lo_bits};
             return HODOR_OK;
         }
@@ -255,13 +257,14 @@ static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLev
     t.log_n = log_n;
     t.lo_bits = lo_bits;
     t.fmt = fmt;
+    t.hi_mult = hi_mult;
     const size_t esz = fmt ? 48 : 32;
     uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
     HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * esz));
     HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * esz));
     Fr b = to_dev(base), one = to_dev(ctx->F.one);
     HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, fmt, ctx->P));
-    HIPCHK(pow_table_launch(ctx->stream, t.hi, b, one, t.lo_bits, hi_cnt, fmt, ctx->P));
+    HIPCHK(pow_table_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, fmt, ctx->P));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // tables are shared across streams afterwards
     ctx->pow_tables.push_back(t);
     *out = TwoLevel{t.lo, t.hi, t.lo_bits};
@@ -342,6 +345,12 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         if (log_n - shift2 <= 17 && shift2 <= 16) tw_lo_bits = shift2;
     }
     if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw, 1, tw_lo_bits))) return rc;
+    // iNTT: fold the n^-1 scale into the `hi` half of the LAST pass's twiddle table — every element of
+    // that pass is multiplied by a twiddle anyway (tw_always covers the exponent-0 ones), so the scale
+    // costs no product of its own (it is a separate streaming pass on the CPU, src/polynomials/mod.rs:777-787)
+    TwoLevel tw_last = tw;
+    const bool fold_scale = scale && passes > 1;
+    if (fold_scale && (rc = get_pow_table(ctx, omega, log_n, &tw_last, 1, tw_lo_bits, scale))) return rc;
     if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t, 1))) return rc;
     if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t, 1))) return rc;
 
@@ -377,7 +386,8 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         A.src = cur;
         A.dst = outs[i];
         if ((rc = get_radix_table(ctx, omega, log_n, log_r, &A.rtw))) return rc;
-        A.tw = tw;
+        A.tw = (i + 1 == passes) ? tw_last : tw;
+        A.tw_always = (fold_scale && i + 1 == passes) ? 1 : 0;
         A.pre = (i == 0) ? pre_t : TwoLevel{nullptr, nullptr, 0};
         A.post = (i + 1 == passes) ? post_t : TwoLevel{nullptr, nullptr, 0};
         A.nnz = (i == 0) ? nnz : (1ull << log_n);
@@ -395,7 +405,7 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
             uint32_t s = log_n - log2u((size_t)nnz);
             A.log_skip = s < log_r ? s : log_r;
         }
-        HIPCHK(ntt_launch_pass(stream, A, (scale && i + 1 == passes) ? &scale_d : nullptr, ctx->Q));
+        HIPCHK(ntt_launch_pass(stream, A, (scale && !fold_scale && i + 1 == passes) ? &scale_d : nullptr, ctx->Q));
         cur = outs[i];
         log_l += log_r;
     }

@@ -153,7 +153,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             if (A.pre.lo != nullptr && g != 0) x = fr9_mul(x, two_level_pow9(A.pre, g, Q), Q);
             if (A.apply_tw && !(A.dbg & 2)) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
-                if (ex != 0) x = fr9_mul(x, two_level_pow9(A.tw, ex, Q), Q);
+                if (ex != 0 || A.tw_always) x = fr9_mul(x, two_level_pow9(A.tw, ex, Q), Q);
             }
         } else {
 #pragma unroll
