@@ -31,7 +31,7 @@ EXPORTS = [
     "hodor_fft", "hodor_lde", "hodor_distribute_powers",
     "hodor_poly_fft", "hodor_poly_coset_fft", "hodor_poly_ifft", "hodor_poly_icoset_fft",
     "hodor_poly_lde", "hodor_poly_coset_lde",
-    "hodor_iop_create", "hodor_iop_challenge", "hodor_iop_path", "hodor_iop_verify",
+    "hodor_iop_create", "hodor_hash_leaf", "hodor_hash_node", "hodor_iop_challenge", "hodor_iop_path", "hodor_iop_verify",
     "hodor_fri_commit", "hodor_fri_free", "hodor_fri_num_steps", "hodor_fri_roots",
     "hodor_fri_final_root", "hodor_fri_challenges", "hodor_fri_final_coefficients",
     "hodor_fri_intermediate_values", "hodor_fri_tree_nodes", "hodor_fri_serialize",
@@ -370,6 +370,16 @@ class Context:
         self._chk(self.L.hodor_iop_create(self.h, _hptr(leafs), C.c_size_t(len(leafs)),
                                           nodes.ctypes.data_as(C.c_void_p)))
         return nodes
+
+    def hash_leaf(self, mont):
+        out, x = (C.c_uint8 * 32)(), _fr(mont)
+        self._chk(self.L.hodor_hash_leaf(self.h, C.byref(x), out))
+        return bytes(out)
+
+    def hash_node(self, left, right):
+        out = (C.c_uint8 * 32)()
+        self._chk(self.L.hodor_hash_node(self.h, bytes(left), bytes(right), out))
+        return bytes(out)
 
     def iop_challenge(self, root):
         out = _Fr()

@@ -1079,6 +1079,21 @@ static void host_hash_node(const hodor_ctx *ctx, const uint8_t *l, const uint8_t
     HostBlake2s::finish(ctx->mid.h, buf, 64, out);
 }
 
+// IopTreeHasher::{hash_leaf, hash_node} (src/iop/blake2s_trivial_iop.rs:81-104) for single digests on
+// the host: the top log2(P) levels of a tree whose subtrees live on P GPUs, path checks, ...
+extern "C" int hodor_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32])
+{
+    if (!ctx || !leaf || !out) return HODOR_ERR_INVALID;
+    host_hash_leaf(ctx, leaf, out);
+    return HODOR_OK;
+}
+extern "C" int hodor_hash_node(const hodor_ctx *ctx, const uint8_t left[32], const uint8_t right[32], uint8_t out[32])
+{
+    if (!ctx || !left || !right || !out) return HODOR_ERR_INVALID;
+    host_hash_node(ctx, left, right, out);
+    return HODOR_OK;
+}
+
 extern "C" int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
                               size_t tree_index, uint8_t *path, size_t *path_len)
 {

@@ -1,0 +1,71 @@
+"""distributed.py — the commit step over the GPUs of one node.
+
+`merkle_commit_distributed`: rank r holds natural block r of the n leaves (exactly what
+`sixstep_ntt` leaves behind).  Each rank builds the complete subtree over its block on its own GPU
+(`Blake2sIopTree::create`, /root/reference/src/iop/blake2s_trivial_iop.rs:131-219); the P subtree
+roots are exchanged with ONE all-gather of 32 bytes per rank (RCCL; gloo in the CPU tests) and every
+rank hashes the top log2(P) levels itself, so all ranks hold the same root and the same challenge.
+The global heap layout is preserved: local node `w + j` of a local level of width w is global node
+`w*P + r*w + j`; the top levels (global widths < P) are replicated.
+
+`lde_commit_distributed`: zero-padded 6-step transform (`sixstep_ntt`) followed by the distributed
+commit — BASELINE config[2]'s shape across a node.
+"""
+import torch
+import torch.distributed as dist
+
+from .sixstep import sixstep_ntt
+
+
+class HipTreeBackend:
+    """Local subtree on the MI355X through the C ABI."""
+
+    def __init__(self, ctx, stream=None):
+        self.ctx, self.stream = ctx, stream
+
+    def tree(self, leafs):
+        n = leafs.shape[0]
+        nodes = torch.empty((n, 32), dtype=torch.uint8, device=leafs.device)
+        self.ctx.iop_create_dev(leafs, n, nodes, stream=self.stream)
+        return nodes
+
+    def hash_node(self, left, right):
+        return self.ctx.hash_node(left, right)
+
+
+def merkle_commit_distributed(backend, leafs_local, rank, world, group=None):
+    """Returns (root: bytes, local_nodes: (n/P, 32) uint8 tensor, top: dict global_node_index -> bytes).
+    `top` holds the replicated levels: global node indices 1 .. 2P-1 (index P+r is rank r's subtree root)."""
+    assert world & (world - 1) == 0, "power-of-two world size"
+    local_nodes = backend.tree(leafs_local)
+    my_root = local_nodes[1].contiguous()
+    if world == 1:
+        roots = [bytes(my_root.cpu().numpy())]
+    else:
+        gathered = torch.empty((world, 32), dtype=torch.uint8, device=my_root.device)
+        dist.all_gather_into_tensor(gathered, my_root.view(1, 32), group=group)
+        roots = [bytes(r) for r in gathered.cpu().numpy()]
+    top = {world + r: roots[r] for r in range(world)}
+    w = world // 2
+    while w >= 1:
+        for i in range(w):
+            top[w + i] = backend.hash_node(top[2 * (w + i)], top[2 * (w + i) + 1])
+        w //= 2
+    return top[1], local_nodes, top
+
+
+def global_node_index(local_index, local_width, rank, world):
+    """Heap index in the n-leaf tree of local node `local_width + j` (local_index = local_width + j)."""
+    j = local_index - local_width
+    return local_width * world + rank * local_width + j
+
+
+def lde_commit_distributed(ntt_backend, tree_backend, coeffs_block, log_n, factor, omega_big, rank, world,
+                           group=None):
+    """`coeffs_block`: this rank's natural block of the ZERO-PADDED coefficient vector of length
+    (1 << log_n) * factor (all-zero on the ranks beyond the coefficients).  Returns
+    (lde_block, root, local_nodes, top)."""
+    log_big = log_n + (factor.bit_length() - 1)
+    lde_block = sixstep_ntt(ntt_backend, coeffs_block, log_big, omega_big, rank, world, group)
+    root, local_nodes, top = merkle_commit_distributed(tree_backend, lde_block, rank, world, group)
+    return lde_block, root, local_nodes, top

@@ -102,6 +102,9 @@ int hodor_poly_coset_lde(hodor_ctx *ctx, const hodor_fr *coeffs, size_t n, size_
 int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n, uint8_t *nodes);
 /* encode_root_into_challenge / interpret_hash — :48-60, :226-234 (host) */
 int hodor_iop_challenge(const hodor_ctx *ctx, const uint8_t root[32], hodor_fr *out);
+/* IopTreeHasher::hash_leaf / hash_node — :81-104 (host, single digests) */
+int hodor_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32]);
+int hodor_hash_node(const hodor_ctx *ctx, const uint8_t left[32], const uint8_t right[32], uint8_t out[32]);
 /* get_path — :251-279 (host; path holds log2(n) digests, returns the count in *path_len) */
 int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
                    size_t tree_index, uint8_t *path, size_t *path_len);

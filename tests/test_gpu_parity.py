@@ -578,3 +578,26 @@ def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
     assert torch.equal(a, b)
     del a, b
     torch.cuda.empty_cache()
+
+
+def test_distributed_commit_single_rank_on_device(gpu_ctxs, oracles):
+    """hodor_amd/distributed.py with the HIP backends at world = 1 == slice API == oracle."""
+    import torch
+    from hodor_amd.distributed import HipTreeBackend, lde_commit_distributed
+    from hodor_amd.sixstep import HipBackend
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n, factor = 10, 8
+    n = 1 << log_n
+    coeffs = O.random_elements(n, 31337)
+    padded = np.zeros((n * factor, 4), dtype=np.uint64)
+    padded[:n] = coeffs
+    d = torch.from_numpy(padded.view(np.int64)).cuda()
+    _, _, Omega = O.domain(n * factor)
+    lde, root, nodes, top = lde_commit_distributed(HipBackend(ctx), HipTreeBackend(ctx), d, log_n, factor, Omega, 0, 1)
+    ctx.synchronize()
+    exp = O.poly_lde(coeffs, factor)
+    assert np.array_equal(lde.cpu().numpy().view(np.uint64), exp)
+    exp_nodes = O.iop_create(exp)
+    assert root == bytes(exp_nodes[1]) and np.array_equal(nodes.cpu().numpy(), exp_nodes)
+    assert ctx.hash_node(bytes(exp_nodes[2]), bytes(exp_nodes[3])) == root
+    assert ctx.hash_leaf(array_to_ints(exp[:1])[0]) == O.hash_leaf(array_to_ints(exp[:1])[0])

@@ -98,3 +98,61 @@ def test_sixstep_matches_single_device_transform(world, log_n):
     assert len(ret) == world
     for r in range(world):
         assert ret[r] == (True, True), (r, ret[r])
+
+
+# ---------------------------------------------------------------- distributed LDE + Merkle commit
+class OracleTreeBackend:
+    def __init__(self, O):
+        self.O = O
+
+    def tree(self, leafs):
+        arr = np.ascontiguousarray(leafs.numpy().view(np.uint64))
+        return torch.from_numpy(self.O.iop_create(arr))
+
+    def hash_node(self, left, right):
+        return self.O.hash_node(left, right)
+
+
+def _commit_worker(rank, world, port, log_n, factor, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hodor_amd.distributed import global_node_index, lde_commit_distributed
+        be = OracleBackend()
+        O = be.O
+        n = 1 << log_n
+        big = n * factor
+        coeffs = O.random_elements(n, 777)
+        padded = np.zeros((big, 4), dtype=np.uint64)
+        padded[:n] = coeffs
+        blk = big // world
+        mine = torch.from_numpy(padded[rank * blk:(rank + 1) * blk].copy().view(np.int64))
+        _, k, Omega = O.domain(big)
+        lde_block, root, local_nodes, top = lde_commit_distributed(be, OracleTreeBackend(O), mine, log_n, factor,
+                                                                  Omega, rank, world)
+        full = O.poly_lde(coeffs, factor)                     # single-device LDE + tree
+        nodes = O.iop_create(full)
+        ok_lde = np.array_equal(lde_block.numpy().view(np.uint64), full[rank * blk:(rank + 1) * blk])
+        ok_root = root == bytes(nodes[1])
+        ok_top = all(top[g] == bytes(nodes[g]) for g in top)
+        ln = local_nodes.numpy()
+        ok_nodes = True
+        w = blk // 2
+        while w >= 1:
+            for j in range(w):
+                ok_nodes &= bytes(ln[w + j]) == bytes(nodes[global_node_index(w + j, w, rank, world)])
+            w //= 2
+        ret[rank] = (ok_lde, ok_root, ok_top, ok_nodes)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,factor", [(2, 5, 4), (4, 6, 8)])
+def test_distributed_lde_commit_matches_single_device(world, log_n, factor):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_commit_worker, args=(world, _free_port(), log_n, factor, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r] == (True, True, True, True), (r, ret[r])
