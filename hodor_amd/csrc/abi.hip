@@ -159,6 +159,8 @@ struct hodor_ctx {
     std::vector<RadixTable> radix_tables;
     void *scratch[2] = {nullptr, nullptr};
     size_t scratch_bytes[2] = {0, 0};
+    void *io[2] = {nullptr, nullptr};       // grow-only device staging of the slice API (in / out)
+    size_t io_bytes[2] = {0, 0};
     void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
     size_t fri_slab_bytes = 0;
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
@@ -291,6 +293,22 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->radix_tables.push_back(t);
     *out = t.rtw;
+    return HODOR_OK;
+}
+
+// staging buffers of the slice API: kept across calls so a caller looping over registers
+// (src/arp/per_register/mod.rs:43-49) pays hipMalloc once, not per call
+static int ensure_io(hodor_ctx *ctx, int which, size_t bytes)
+{
+    if (ctx->io_bytes[which] >= bytes) return HODOR_OK;
+    if (ctx->io[which]) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(ctx->io[which]));
+        ctx->io[which] = nullptr;
+        ctx->io_bytes[which] = 0;
+    }
+    HIPCHK(hipMalloc(&ctx->io[which], bytes));
+    ctx->io_bytes[which] = bytes;
     return HODOR_OK;
 }
 
@@ -515,6 +533,8 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         for (int i = 0; i < 2; i++)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
         if (ctx->fri_slab) (void)hipFree(ctx->fri_slab);
+        for (int i = 0; i < 2; i++)
+            if (ctx->io[i]) (void)hipFree(ctx->io[i]);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -948,15 +968,15 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
 template <class Op>
 static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *out, size_t n_out, Op op)
 {
-    DevBuf din, dout;
-    HIPCHK(hipMalloc(&din.p, (n_in ? n_in : 1) * 32));
-    void *dptr_out = din.p;
+    int rc = ensure_io(ctx, 0, (n_in ? n_in : 1) * 32);
+    if (rc) return rc;
+    void *din = ctx->io[0], *dptr_out = din;
     if (n_out != n_in) {
-        HIPCHK(hipMalloc(&dout.p, (n_out ? n_out : 1) * 32));
-        dptr_out = dout.p;
+        if ((rc = ensure_io(ctx, 1, (n_out ? n_out : 1) * 32))) return rc;
+        dptr_out = ctx->io[1];
     }
-    HIPCHK(hipMemcpyAsync(din.p, in, n_in * 32, hipMemcpyHostToDevice, ctx->stream));
-    int rc = op((const uint4 *)din.p, (uint4 *)dptr_out);
+    HIPCHK(hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = op((const uint4 *)din, (uint4 *)dptr_out);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     HIPCHK(hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1040,12 +1060,11 @@ extern "C" int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n,
     if (!leafs || !nodes) return HODOR_ERR_INVALID;
     if (!is_pow2(n) || n < 2) { ctx->err = "iop_create: n must be a power of two >= 2"; return HODOR_ERR_SIZE; }
     std::lock_guard<std::mutex> lk(ctx->mu);
-    DevBuf dl, dn;
-    HIPCHK(hipMalloc(&dl.p, n * 32));
-    HIPCHK(hipMalloc(&dn.p, n * 32));
-    HIPCHK(hipMemcpyAsync(dl.p, leafs, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(merkle_build_launch(ctx->stream, (const uint4 *)dl.p, (uint4 *)dn.p, n, ctx->mid));
-    HIPCHK(hipMemcpyAsync(nodes, dn.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = ensure_io(ctx, 0, n * 32);
+    if (rc || (rc = ensure_io(ctx, 1, n * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->io[0], leafs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(merkle_build_launch(ctx->stream, (const uint4 *)ctx->io[0], (uint4 *)ctx->io[1], n, ctx->mid));
+    HIPCHK(hipMemcpyAsync(nodes, ctx->io[1], n * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return HODOR_OK;
 }

@@ -17,7 +17,7 @@
 //   * Inside the kernel elements live in the carry-free 9 x 29-bit form of fr9.cuh (162 mads per
 //     product, add/sub = 9 plain adds, lazily reduced); HBM always holds the reference's 8 x 32-bit
 //     Montgomery image.  LDS keeps limbs 0-3 / 4-7 as two 16-byte arrays plus a 4-byte array for
-//     limb 8, rows padded by one slot.
+//     limb 8, columns XOR-swizzled by the row index.
 //   * Inter-pass twiddles come from a two-level power table (L2-resident) instead of an n-entry
 //     table streamed from HBM.
 //
@@ -186,7 +186,6 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         log_m += 1;
         __syncthreads();
     }
-    bool first = true;
     if (A.dbg & 1) log_m = log_r;
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
@@ -233,10 +232,8 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             lds_put(D, s2, x2);
             lds_put(D, s3, x3);
         }
-        first = false;
         __syncthreads();
     }
-    (void)first;
 
     // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
     const bool transposed = (A.log_l == 0);   // first pass: outputs of one sub-transform are contiguous
