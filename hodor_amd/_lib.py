@@ -40,7 +40,7 @@ EXPORTS = [
     "hodor_transcript_get_challenge", "hodor_bytes_to_challenge_index",
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
-    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_distribute_powers_dev",
+    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev",
@@ -444,6 +444,15 @@ class Context:
     def poly_lde_dev(self, src, dst, log_n, factor, coset=False, stream=None):
         self._chk(self.L.hodor_poly_lde_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
                                             C.c_uint32(log_n), C.c_size_t(factor), C.c_int(1 if coset else 0)))
+
+    def poly_lde_batch_dev(self, src, dst, log_n, factor, batch, coset=False, stream=None):
+        self._chk(self.L.hodor_poly_lde_batch_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                  C.c_uint32(log_n), C.c_size_t(factor),
+                                                  C.c_int(1 if coset else 0), C.c_size_t(batch)))
+
+    def iop_create_batch_dev(self, leafs, n, batch, nodes, stream=None):
+        self._chk(self.L.hodor_iop_create_batch_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n),
+                                                    C.c_size_t(batch), _dptr(nodes)))
 
     def distribute_powers_dev(self, a, n, g, stream=None):
         gg = _fr(g)

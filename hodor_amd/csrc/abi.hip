@@ -31,7 +31,8 @@ hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr 
                               uint32_t *ticket, uint4 *out, const FrParams &);
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
                               const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
-hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &);
+hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &,
+                               uint32_t batch = 1);
 hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &);
 hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, const Fr &r2,
@@ -417,6 +418,7 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         A.log_l = log_l;
         A.apply_tw = (i == 0) ? 0 : 1;
         A.batch = batch;
+        A.src_batch_stride = (i == 0) ? nnz : (1ull << log_n);
         A.dbg = 0;
         A.log_skip = 0;
         if (i == 0 && nnz && nnz < (1ull << log_n) && !(nnz & (nnz - 1))) {
@@ -471,7 +473,7 @@ static int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, 
 // lde / coset_lde: one zero-padded transform of size n*factor — identical output to the
 // reference's per-coset schedule (asserted by its own tests, src/polynomials/mod.rs:1026-1031)
 static int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
-                         uint32_t log_n, size_t factor, int coset)
+                         uint32_t log_n, size_t factor, int coset, uint32_t batch = 1)
 {
     if (!is_pow2(factor)) { ctx->err = "lde factor must be a power of two"; return HODOR_ERR_SIZE; }
     uint32_t log_big = log_n + log2u(factor);
@@ -479,7 +481,7 @@ static int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, u
     int rc = poly_domain(ctx, log_big, &Omega);
     if (rc) return rc;
     return ntt_exec(ctx, stream, src, dst, log_big, Omega, 1ull << log_n, nullptr,
-                    coset ? &ctx->F.generator : nullptr, nullptr);
+                    coset ? &ctx->F.generator : nullptr, nullptr, batch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -694,6 +696,30 @@ extern "C" int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *
     std::lock_guard<std::mutex> lk(ctx->mu);
     return poly_lde_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, factor,
                          coset);
+}
+
+// Batched multi-column LDE and commit: all registers' f_ldes and their oracles in
+// one call each (src/prover/mod.rs:73-80 loops over the witness polynomials).
+extern "C" int hodor_poly_lde_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                                        uint32_t log_n, size_t factor, int coset, size_t batch)
+{
+    NEED_DEVICE();
+    if (!src || !dst || src == dst) return HODOR_ERR_INVALID;
+    if (batch == 0 || batch > 65535) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_lde_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, factor, coset,
+                         (uint32_t)batch);
+}
+
+extern "C" int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n,
+                                          size_t batch, uint8_t *nodes)
+{
+    NEED_DEVICE();
+    if (!leafs || !nodes) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2 || batch == 0 || batch > 65535) return HODOR_ERR_SIZE;
+    HIPCHK(merkle_build_launch(pick_stream(ctx, stream), (const uint4 *)leafs, (uint4 *)nodes, n, ctx->mid,
+                               (uint32_t)batch));
+    return HODOR_OK;
 }
 
 extern "C" int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n,

@@ -103,8 +103,11 @@ constexpr uint32_t MERKLE_LOG_CH = 11;   // 2048 inputs per workgroup: 32 KiB + 
 
 template <bool LEAF>
 __global__ void __launch_bounds__(256)
-k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, B2Mid mid)
+k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint64_t n, B2Mid mid)
 {
+    // blockIdx.y selects one of several independent trees over n leaves each (batched commit)
+    leafs += 2 * (uint64_t)blockIdx.y * n;
+    nodes += 2 * (uint64_t)blockIdx.y * n;
     __shared__ uint4 buf_a[2 * (1u << (MERKLE_LOG_CH - 1))];   // up to 1024 digests
     __shared__ uint4 buf_b[2 * (1u << (MERKLE_LOG_CH - 2))];   // up to 512 digests
     const uint32_t tid = threadIdx.x;
@@ -208,11 +211,13 @@ hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *
 }
 
 hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,
-                               const B2Mid &mid)
+                               const B2Mid &mid, uint32_t batch)
 {
-    // n >= 2, power of two (checked by the caller)
-    hipError_t e = hipMemsetAsync(nodes, 0, 32, s);   // nodes[0] is unused by the layout
-    if (e != hipSuccess) return e;
+    // n >= 2, power of two (checked by the caller); `batch` trees back to back
+    for (uint32_t b = 0; b < batch; b++) {   // nodes[0] of every tree is unused by the layout
+        hipError_t e = hipMemsetAsync((uint8_t *)nodes + (size_t)b * n * 32, 0, 32, s);
+        if (e != hipSuccess) return e;
+    }
     uint64_t m = n;
     bool first = true;
     while (m > 1) {
@@ -220,11 +225,11 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
         while ((1ull << (log_ch + 1)) <= m && log_ch + 1 <= MERKLE_LOG_CH) log_ch++;
         uint64_t chunks = m >> log_ch;
         if (first)
-            hipLaunchKernelGGL(k_merkle_subtree<true>, dim3((unsigned)chunks), dim3(256), 0, s, leafs, nodes, m,
-                               log_ch, mid);
+            hipLaunchKernelGGL(k_merkle_subtree<true>, dim3((unsigned)chunks, batch), dim3(256), 0, s, leafs, nodes,
+                               m, log_ch, n, mid);
         else
-            hipLaunchKernelGGL(k_merkle_subtree<false>, dim3((unsigned)chunks), dim3(256), 0, s, leafs, nodes, m,
-                               log_ch, mid);
+            hipLaunchKernelGGL(k_merkle_subtree<false>, dim3((unsigned)chunks, batch), dim3(256), 0, s, leafs, nodes,
+                               m, log_ch, n, mid);
         m >>= log_ch;
         first = false;
     }

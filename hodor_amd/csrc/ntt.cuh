@@ -32,7 +32,8 @@ struct PassArgs {
     uint32_t log_l;          // product of the radices of the previous passes (L = 2^log_l)
     uint32_t apply_tw;       // 0: no inter-pass twiddle (first pass)  1: lo*hi  2: hi only
     uint32_t tw_always;      // 1: multiply by the twiddle even when its exponent is 0 (hi carries the iNTT scale)
-    uint32_t batch;          // number of independent size-n transforms (grid.y); arrays are n elements apart
+    uint32_t batch;          // number of independent size-n transforms (grid.y); dst arrays are n elements apart
+    uint64_t src_batch_stride;   // distance between the batch's source arrays, in elements
     uint32_t log_skip;       // first pass of a zero-padded transform: nnz == n >> log_skip (see k_ntt_pass)
     uint32_t dbg;            // profiling only (HODOR_DBG): 1 skip butterflies, 2 skip twiddles, 4 skip loads, 8 skip stores
 };

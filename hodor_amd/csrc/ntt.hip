@@ -124,7 +124,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     for (uint32_t e = tid; e < (R >> 1); e += nthreads) lds_put(T, e, fr9_load48(A.rtw + 3 * e));
 
     // batched transforms: blockIdx.y selects one of `batch` independent size-n arrays
-    const uint4 *src_b = A.src + ((2ull * blockIdx.y) << A.log_n);
+    const uint4 *src_b = A.src + 2ull * blockIdx.y * A.src_batch_stride;   // first LDE pass: n/f apart
     uint4 *dst_b = A.dst + ((2ull * blockIdx.y) << A.log_n);
     const uint64_t n_over_r = 1ull << (A.log_n - log_r);
     const uint64_t j0 = (uint64_t)blockIdx.x << log_c;

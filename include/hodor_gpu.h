@@ -171,6 +171,13 @@ int hodor_poly_icoset_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src,
 /* LDE: src has 1<<log_n coefficients, dst has (1<<log_n)*factor values; coset != 0 -> coset_lde */
 int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                        uint32_t log_n, size_t factor, int coset);
+/* `batch` polynomials at once (all registers of the trace, src/prover/mod.rs:73-80): src holds batch
+ * arrays of 1<<log_n coefficients back to back, dst batch arrays of (1<<log_n)*factor values; the
+ * commit twin builds batch trees over n leaves each into batch node arrays of n*32 bytes. */
+int hodor_poly_lde_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                             uint32_t log_n, size_t factor, int coset, size_t batch);
+int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, size_t batch,
+                               uint8_t *nodes);
 int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
 /* ---- value-form polynomial arithmetic on device-resident buffers (the pointwise steps either side of
  * every LDE in ALI: src/polynomials/mod.rs:60-83, 640-683, 744-771, 817-954) ---- */

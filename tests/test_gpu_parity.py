@@ -601,3 +601,26 @@ def test_distributed_commit_single_rank_on_device(gpu_ctxs, oracles):
     assert root == bytes(exp_nodes[1]) and np.array_equal(nodes.cpu().numpy(), exp_nodes)
     assert ctx.hash_node(bytes(exp_nodes[2]), bytes(exp_nodes[3])) == root
     assert ctx.hash_leaf(array_to_ints(exp[:1])[0]) == O.hash_leaf(array_to_ints(exp[:1])[0])
+
+
+# ---------------------------------------------------------------- batched multi-column LDE + commit (§8 f.4)
+@pytest.mark.parametrize("log_n,factor,batch", [(4, 4, 3), (10, 8, 5), (13, 16, 4)])
+def test_batched_lde_and_commit(gpu_ctxs, oracles, log_n, factor, batch):
+    """All registers at once (src/prover/mod.rs:73-80): same values and trees as one call per polynomial."""
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    big = n * factor
+    coeffs = O.random_elements(n * batch, 4040 + log_n)
+    d_c = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    d_lde = torch.empty((big * batch, 4), dtype=torch.int64, device="cuda")
+    d_nodes = torch.empty((big * batch, 32), dtype=torch.uint8, device="cuda")
+    for coset in (False, True):
+        ctx.poly_lde_batch_dev(d_c, d_lde, log_n, factor, batch, coset=coset)
+        ctx.iop_create_batch_dev(d_lde, big, batch, d_nodes)
+        ctx.synchronize()
+        lde, nodes = d_lde.cpu().numpy().view(np.uint64), d_nodes.cpu().numpy()
+        for b in range(batch):
+            exp = O.poly_lde(np.ascontiguousarray(coeffs[b * n:(b + 1) * n]), factor, coset)
+            assert np.array_equal(lde[b * big:(b + 1) * big], exp), (b, coset)
+            assert np.array_equal(nodes[b * big:(b + 1) * big], O.iop_create(exp)), (b, coset)
