@@ -292,3 +292,64 @@ def bytes_to_challenge_index(b, lde_size, lde_factor):
     if idx % 2 == 0:
         idx = (idx + 1) % lde_size
     return idx
+
+
+# ------------------------------------------------------------------ FRI verifier (acceptance oracle)
+def fri_verify_proof_queries(F, proof, natural_element_index, expected_value_from_oracle, degree=2):
+    """NaiveFriIop::verify_proof_queries, src/fri/verifier.rs:131-289, restated line for line.
+    `proof`: dict(queries=[(natural_index, value_mont, [path digests])], roots=[bytes], final_coeffs=[mont],
+    initial_degree_plus_one, lde_factor).  Returns True / False (Err cases raise ValueError).
+    NOTE (reference behaviour): after the last oracle the verifier folds once more with the challenge of
+    the final root and compares with the final coefficients evaluated in the next domain — consistent
+    with the prover only when output_coeffs_at_degree_plus_one == 1."""
+    p = F.p
+    two_inv = pow(2, -1, p)
+    size = proof["initial_degree_plus_one"] * proof["lde_factor"]
+    omega, _, size = F.domain_generator(size)
+    x = pow(omega, natural_element_index, p)
+    if pow(x, size, p) != 1 or pow(x, size // 2, p) == 1:
+        raise ValueError("initial challenge value is not in the LDE domain")
+    omega_inv = pow(omega, -1, p)
+    expected = None
+    domain_size, domain_idx = size, natural_element_index
+    queries = proof["queries"]
+    if len(queries) % degree != 0:
+        raise ValueError("invalid number of queries")
+    for rnd, root in enumerate(proof["roots"]):
+        qs = queries[degree * rnd:degree * (rnd + 1)]
+        pair = (domain_idx + domain_size // 2) % domain_size
+        coset = sorted([domain_idx, pair])
+        if any(q[0] not in coset for q in qs):
+            return False
+        if rnd == 0:
+            for q in qs:
+                if q[0] == natural_element_index and q[1] != expected_value_from_oracle:
+                    return False
+        for c, q in zip(coset, qs):
+            if q[0] != c:
+                raise ValueError("invalid tree index")
+        for q in qs:
+            if not iop_verify(root, q[1], q[2], q[0]):
+                return False
+        challenge = interpret_hash(F, root)
+        f_at_omega = F.from_mont(qs[0][1])
+        if expected is not None:
+            hit = [q for q in qs if q[0] == domain_idx]
+            if len(hit) != 1 or F.from_mont(hit[0][1]) != expected:
+                return False
+        f_at_minus_omega = F.from_mont(qs[1][1])
+        divisor = pow(omega_inv, coset[0], p)
+        even = (f_at_omega + f_at_minus_omega) % p
+        odd = (f_at_omega - f_at_minus_omega) * divisor % p
+        expected = (odd * challenge + even) * two_inv % p
+        nxt = domain_size // 2
+        domain_idx = domain_idx if domain_idx < nxt else domain_idx - nxt
+        domain_size = nxt
+        omega = omega * omega % p
+        omega_inv = omega_inv * omega_inv % p
+    point = pow(omega, domain_idx, p)
+    acc, power = 0, 1
+    for c in proof["final_coeffs"]:
+        acc = (acc + power * F.from_mont(c)) % p
+        power = power * point % p
+    return acc == expected

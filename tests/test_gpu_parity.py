@@ -624,3 +624,37 @@ def test_batched_lde_and_commit(gpu_ctxs, oracles, log_n, factor, batch):
             exp = O.poly_lde(np.ascontiguousarray(coeffs[b * n:(b + 1) * n]), factor, coset)
             assert np.array_equal(lde[b * big:(b + 1) * big], exp), (b, coset)
             assert np.array_equal(nodes[b * big:(b + 1) * big], O.iop_create(exp)), (b, coset)
+
+
+@pytest.mark.parametrize("log_deg,lde_factor", [(4, 4), (9, 8), (12, 16)])
+def test_fri_proof_accepted_by_restated_verifier(gpu_ctxs, oracles, log_deg, lde_factor):
+    """Acceptance oracle: the reference's own verifier (verify_proof_queries, src/fri/verifier.rs:131-289,
+    restated in oracle/pyref.py) accepts proofs produced on the device and rejects tampered ones
+    (test_fib_fri_iop_verifier, src/fri/mod.rs:364-507: 'wrong expected value rejected')."""
+    import torch
+    ctx, O, F = gpu_ctxs["bn256"], oracles["bn256"], P.BN256
+    coeffs = O.random_elements(1 << log_deg, 1 + log_deg)
+    lde = O.poly_lde(coeffs, lde_factor)
+    n = len(lde)
+    d_lde = torch.from_numpy(lde.view(np.int64)).cuda()
+    proto = ctx.fri_commit_dev(d_lde, n, lde_factor, 1)
+    ints = array_to_ints(lde)
+    for index in (1, 3, n // 2 + 1, n - 1):          # odd indices: never in the sub-domain of size n/2
+        proof = proto.produce_proof(d_lde, index)
+        assert P.fri_verify_proof_queries(F, proof, index, ints[index])
+        assert not P.fri_verify_proof_queries(F, proof, index, ints[index] ^ 1)      # wrong expected value
+        bad = dict(proof)
+        q = list(proof["queries"])
+        q[2] = (q[2][0], q[2][1] ^ 2, q[2][2])                                        # corrupt a round-1 value
+        bad["queries"] = q
+        assert not P.fri_verify_proof_queries(F, bad, index, ints[index])
+        bad = dict(proof)
+        q = list(proof["queries"])
+        path = list(q[1][2]); path[-1] = bytes(32)
+        q[1] = (q[1][0], q[1][1], path)                                               # corrupt a path
+        bad["queries"] = q
+        assert not P.fri_verify_proof_queries(F, bad, index, ints[index])
+        bad = dict(proof)
+        bad["final_coeffs"] = [proof["final_coeffs"][0] ^ 4]
+        assert not P.fri_verify_proof_queries(F, bad, index, ints[index])
+    proto.free()
