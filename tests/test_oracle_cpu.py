@@ -186,3 +186,30 @@ def test_value_form_ops_against_bigint(oracles, field_name):
     with pytest.raises(ValueError):
         O.poly_batch_inversion(z)
     assert np.array_equal(z, before)
+
+
+def test_restated_verifier_accepts_oracle_proofs(oracles):
+    """verify_proof_queries (src/fri/verifier.rs:131-289) over a proof assembled from the oracle's commit
+    + get_path, the way produce_proof does (src/fri/query_producer.rs:10-53)."""
+    O, F = oracles["bn256"], PYF["bn256"]
+    coeffs = O.random_elements(32, 3)
+    f = 8
+    lde = O.poly_lde(coeffs, f)
+    n = len(lde)
+    r = O.fri_commit(lde, f, 1)
+    vectors = [lde] + r["inter_values"]
+    for index in (1, 77, n - 1):
+        queries, size, idx = [], n, index
+        for vec in vectors:
+            nodes = O.iop_create(vec)
+            ints = array_to_ints(vec)
+            for c in sorted([idx, (idx + size // 2) % size]):
+                queries.append((c, ints[c], [bytes(x) for x in O.iop_path(nodes, vec, c)]))
+            idx = idx if idx < size // 2 else idx - size // 2
+            size //= 2
+        proof = dict(queries=queries, roots=r["roots"], final_coeffs=array_to_ints(r["final_coeffs"]),
+                     initial_degree_plus_one=n // f, lde_factor=f)
+        assert P.fri_verify_proof_queries(F, proof, index, array_to_ints(lde)[index])
+        assert not P.fri_verify_proof_queries(F, proof, index, array_to_ints(lde)[index] ^ 1)
+    with pytest.raises(ValueError):
+        P.fri_verify_proof_queries(F, proof, 2, 0)      # even index: lies in the half-size sub-domain
