@@ -170,17 +170,19 @@ def main():
         avg_launch_ms = kernel_ms / launches
         alg_bytes_per_launch = 2.0 * n * 32 / passes
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None     # HBM bytes per launch from the committed rocprofv3 PMC passes (not live)
+        traffic = profiled_ms = None   # from the committed rocprofv3 passes of the same command (not live)
         try:
             pmcs = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r"))
             t = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1], "pmc_traffic.json")))
             if t.get("log_n") == log_n and args.mode == "replicas":
                 traffic = t["hbm_bytes_per_launch"]
+                profiled_ms = t.get("kernel_trace_avg_launch_ms")
         except Exception:
             pass
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "kernel": "k_ntt_pass", "avg_launch_ms": avg_launch_ms,
+                              "rocprofv3_avg_launch_ms": profiled_ms,
                               "launches_per_transform": passes,
                               "alg_bytes_per_launch": alg_bytes_per_launch,
                               "note": "integer-ALU-bound kernel (v_mad_u64_u32); HBM fraction reported as required"}
