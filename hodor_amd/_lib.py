@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libhodor_gpu.so")
+_LIB = os.environ.get("HODOR_LIB") or os.path.join(_HERE, "libhodor_gpu.so")   # HODOR_LIB: A/B builds (bench/ab.sh)
 _CSRC = os.path.join(_HERE, "csrc")
 
 # Fields the reference defines (src/bn256.rs:5-6, src/experiments/mod.rs:19-20)
