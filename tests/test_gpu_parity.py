@@ -658,3 +658,52 @@ def test_fri_proof_accepted_by_restated_verifier(gpu_ctxs, oracles, log_deg, lde
         bad["final_coeffs"] = [proof["final_coeffs"][0] ^ 4]
         assert not P.fri_verify_proof_queries(F, bad, index, ints[index])
     proto.free()
+
+
+# ---------------------------------------------------------------- randomized sweep
+def test_randomized_configurations(gpu_ctxs, oracles, field_name):
+    """60 seeded random (size, operation, factor, batch) draws against the oracle: plan shapes with odd
+    and even stage counts, every zero-padding depth, in-place and out-of-place device calls."""
+    import random
+    import torch
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    rng = random.Random(0xC0FFEE if field_name == "bn256" else 0xBEEF)
+    for it in range(60):
+        log_n = rng.randint(0, 14)
+        n = 1 << log_n
+        a = O.random_elements(n, rng.randrange(1 << 30))
+        op = rng.choice(["fft", "ifft", "coset_fft", "icoset_fft", "lde", "coset_lde", "batch", "omega"])
+        if op in ("fft", "ifft", "coset_fft", "icoset_fft"):
+            exp = a.copy()
+            getattr(O, "poly_" + op)(exp)
+            d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+            out = d if rng.random() < 0.5 else torch.empty_like(d)
+            getattr(ctx, "poly_%s_dev" % op)(d, out, log_n)
+            ctx.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint64), exp), (it, op, log_n)
+        elif op in ("lde", "coset_lde"):
+            factor = 1 << rng.randint(0, 5)
+            exp = O.poly_lde(a, factor, coset=(op == "coset_lde"))
+            assert np.array_equal(ctx.poly_lde(a, factor, coset=(op == "coset_lde")), exp), (it, op, log_n, factor)
+        elif op == "batch":
+            batch = rng.randint(1, 6)
+            big = O.random_elements(n * batch, rng.randrange(1 << 30))
+            _, _, w = O.domain(n)
+            d = torch.from_numpy(big.view(np.int64).copy()).cuda()
+            out = torch.empty_like(d)
+            ctx.fft_batch_dev(d, out, log_n, batch, w)
+            ctx.synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+            for b in range(batch):
+                row = np.ascontiguousarray(big[b * n:(b + 1) * n])
+                O.serial_fft(row, w, log_n)
+                assert np.array_equal(got[b * n:(b + 1) * n], row), (it, op, log_n, b)
+        else:   # arbitrary generator of the order-n subgroup
+            _, _, w = O.domain(n)
+            k = rng.randrange(1, max(2, n)) | 1
+            wk = O.pow(w, k)
+            exp = a.copy()
+            O.serial_fft(exp, wk, log_n)
+            got = a.copy()
+            ctx.fft(got, wk, log_n)
+            assert np.array_equal(got, exp), (it, op, log_n, k)
