@@ -78,7 +78,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     if world > 1 or "RANK" in os.environ:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints banner lines ("Hostname : ...", "Librccl path : ...") on STDOUT when the first
+        # communicator is created; keep stdout to the single JSON line by parking fd 1 meanwhile.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+            os.close(devnull)
 
     ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=local_rank)
     log_n = args.log_n
