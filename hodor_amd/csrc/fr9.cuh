@@ -138,9 +138,10 @@ __device__ __forceinline__ Fr9 fr9_mul(const Fr9 &a, const Fr9 &b, const Fr9Para
 
 // Bring a lazy value (limbs < 2^32, value < 2^261) below 2^250 + 2p < 2^256 by subtracting
 // q*p with q = floor(floor(x / 2^250) * mu / 2^16) <= floor(x / p); result normalized.
+template <bool NORMALIZED = false>   // NORMALIZED: limbs 0..7 are already < 2^29 (skip the first carry pass)
 __device__ __forceinline__ void fr9_reduce_partial(Fr9 &a, const Fr9Params &P)
 {
-    fr9_normalize(a);
+    if (!NORMALIZED) fr9_normalize(a);
     // bits >= 250 : limb 8 holds bits 232.., so x >> 250 = v[8] >> 18
     uint32_t q = ((a.v[8] >> 18) * P.mu) >> 16;
     uint64_t carry = 0;
@@ -167,18 +168,20 @@ __device__ __forceinline__ void fr9_cond_sub_p(Fr9 &a, const Fr9Params &P)
 }
 
 // lazy value -> canonical [0, p) in the 8 x 32-bit memory format
+template <bool NORMALIZED = false>
 __device__ __forceinline__ Fr fr9_to_canonical(Fr9 a, const Fr9Params &P)
 {
-    fr9_reduce_partial(a, P);      // < 2^250 + 2p  (< 3p)
+    fr9_reduce_partial<NORMALIZED>(a, P);      // < 2^250 + 2p  (< 3p)
     fr9_cond_sub_p(a, P);
     fr9_cond_sub_p(a, P);
     return fr9_pack(a);
 }
 
 // lazy value -> some representative < 2^256 in the 8 x 32-bit memory format (between passes)
+template <bool NORMALIZED = false>
 __device__ __forceinline__ Fr fr9_to_packed(Fr9 a, const Fr9Params &P)
 {
-    fr9_reduce_partial(a, P);
+    fr9_reduce_partial<NORMALIZED>(a, P);
     return fr9_pack(a);
 }
 

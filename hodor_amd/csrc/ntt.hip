@@ -248,7 +248,8 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         Fr9 x = lds_get(D, SLOT(cc, c));
         if (has_scale) x = fr9_mul(x, scale, Q);
         if (A.post.lo != nullptr && o != 0) x = fr9_mul(x, two_level_pow9(A.post, o, Q), Q);
-        Fr y = last ? fr9_to_canonical(x, Q) : fr9_to_packed(x, Q);
+        // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
+        Fr y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
         if ((A.dbg & 8) && y.v[0] != 0x12345u) continue;
         fr_store(dst_b + 2 * o, y);
     }
