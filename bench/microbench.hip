@@ -431,7 +431,7 @@ int main()
         Fr9Params Q;
         const uint32_t p9[9] = {0x00000001, 0x1ffffff8, 0x1f96ffbf, 0x1b4805ff, 0x0c0a77b4, 0x0c0404d0, 0x11f52199, 0x1a94ce9d, 0x0073eda7};
         for (int i = 0; i < 9; i++) { Q.p[i] = p9[i]; Q.c4p[i] = 0x20000000u + p9[i]; }
-        Q.pinv = 0x1fffffff; Q.mu = 2262;
+        Q.pinv = 0x1fffffff; Q.mu = 2262; Q.red_shift = 18;
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9mul, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
         printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr9_mul (9x29)", ms, muls / ms * 1e-6);
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9addsub, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });

@@ -99,13 +99,16 @@ static void make_params9(const HostField &F, Fr9Params *Q)
         if (i > 0) c -= 1;
         Q->c4p[i] = c;
     }
-    // mu = floor(2^266 / p) by binary long division (quotient has ~12 bits)
+    // mu = floor(2^(red_bit + 16) / p), red_bit = NUM_BITS - 5, by binary long division (~12-bit quotient)
+    const int red_bit = (int)F.num_bits - 5;
+    Q->red_shift = (uint32_t)(red_bit - 232);
+    const int top = red_bit + 16;
     uint64_t rem[5] = {0, 0, 0, 0, 0};
     uint32_t mu = 0;
-    for (int bit = 266; bit >= 0; bit--) {
+    for (int bit = top; bit >= 0; bit--) {
         for (int i = 4; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);   // rem <<= 1
         rem[0] <<= 1;
-        if (bit == 266) rem[0] |= 1;
+        if (bit == top) rem[0] |= 1;
         bool ge = rem[4] != 0;
         if (!ge) {
             ge = true;
@@ -494,6 +497,9 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
     hodor_ctx *ctx = new (std::nothrow) hodor_ctx();
     if (!ctx) return HODOR_ERR_INVALID;
     if (!ctx->F.init(modulus, generator)) { delete ctx; return HODOR_ERR_INVALID; }
+    // the 9 x 29-bit kernels keep the top bits of a value in limb 8 (bits 232..): 240 <= NUM_BITS <= 255
+    // covers both 4-limb fields of the reference (255 and 252 bits)
+    if (ctx->F.num_bits < 240) { delete ctx; return HODOR_ERR_INVALID; }
     for (int i = 0; i < 4; i++) {
         ctx->P.p[2 * i] = (uint32_t)ctx->F.p[i];
         ctx->P.p[2 * i + 1] = (uint32_t)(ctx->F.p[i] >> 32);

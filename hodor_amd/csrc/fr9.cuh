@@ -33,7 +33,8 @@ struct Fr9Params {      // kernel argument -> SGPRs
     uint32_t p[9];      // modulus, normalized 29-bit limbs
     uint32_t pinv;      // -p^-1 mod 2^29
     uint32_t c4p[9];    // 4p with limbs 0..7 in [2^29, 2^30): subtraction offset
-    uint32_t mu;        // floor(2^266 / p): quotient estimate for the partial reduction
+    uint32_t mu;        // floor(2^(red_bit + 16) / p): quotient estimate for the partial reduction
+    uint32_t red_shift; // red_bit - 232 with red_bit = NUM_BITS - 5: the estimate reads x >> red_bit from limb 8
 };
 
 // ---- format conversion: 8 x 32-bit words <-> 9 x 29-bit limbs (same integer) ----
@@ -136,14 +137,16 @@ __device__ __forceinline__ Fr9 fr9_mul(const Fr9 &a, const Fr9 &b, const Fr9Para
     return t;
 }
 
-// Bring a lazy value (limbs < 2^32, value < 2^261) below 2^250 + 2p < 2^256 by subtracting
-// q*p with q = floor(floor(x / 2^250) * mu / 2^16) <= floor(x / p); result normalized.
+// Bring a lazy value (limbs < 2^32, value < 2^261) into [0, 2p) by subtracting q*p with
+//   q = floor(floor(x / 2^b) * mu / 2^16),  b = NUM_BITS - 5,  mu = floor(2^(b+16) / p).
+// q never exceeds floor(x/p), and q >= x/p - x/2^(b+16) - 2^b/p > x/p - 1/32 - 1/16, hence
+// q >= floor(x/p) - 1 and the remainder is < 2p (one conditional subtraction away from canonical).
+// Result normalized.  (NUM_BITS >= 240 is checked at context creation, so bit b lies in limb 8.)
 template <bool NORMALIZED = false>   // NORMALIZED: limbs 0..7 are already < 2^29 (skip the first carry pass)
 __device__ __forceinline__ void fr9_reduce_partial(Fr9 &a, const Fr9Params &P)
 {
     if (!NORMALIZED) fr9_normalize(a);
-    // bits >= 250 : limb 8 holds bits 232.., so x >> 250 = v[8] >> 18
-    uint32_t q = ((a.v[8] >> 18) * P.mu) >> 16;
+    uint32_t q = ((a.v[8] >> P.red_shift) * P.mu) >> 16;   // limb 8 holds bits 232 and up
     uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -171,8 +174,7 @@ __device__ __forceinline__ void fr9_cond_sub_p(Fr9 &a, const Fr9Params &P)
 template <bool NORMALIZED = false>
 __device__ __forceinline__ Fr fr9_to_canonical(Fr9 a, const Fr9Params &P)
 {
-    fr9_reduce_partial<NORMALIZED>(a, P);      // < 2^250 + 2p  (< 3p)
-    fr9_cond_sub_p(a, P);
+    fr9_reduce_partial<NORMALIZED>(a, P);      // < 2p
     fr9_cond_sub_p(a, P);
     return fr9_pack(a);
 }

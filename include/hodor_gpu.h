@@ -51,7 +51,8 @@ typedef struct {
 
 /* ---- context: the constants `#[derive(PrimeField)]` generates (src/bn256.rs:4-7,
  * src/experiments/mod.rs:18-21) + device state (streams, twiddle cache, scratch).
- * `modulus` must be an odd prime with 2^192 < p < 2^255 (4-limb ff_ce field, R = 2^256). */
+ * `modulus` must be an odd prime with 2^239 < p < 2^255 (4-limb ff_ce field, R = 2^256; the reference's
+ * two 4-limb fields have 255 and 252 bits). */
 int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
 void hodor_ctx_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
