@@ -16,6 +16,8 @@
 //
 // 32-bit ARX integer work: no MFMA.  One hash per lane, all 16 state words + 16 message words in
 // VGPRs, sigma schedule resolved at compile time.
+#include <cstdlib>
+
 #include "fr.cuh"
 
 namespace hodor {
@@ -103,7 +105,8 @@ constexpr uint32_t MERKLE_LOG_CH = 11;   // 2048 inputs per workgroup: 32 KiB + 
 
 template <bool LEAF>
 __global__ void __launch_bounds__(256)
-k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint64_t n, B2Mid mid)
+k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint32_t levels, uint64_t n,
+                 B2Mid mid)
 {
     // blockIdx.y selects one of several independent trees over n leaves each (batched commit)
     leafs += 2 * (uint64_t)blockIdx.y * n;
@@ -137,7 +140,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
 
     // levels 2 .. log_ch: ping-pong between the two LDS buffers
     uint4 *src = buf_a, *dst = buf_b;
-    for (uint32_t k = 2; k <= log_ch; k++) {
+    for (uint32_t k = 2; k <= levels; k++) {
         const uint32_t w = ch >> k;
         lvl_out = nodes + 2 * ((m >> k) + chunk * w);
         for (uint32_t g = tid; g < w; g += 256) {
@@ -224,13 +227,23 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
         uint32_t log_ch = 0;
         while ((1ull << (log_ch + 1)) <= m && log_ch + 1 <= MERKLE_LOG_CH) log_ch++;
         uint64_t chunks = m >> log_ch;
+        // A chunk's last levels are narrower than a wave: each is one compression's latency with the
+        // rest of the workgroup idle.  When many chunks follow anyway, stop at level width `tail_w`
+        // and let the next launch (whose chunks are again full) pick the survivors up.
+        static int tail_log = -1;
+        if (tail_log < 0) {
+            const char *e = getenv("HODOR_MERKLE_TAIL_LOG");
+            tail_log = e ? atoi(e) : 6;
+        }
+        uint32_t levels = log_ch;
+        if (chunks >= 512 && log_ch > (uint32_t)tail_log) levels = log_ch - (uint32_t)tail_log;
         if (first)
             hipLaunchKernelGGL(k_merkle_subtree<true>, dim3((unsigned)chunks, batch), dim3(256), 0, s, leafs, nodes,
-                               m, log_ch, n, mid);
+                               m, log_ch, levels, n, mid);
         else
             hipLaunchKernelGGL(k_merkle_subtree<false>, dim3((unsigned)chunks, batch), dim3(256), 0, s, leafs, nodes,
-                               m, log_ch, n, mid);
-        m >>= log_ch;
+                               m, log_ch, levels, n, mid);
+        m >>= levels;
         first = false;
     }
     return hipGetLastError();
