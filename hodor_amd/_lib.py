@@ -40,7 +40,7 @@ EXPORTS = [
     "hodor_transcript_get_challenge", "hodor_bytes_to_challenge_index",
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
-    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev",
+    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev",
@@ -457,6 +457,12 @@ class Context:
     def distribute_powers_dev(self, a, n, g, stream=None):
         gg = _fr(g)
         self._chk(self.L.hodor_distribute_powers_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.byref(gg)))
+
+    def precomputed_omegas_dev(self, log_n, omegas=None, coset=None, omegas_inv=None, stream=None):
+        """PrecomputedOmegas::new_for_domain (src/precomputations/mod.rs:14-66) into device buffers."""
+        p = lambda t: _dptr(t) if t is not None else C.c_void_p(None)
+        self._chk(self.L.hodor_precomputed_omegas_dev(self.h, C.c_void_p(stream), C.c_uint32(log_n), p(omegas),
+                                                      p(coset), p(omegas_inv)))
 
     def poly_binary_dev(self, a, b, n, op, stream=None):
         self._chk(self.L.hodor_poly_binary_dev(self.h, C.c_void_p(stream), _dptr(a), _dptr(b), C.c_size_t(n),

@@ -35,7 +35,7 @@ hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, ui
                                uint32_t batch = 1);
 hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &);
-hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, const Fr &r2,
+hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, uint4 *root_out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &);
 hipError_t fri_round_table_launch(hipStream_t, const uint4 *hi, uint4 *hi_out, uint64_t count,
                                   const uint4 *challenge, const Fr9 &c16, const Fr9Params &);
@@ -737,6 +737,27 @@ extern "C" int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_f
     return HODOR_OK;
 }
 
+extern "C" int hodor_precomputed_omegas_dev(hodor_ctx *ctx, void *stream, uint32_t log_n, hodor_fr *omegas,
+                                            hodor_fr *coset, hodor_fr *omegas_inv)
+{
+    NEED_DEVICE();
+    uint64_t size;
+    uint32_t lg;
+    HFr w, winv;
+    if (log_n > 40 || !ctx->F.domain(1ull << log_n, &size, &lg, &w)) {
+        ctx->err = "domain larger than the field's two-adicity";
+        return HODOR_ERR_SIZE;
+    }
+    if (!ctx->F.inverse(w, &winv)) return HODOR_ERR_INVALID;
+    hipStream_t s = pick_stream(ctx, stream);
+    const uint64_t n = 1ull << log_n;
+    if (omegas) HIPCHK(pow_table_launch(s, (uint4 *)omegas, to_dev(w), to_dev(ctx->F.one), 0, n, 0, ctx->P));
+    if (coset) HIPCHK(pow_table_launch(s, (uint4 *)coset, to_dev(w), to_dev(ctx->F.generator), 0, n, 0, ctx->P));
+    if (omegas_inv && n >= 2)
+        HIPCHK(pow_table_launch(s, (uint4 *)omegas_inv, to_dev(winv), to_dev(ctx->F.one), 0, n / 2, 0, ctx->P));
+    return HODOR_OK;
+}
+
 extern "C" int hodor_fft_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                                    uint32_t log_n, size_t batch, const hodor_fr *omega)
 {
@@ -958,8 +979,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     Fr r2 = to_dev(ctx->F.r2);
 
     FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
-    FRICHK(challenge_launch(stream, (const uint4 *)p->l0_nodes, d_chal, r2, shave, ctx->P));             // :51
-    FRICHK(hipMemcpyAsync(d_roots, (const uint8_t *)p->l0_nodes + 32, 32, hipMemcpyDeviceToDevice, stream));
+    FRICHK(challenge_launch(stream, (const uint4 *)p->l0_nodes, d_chal, d_roots, r2, shave, ctx->P));    // :51
 
     const uint4 *values = (const uint4 *)lde_values;
     size_t next_size = n / 2;
@@ -969,9 +989,8 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
         FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits,
                                (uint32_t)i, ctx->Q));                                                    // :70-104
         FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid));   // :106
-        FRICHK(challenge_launch(stream, (const uint4 *)nodes, d_chal + 2 * (i + 1), r2, shave, ctx->P));
-        FRICHK(hipMemcpyAsync((uint8_t *)d_roots + 32 * (i + 1), (const uint8_t *)nodes + 32, 32,
-                              hipMemcpyDeviceToDevice, stream));
+        FRICHK(challenge_launch(stream, (const uint4 *)nodes, d_chal + 2 * (i + 1), d_roots + 2 * (i + 1), r2,
+                                shave, ctx->P));
         values = (const uint4 *)next;
         next_size >>= 1;
     }

@@ -111,6 +111,31 @@ struct Domain {
     }
 };
 
+// src/precomputations/mod.rs:7-66 — omegas[i] = w^i, coset[i] = g*w^i (domain size), omegas_inv[i] = w^-i
+// (half the domain); the tables are produced on the device and downloaded.
+struct PrecomputedOmegas {
+    std::vector<Fr> omegas, coset, omegas_inv;
+
+    static PrecomputedOmegas new_for_domain(const Field &F, const Domain &domain)
+    {
+        PrecomputedOmegas t;
+        const size_t n = (size_t)domain.size;
+        t.omegas.resize(n);
+        t.coset.resize(n);
+        t.omegas_inv.resize(n / 2);
+        void *dev = nullptr;
+        F.check(hodor_buf_alloc(F.ctx(), (2 * n + n / 2 + 1) * sizeof(Fr), &dev), "PrecomputedOmegas: alloc");
+        Fr *d = static_cast<Fr *>(dev);
+        int rc = hodor_precomputed_omegas_dev(F.ctx(), nullptr, (uint32_t)domain.power_of_two, d, d + n, d + 2 * n);
+        if (!rc) rc = hodor_buf_download(F.ctx(), t.omegas.data(), d, n * sizeof(Fr));
+        if (!rc) rc = hodor_buf_download(F.ctx(), t.coset.data(), d + n, n * sizeof(Fr));
+        if (!rc && n >= 2) rc = hodor_buf_download(F.ctx(), t.omegas_inv.data(), d + 2 * n, (n / 2) * sizeof(Fr));
+        hodor_buf_free(F.ctx(), dev);
+        F.check(rc, "PrecomputedOmegas::new_for_domain");
+        return t;
+    }
+};
+
 struct Coefficients {};
 struct Values {};
 

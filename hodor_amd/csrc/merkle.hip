@@ -156,13 +156,24 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
         __syncthreads();
         uint4 *t = src; src = dst; dst = t;
     }
+    // the launch that produces the root also clears nodes[0], which the heap layout leaves unused
+    if ((m >> levels) == 1 && tid == 0) {
+        nodes[0] = make_uint4(0, 0, 0, 0);
+        nodes[1] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 // K8: root digest -> field challenge (interpret_hash): big-endian read, clear the top
 // 256 - CAPACITY bits, convert to Montgomery form (multiply by R^2).
-__global__ void k_challenge(const uint4 *nodes, uint4 *out, Fr r2, uint32_t shave_bits, FrParams P)
+// `root_out` (optional) receives a copy of the root digest: the FRI round loop collects its roots there.
+__global__ void k_challenge(const uint4 *nodes, uint4 *out, uint4 *root_out, Fr r2, uint32_t shave_bits,
+                            FrParams P)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (root_out) {
+        root_out[0] = nodes[2];
+        root_out[1] = nodes[3];
+    }
     const uint32_t *d = reinterpret_cast<const uint32_t *>(nodes + 2);   // nodes[1]
     Fr x;
 #pragma unroll
@@ -217,10 +228,6 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
                                const B2Mid &mid, uint32_t batch)
 {
     // n >= 2, power of two (checked by the caller); `batch` trees back to back
-    for (uint32_t b = 0; b < batch; b++) {   // nodes[0] of every tree is unused by the layout
-        hipError_t e = hipMemsetAsync((uint8_t *)nodes + (size_t)b * n * 32, 0, 32, s);
-        if (e != hipSuccess) return e;
-    }
     uint64_t m = n;
     bool first = true;
     while (m > 1) {
@@ -249,10 +256,10 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
     return hipGetLastError();
 }
 
-hipError_t challenge_launch(hipStream_t s, const uint4 *nodes, uint4 *out, const Fr &r2,
+hipError_t challenge_launch(hipStream_t s, const uint4 *nodes, uint4 *out, uint4 *root_out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &P)
 {
-    hipLaunchKernelGGL(k_challenge, dim3(1), dim3(64), 0, s, nodes, out, r2, shave_bits, P);
+    hipLaunchKernelGGL(k_challenge, dim3(1), dim3(64), 0, s, nodes, out, root_out, r2, shave_bits, P);
     return hipGetLastError();
 }
 

@@ -180,6 +180,11 @@ int hodor_poly_lde_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, 
 int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, size_t batch,
                                uint8_t *nodes);
 int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
+/* PrecomputedOmegas::new_for_domain — src/precomputations/mod.rs:14-66: for the domain of size
+ * n = 1<<log_n with generator w: omegas[i] = w^i (n entries), coset[i] = g*w^i (n entries, g the
+ * multiplicative generator), omegas_inv[i] = w^-i (n/2 entries).  A NULL output is skipped. */
+int hodor_precomputed_omegas_dev(hodor_ctx *ctx, void *stream, uint32_t log_n, hodor_fr *omegas,
+                                 hodor_fr *coset, hodor_fr *omegas_inv);
 /* ---- value-form polynomial arithmetic on device-resident buffers (the pointwise steps either side of
  * every LDE in ALI: src/polynomials/mod.rs:60-83, 640-683, 744-771, 817-954) ---- */
 enum { HODOR_OP_ADD = 0, HODOR_OP_SUB = 1, HODOR_OP_MUL = 2 };

@@ -164,12 +164,30 @@ static void test_domain_errors(const Field &F)
     CHECK(nx.first == 5 && nx.second == 8);
 }
 
+// PrecomputedOmegas::new_for_domain (src/precomputations/mod.rs:14-66) against running products
+static void test_precomputed_omegas(const Field &F)
+{
+    Domain d = Domain::new_for_size(F, 64);
+    auto t = PrecomputedOmegas::new_for_domain(F, d);
+    CHECK(t.omegas.size() == 64 && t.coset.size() == 64 && t.omegas_inv.size() == 32);
+    Fr w = F.one(), wi = F.one(), inv = F.inverse(d.generator);
+    for (size_t i = 0; i < 64; i++) {
+        CHECK(t.omegas[i] == w);
+        CHECK(t.coset[i] == F.mul(w, F.multiplicative_generator()));
+        if (i < 32) CHECK(t.omegas_inv[i] == wi);
+        w = F.mul(w, d.generator);
+        wi = F.mul(wi, inv);
+    }
+    CHECK(w == F.one());
+}
+
 int main()
 {
     Field F(BN256_FR, 7, 0);
     CHECK(F.S() == 32 && F.capacity() == 254);
     test_domain_errors(F);
     test_ragged_and_empty_inputs(F);
+    test_precomputed_omegas(F);
     test_fft_inverse_identity(F);
     test_lde_correctness(F);
     test_make_small_iop(F);

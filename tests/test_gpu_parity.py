@@ -119,6 +119,34 @@ def test_distribute_powers(gpu_ctxs, oracles, field_name, n):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("log_n", [0, 1, 5, 12])
+def test_precomputed_omegas_dev(gpu_ctxs, oracles, field_name, log_n):
+    """PrecomputedOmegas::new_for_domain (src/precomputations/mod.rs:14-66): w^i, g*w^i, w^-i (n/2)."""
+    import torch
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n = 1 << log_n
+    _, _, omega = O.domain(n)
+    one = O.one()
+    ones = np.array([[(one >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]] * n, dtype=np.uint64)
+    exp_w, exp_inv = ones.copy(), ones.copy()
+    O.distribute_powers(exp_w, omega)
+    O.distribute_powers(exp_inv, O.inverse(omega))
+    exp_c = exp_w.copy()
+    O.poly_unary(exp_c, "scale", c=O.const("generator"))
+    d_w = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d_c = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d_i = torch.zeros((max(n // 2, 1), 4), dtype=torch.int64, device="cuda")
+    ctx.precomputed_omegas_dev(log_n, d_w, d_c, d_i)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_w.cpu().numpy().view(np.uint64), exp_w)
+    assert np.array_equal(d_c.cpu().numpy().view(np.uint64), exp_c)
+    if n >= 2:
+        assert np.array_equal(d_i.cpu().numpy().view(np.uint64), exp_inv[: n // 2])
+    ctx.precomputed_omegas_dev(log_n, None, None, None)    # all outputs optional
+    with pytest.raises(Exception):
+        ctx.precomputed_omegas_dev(41, d_w)
+
+
 # ---------------------------------------------------------------- LDE
 @pytest.mark.parametrize("log_n,factor", [(0, 2), (2, 16), (3, 1), (4, 8), (8, 8), (10, 4), (12, 8), (13, 16)])
 def test_lde_matches_oracle_and_padded_fft(gpu_ctxs, oracles, field_name, log_n, factor):
