@@ -279,6 +279,115 @@ __global__ void k_alignbit2(uint64_t *out, uint32_t a, uint32_t b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+__global__ void k_xor_sdwa(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_rot16_sdwa(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_rot16_plain(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xor_b32 %0, %1, %2\n v_alignbit_b32 %0, %0, %0, 16" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_xad(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xad_u32 %0, %1, %2, %2" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_xor_dpp(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xor_b32_dpp %0, %1, %2 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_add_dpp(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 #define MUL_ITERS 256
 __global__ void k_frmul(uint64_t *out, FrParams P, uint32_t seed)
 {
@@ -415,6 +524,12 @@ int main()
     RUN("v_perm_b32", k_perm)
     RUN("v_and_b32", k_lshrrev64x)
     RUN("v_alignbit_b32", k_alignbit2)
+    RUN("v_xor_b32_sdwa", k_xor_sdwa)
+    RUN("rot16: 2x sdwa", k_rot16_sdwa)
+    RUN("rot16: xor+align", k_rot16_plain)
+    RUN("v_xad_u32", k_xad)
+    RUN("v_xor_b32_dpp", k_xor_dpp)
+    RUN("v_add_u32_dpp", k_add_dpp)
     FrParams P;
     // BLS12-381 Fr (the field in src/bn256.rs)
     const uint32_t p[8] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753};

@@ -43,7 +43,7 @@ EXPORTS = [
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev",
-    "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev",
+    "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_prototype",
 ]
 
 
@@ -204,6 +204,13 @@ class FriPrototype:
         meta = (u64(), u64(), u64())
         return dict(queries=queries, roots=roots, final_coeffs=final, initial_degree_plus_one=meta[0],
                     output_coeffs_at_degree_plus_one=meta[1], lde_factor=meta[2], raw=raw)
+
+    def verify_prototype(self, lde_values_dev, natural_index):
+        """NaiveFriIop::verify_prototype (src/fri/verifier.rs:10-129) -> bool."""
+        ok = C.c_int(0)
+        self.ctx._chk(self.ctx.L.hodor_fri_verify_prototype(self.h, _dptr(lde_values_dev), C.c_size_t(natural_index),
+                                                            C.byref(ok)))
+        return bool(ok.value)
 
     def free(self):
         if self.h:
@@ -463,6 +470,15 @@ class Context:
         p = lambda t: _dptr(t) if t is not None else C.c_void_p(None)
         self._chk(self.L.hodor_precomputed_omegas_dev(self.h, C.c_void_p(stream), C.c_uint32(log_n), p(omegas),
                                                       p(coset), p(omegas_inv)))
+
+    def fri_verify_proof(self, raw, natural_index, expected_value):
+        """NaiveFriIop::verify_proof_queries (src/fri/verifier.rs:131-289) over serialised proof bytes -> bool;
+        the reference's Err(..) cases raise HodorError.  Host-only."""
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        ev, ok = _fr(expected_value), C.c_int(0)
+        self._chk(self.L.hodor_fri_verify_proof(self.h, buf, C.c_size_t(len(raw)), C.c_size_t(natural_index),
+                                                C.byref(ev), C.byref(ok)))
+        return bool(ok.value)
 
     def poly_binary_dev(self, a, b, n, op, stream=None):
         self._chk(self.L.hodor_poly_binary_dev(self.h, C.c_void_p(stream), _dptr(a), _dptr(b), C.c_size_t(n),

@@ -3,6 +3,7 @@
 // context without a device refuses every compute call with HODOR_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -1301,6 +1302,194 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     put64(p->out_deg);
     put64(p->lde_factor);
     return o;
+}
+
+// NaiveFriIop::verify_proof_queries (src/fri/verifier.rs:131-289) over the serialised FRIProof that
+// hodor_fri_produce_proof writes.  Host-only (log n hashes and a handful of field operations per
+// round): works on a ctx without a device.  *valid = Ok(true/false); the reference's Err(..) cases
+// (point outside the LDE domain, query count not a multiple of DEGREE = 2, wrong tree index) and a
+// malformed buffer return HODOR_ERR_INVALID.
+extern "C" int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len,
+                                      size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
+                                      int *valid)
+{
+    if (!ctx || !proof || !expected_value_from_oracle || !valid) return HODOR_ERR_INVALID;
+    *valid = 0;
+    size_t o = 0;
+    bool bad = false;
+    auto get64 = [&]() -> uint64_t {
+        uint64_t v = 0;
+        if (o > len || len - o < 8) { bad = true; return 0; }
+        memcpy(&v, proof + o, 8);
+        o += 8;
+        return v;
+    };
+    auto take = [&](uint64_t count) -> const uint8_t * {   // count 32-byte entries
+        if (bad || count > (len - o) / 32) { bad = true; return nullptr; }
+        const uint8_t *r = proof + o;
+        o += (size_t)count * 32;
+        return r;
+    };
+    struct Query { uint64_t index; const uint8_t *value; uint64_t path_len; const uint8_t *path; };
+    uint64_t nq = get64();
+    if (bad || nq > len / 48) return HODOR_ERR_INVALID;
+    std::vector<Query> queries((size_t)nq);
+    for (auto &q : queries) {
+        q.index = get64();
+        q.value = take(1);
+        q.path_len = get64();
+        q.path = take(q.path_len);
+        if (bad) return HODOR_ERR_INVALID;
+    }
+    uint64_t n_roots = get64();
+    const uint8_t *roots = take(n_roots);
+    uint64_t n_final = get64();
+    const uint8_t *final_coeffs = take(n_final);
+    uint64_t initial_degree_plus_one = get64();
+    (void)get64();   // output_coeffs_at_degree_plus_one: carried by the proof, unused by the verifier
+    uint64_t lde_factor = get64();
+    if (bad || o != len) return HODOR_ERR_INVALID;
+
+    const HostField &F = ctx->F;
+    HFr two_inv, omega, omega_inv;
+    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_size;
+    if (lde_factor && initial_degree_plus_one > ~0ull / lde_factor) return HODOR_ERR_SIZE;
+    if (!F.domain(initial_degree_plus_one * lde_factor, &size, &log_size, &omega)) return HODOR_ERR_SIZE;
+    HFr x = F.pow(omega, natural_element_index);
+    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) return HODOR_ERR_INVALID;
+    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
+    if (queries.size() % 2 != 0) return HODOR_ERR_INVALID;
+
+    auto value_of = [&](const Query &q) { hodor_fr v; memcpy(v.l, q.value, 32); return to_h(&v); };
+    bool have_expected = false;
+    HFr expected = F.one;
+    uint64_t domain_size = size, domain_idx = natural_element_index;
+    const HFr oracle_value = to_h(expected_value_from_oracle);
+    const size_t rounds = std::min<size_t>((size_t)n_roots, queries.size() / 2);   // zip(roots, chunks_exact)
+    for (size_t rnd = 0; rnd < rounds; rnd++) {
+        if (domain_size < 2) return HODOR_ERR_INVALID;
+        const Query *qs = &queries[2 * rnd];
+        const uint8_t *root = roots + 32 * rnd;
+        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
+        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
+        for (int k = 0; k < 2; k++)
+            if (qs[k].index != coset[0] && qs[k].index != coset[1]) return HODOR_OK;          // Ok(false)
+        if (rnd == 0)
+            for (int k = 0; k < 2; k++)
+                if (qs[k].index == natural_element_index && !(value_of(qs[k]) == oracle_value)) return HODOR_OK;
+        for (int k = 0; k < 2; k++)
+            if (qs[k].index != coset[k]) return HODOR_ERR_INVALID;                            // "invalid tree index"
+        for (int k = 0; k < 2; k++) {
+            int ok = 0;
+            hodor_fr leaf;
+            memcpy(leaf.l, qs[k].value, 32);
+            hodor_iop_verify(ctx, root, &leaf, qs[k].path, (size_t)qs[k].path_len, (size_t)qs[k].index, &ok);
+            if (!ok) return HODOR_OK;
+        }
+        hodor_fr ch;
+        if (hodor_iop_challenge(ctx, root, &ch)) return HODOR_ERR_INVALID;
+        const HFr challenge = to_h(&ch);
+        const HFr f_at_omega = value_of(qs[0]), f_at_minus_omega = value_of(qs[1]);
+        if (have_expected) {
+            int hits = 0;
+            HFr supplied = F.one;
+            for (int k = 0; k < 2; k++)
+                if (qs[k].index == domain_idx) { hits++; supplied = value_of(qs[k]); }
+            if (hits != 1 || !(supplied == expected)) return HODOR_OK;
+        }
+        HFr divisor = F.pow(omega_inv, coset[0]);
+        HFr even = F.add(f_at_omega, f_at_minus_omega);
+        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
+        expected = F.mul(F.add(F.mul(odd, challenge), even), two_inv);
+        have_expected = true;
+        uint64_t next = domain_size / 2;                      // index_and_size_for_next_domain
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+        omega = F.sqr(omega);
+        omega_inv = F.sqr(omega_inv);
+    }
+    if (!have_expected) return HODOR_ERR_INVALID;             // expect("is some")
+    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
+    for (uint64_t i = 0; i < n_final; i++) {
+        hodor_fr c;
+        memcpy(c.l, final_coeffs + 32 * i, 32);
+        acc = F.add(acc, F.mul(power, to_h(&c)));
+        power = F.mul(power, point);
+    }
+    *valid = (acc == expected) ? 1 : 0;
+    return HODOR_OK;
+}
+
+// NaiveFriIop::verify_prototype (src/fri/verifier.rs:10-129): the same folding walk against the
+// prover's own (device-resident) vectors instead of Merkle queries — two elements per round are
+// fetched from the device.  `lde_values_dev` is the codeword the prototype was committed from.
+extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
+                                          size_t natural_element_index, int *valid)
+{
+    if (!p || !lde_values_dev || !valid) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = p->ctx;
+    NEED_DEVICE();
+    *valid = 0;
+    const HostField &F = ctx->F;
+    HFr two_inv, omega, omega_inv;
+    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_size;
+    if (!F.domain((uint64_t)p->initial_degree_plus_one * p->lde_factor, &size, &log_size, &omega))
+        return HODOR_ERR_SIZE;
+    HFr x = F.pow(omega, natural_element_index);
+    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) {
+        ctx->err = "initial challenge value is not in the LDE domain";
+        return HODOR_ERR_INVALID;
+    }
+    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    bool have_expected = false;
+    HFr expected = F.one;
+    uint64_t domain_size = size, domain_idx = natural_element_index;
+    auto fetch = [&](const hodor_fr *base, uint64_t i, HFr *out) -> bool {
+        hodor_fr v;
+        if (hipMemcpy(&v, base + i, 32, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        *out = to_h(&v);
+        return true;
+    };
+    // zip(leaf_values ++ intermediate_values, challenges): num_steps rounds
+    for (size_t rnd = 0; rnd < p->num_steps; rnd++) {
+        const hodor_fr *values = rnd == 0 ? lde_values_dev : (const hodor_fr *)p->inter_values[rnd - 1];
+        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
+        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
+        HFr f_at_omega, f_at_minus_omega;
+        if (!fetch(values, coset[0], &f_at_omega) || !fetch(values, coset[1], &f_at_minus_omega)) {
+            ctx->err = "verify_prototype: device read failed";
+            return HODOR_ERR_DEVICE;
+        }
+        if (have_expected) {
+            const HFr &supplied = domain_idx == coset[0] ? f_at_omega : f_at_minus_omega;
+            if (!(supplied == expected)) return HODOR_OK;     // Ok(false)
+        }
+        hodor_fr ch = p->challenges[rnd];
+        HFr divisor = F.pow(omega_inv, coset[0]);
+        HFr even = F.add(f_at_omega, f_at_minus_omega);
+        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
+        expected = F.mul(F.add(F.mul(odd, to_h(&ch)), even), two_inv);
+        have_expected = true;
+        uint64_t next = domain_size / 2;
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+        omega = F.sqr(omega);
+        omega_inv = F.sqr(omega_inv);
+    }
+    if (!have_expected) return HODOR_ERR_INVALID;
+    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
+    for (size_t i = 0; i < p->final_coeffs.size(); i++) {
+        hodor_fr c = p->final_coeffs[i];
+        acc = F.add(acc, F.mul(power, to_h(&c)));
+        power = F.mul(power, point);
+    }
+    *valid = (acc == expected) ? 1 : 0;
+    return HODOR_OK;
 }
 
 // ---- Blake2sTranscript (src/transcript/mod.rs:10-80): host-side, sequential, O(#roots) ----

@@ -339,8 +339,71 @@ struct FRIProofPrototype {
     }
 };
 
+// src/fri/mod.rs:139-147
+struct FRIProof {
+    std::vector<TrivialBlake2sIopQuery> queries;
+    std::vector<Hash32> roots;
+    std::vector<Fr> final_coefficients;
+    size_t initial_degree_plus_one, output_coeffs_at_degree_plus_one, lde_factor;
+
+    // the wire format of hodor_fri_produce_proof / hodor_fri_verify_proof (documented in csrc/abi.hip)
+    std::vector<uint8_t> to_bytes() const
+    {
+        std::vector<uint8_t> out;
+        auto put64 = [&](uint64_t v) { for (int b = 0; b < 8; b++) out.push_back((uint8_t)(v >> (8 * b))); };
+        auto put = [&](const void *p, size_t n) { out.insert(out.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+        put64(queries.size());
+        for (auto &q : queries) {
+            put64(q.index);
+            put(q.value_.l, 32);
+            put64(q.path_.size());
+            for (auto &h : q.path_) put(h.data(), 32);
+        }
+        put64(roots.size());
+        for (auto &r : roots) put(r.data(), 32);
+        put64(final_coefficients.size());
+        for (auto &c : final_coefficients) put(c.l, 32);
+        put64(initial_degree_plus_one);
+        put64(output_coeffs_at_degree_plus_one);
+        put64(lde_factor);
+        return out;
+    }
+};
+
+// FRIProofPrototype::produce_proof, src/fri/query_producer.rs:10-53 (host-resident prototype)
+inline FRIProof produce_proof(const FRIProofPrototype &p, const Polynomial<Values> &iop_values,
+                              size_t natural_first_element_index)
+{
+    FRIProof proof{{}, {}, p.final_coefficients, p.initial_degree_plus_one, p.output_coeffs_at_degree_plus_one,
+                   p.lde_factor};
+    size_t domain_size = p.initial_degree_plus_one * p.lde_factor, domain_idx = natural_first_element_index;
+    for (size_t r = 0; r <= p.intermediate_commitments.size(); r++) {
+        const TrivialBlake2sIOP &iop = r == 0 ? p.l0_commitment : p.intermediate_commitments[r - 1];
+        const std::vector<Fr> &leafs = r == 0 ? iop_values.coeffs : p.intermediate_values[r - 1].coeffs;
+        for (size_t idx : Domain::coset_for_natural_index_and_size(domain_idx, domain_size))
+            proof.queries.push_back(iop.query(idx, leafs));
+        proof.roots.push_back(iop.get_root());
+        auto nx = Domain::index_and_size_for_next_domain(domain_idx, domain_size);
+        domain_idx = nx.first;
+        domain_size = nx.second;
+    }
+    return proof;
+}
+
 // src/fri/mod.rs:63-104 + src/fri/fri_on_values.rs:11-159
 struct NaiveFriIop {
+    // FriIop::verify_proof -> verify_proof_queries (src/fri/mod.rs:96-102, src/fri/verifier.rs:131-289);
+    // Err(..) surfaces as SynthesisError
+    static bool verify_proof(const Field &F, const FRIProof &proof, size_t natural_element_index,
+                             const Fr &expected_value)
+    {
+        std::vector<uint8_t> raw = proof.to_bytes();
+        int ok = 0;
+        F.check(hodor_fri_verify_proof(F.ctx(), raw.data(), raw.size(), natural_element_index, &expected_value, &ok),
+                "verify_proof_queries");
+        return ok != 0;
+    }
+
     static FRIProofPrototype proof_from_lde(const Polynomial<Values> &lde_values, size_t lde_factor,
                                             size_t output_coeffs_at_degree_plus_one)
     {

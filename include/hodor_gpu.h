@@ -216,6 +216,15 @@ int hodor_iop_query_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, con
  * byte count; writes only when buf != NULL and cap is large enough; 0 on error. */
 size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
                                size_t natural_first_element_index, uint8_t *buf, size_t cap);
+/* NaiveFriIop::verify_proof_queries — src/fri/verifier.rs:131-289 (FriIop::verify_proof,
+ * src/fri/mod.rs:96-102) over the bytes hodor_fri_produce_proof wrote.  Host-only.  *valid = 1/0 for
+ * Ok(true)/Ok(false); the reference's Err(..) cases and a malformed buffer give HODOR_ERR_INVALID. */
+int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t natural_element_index,
+                           const hodor_fr *expected_value_from_oracle, int *valid);
+/* NaiveFriIop::verify_prototype — src/fri/verifier.rs:10-129: the folding walk against the prover's own
+ * device-resident vectors (two elements fetched per round).  *valid as above. */
+int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_dev, size_t natural_element_index,
+                               int *valid);
 /* FRI commit over a device-resident codeword; the prototype keeps its vectors/trees on the device */
 int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
                          size_t lde_factor, size_t output_coeffs_at_degree_plus_one,

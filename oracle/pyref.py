@@ -294,6 +294,42 @@ def bytes_to_challenge_index(b, lde_size, lde_factor):
     return idx
 
 
+# ------------------------------------------------------------------ FRI query phase
+def fri_produce_proof(F, proto, lde_values, natural_first_element_index, lde_factor, out_deg_plus_one):
+    """FRIProofPrototype::produce_proof, src/fri/query_producer.rs:10-53: for the l0 oracle and each
+    intermediate one, the two queries of the (sorted) coset of domain_idx; the index halves with the
+    domain.  `proto` = fri_commit(...) output, `lde_values` canonical ints.  Values are returned in
+    Montgomery form (the leaf bytes), like the device path does."""
+    domain_size, domain_idx = len(lde_values), natural_first_element_index
+    queries, roots = [], []
+    for r, vec in enumerate([lde_values] + proto["inter_values"]):
+        leafs = [F.to_mont(v) for v in vec]
+        nodes = iop_create(leafs)
+        pair = (domain_idx + domain_size // 2) % domain_size
+        for idx in sorted([domain_idx, pair]):
+            queries.append((idx, leafs[idx], iop_path(nodes, leafs, idx)))
+        roots.append(nodes[1])
+        nxt = domain_size // 2
+        domain_idx = domain_idx if domain_idx < nxt else domain_idx - nxt
+        domain_size = nxt
+    return dict(queries=queries, roots=roots, final_coeffs=[F.to_mont(c) for c in proto["final_coeffs"]],
+                initial_degree_plus_one=len(lde_values) // lde_factor,
+                output_coeffs_at_degree_plus_one=out_deg_plus_one, lde_factor=lde_factor)
+
+
+def fri_proof_to_bytes(proof):
+    """The FRIProof wire format this build defines (hodor_amd/csrc/abi.hip, hodor_fri_produce_proof)."""
+    u64 = lambda v: int(v).to_bytes(8, "little")
+    out = u64(len(proof["queries"]))
+    for idx, value, path in proof["queries"]:
+        out += u64(idx) + mont_to_bytes(value) + u64(len(path)) + b"".join(bytes(x) for x in path)
+    out += u64(len(proof["roots"])) + b"".join(bytes(r) for r in proof["roots"])
+    out += u64(len(proof["final_coeffs"])) + b"".join(mont_to_bytes(c) for c in proof["final_coeffs"])
+    out += u64(proof["initial_degree_plus_one"]) + u64(proof["output_coeffs_at_degree_plus_one"])
+    out += u64(proof["lde_factor"])
+    return out
+
+
 # ------------------------------------------------------------------ FRI verifier (acceptance oracle)
 def fri_verify_proof_queries(F, proof, natural_element_index, expected_value_from_oracle, degree=2):
     """NaiveFriIop::verify_proof_queries, src/fri/verifier.rs:131-289, restated line for line.

@@ -164,6 +164,32 @@ static void test_domain_errors(const Field &F)
     CHECK(nx.first == 5 && nx.second == 8);
 }
 
+// test_fib_fri_iop_verifier (src/fri/mod.rs:364-507): commit down to a constant, produce_proof, then
+// verify_proof with the right and a wrong expected value and with a corrupted query
+static void test_fri_proof_and_verifier(const Field &F)
+{
+    XorShiftRng rng;
+    std::vector<Fr> coeffs(64);
+    for (auto &v : coeffs) v = rand_fr(rng, BN256_FR, 1);
+    const size_t lde_factor = 8;
+    auto lde_values = lde(from_coeffs(F, coeffs), lde_factor);
+    auto proto = NaiveFriIop::proof_from_lde(lde_values, lde_factor, 1);
+    CHECK(proto.intermediate_values.size() == 6 && proto.final_coefficients.size() == 1);
+    for (size_t index : {size_t(1), size_t(77), lde_values.size() - 1}) {
+        FRIProof proof = produce_proof(proto, lde_values, index);
+        CHECK(proof.queries.size() == 2 * proof.roots.size() && proof.roots.size() == 7);
+        CHECK(NaiveFriIop::verify_proof(F, proof, index, lde_values.coeffs[index]));
+        CHECK(!NaiveFriIop::verify_proof(F, proof, index, F.add(lde_values.coeffs[index], F.one())));
+        FRIProof bad = proof;
+        bad.queries[3].value_ = F.add(bad.queries[3].value_, F.one());
+        CHECK(!NaiveFriIop::verify_proof(F, bad, index, lde_values.coeffs[index]));
+    }
+    bool threw = false;   // Err: a point of the half-size sub-domain
+    try { NaiveFriIop::verify_proof(F, produce_proof(proto, lde_values, 2), 2, lde_values.coeffs[2]); }
+    catch (const SynthesisError &) { threw = true; }
+    CHECK(threw);
+}
+
 // PrecomputedOmegas::new_for_domain (src/precomputations/mod.rs:14-66) against running products
 static void test_precomputed_omegas(const Field &F)
 {
@@ -192,6 +218,7 @@ int main()
     test_lde_correctness(F);
     test_make_small_iop(F);
     test_one_fri_step(F);
+    test_fri_proof_and_verifier(F);
     printf("host_cpp: all tests passed\n");
     return 0;
 }

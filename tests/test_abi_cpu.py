@@ -112,3 +112,56 @@ def test_transcript_matches_hashlib_restatement(F):
             b = bytes((k * 37 + i * 11) & 255 for i in range(32))
             assert ctx.bytes_to_challenge_index(b, lde_size, f) == P.bytes_to_challenge_index(b, lde_size, f)
     ctx.close()
+
+
+def test_fri_verifier_on_host_matches_restated_verifier():
+    """hodor_fri_verify_proof (verify_proof_queries, src/fri/verifier.rs:131-289) needs no device: feed it
+    proofs assembled by the Python restatement of the prover (fri_on_values.rs + query_producer.rs) and
+    compare verdicts with the restated verifier, valid and tampered."""
+    F = P.BN256
+    ctx = hodor_amd.Context(F.p, F.g, device=-1)
+    log_deg, f = 3, 4
+    coeffs = [pow(5, 77 + i, F.p) for i in range(1 << log_deg)]
+    lde = P.poly_lde(F, coeffs, f)
+    n = len(lde)
+    proto = P.fri_commit(F, lde, f, 1)
+    for index in (1, 7, n // 2 + 3, n - 1):
+        proof = P.fri_produce_proof(F, proto, lde, index, f, 1)
+        raw = P.fri_proof_to_bytes(proof)
+        expected = F.to_mont(lde[index])
+        assert P.fri_verify_proof_queries(F, proof, index, expected)
+        assert ctx.fri_verify_proof(raw, index, expected) is True
+        assert ctx.fri_verify_proof(raw, index, expected ^ 1) is False            # wrong value from the oracle
+        # tampering: a round-1 value, a path digest, a root, the final coefficient
+        def variant(mut):
+            bad = dict(proof, queries=list(proof["queries"]), roots=list(proof["roots"]),
+                       final_coeffs=list(proof["final_coeffs"]))
+            mut(bad)
+            return bad
+        def m_value(b): q = b["queries"][2]; b["queries"][2] = (q[0], q[1] ^ 2, q[2])
+        def m_path(b): q = b["queries"][1]; b["queries"][1] = (q[0], q[1], [bytes(32)] + list(q[2][1:]))
+        def m_root(b): b["roots"][1] = bytes(32)
+        def m_final(b): b["final_coeffs"][0] ^= 4
+        def m_swap(b): b["queries"][0], b["queries"][1] = b["queries"][1], b["queries"][0]
+        for mut in (m_value, m_path, m_root, m_final):
+            bad = variant(mut)
+            assert P.fri_verify_proof_queries(F, bad, index, expected) is False
+            assert ctx.fri_verify_proof(P.fri_proof_to_bytes(bad), index, expected) is False
+        # Err(..) cases: unsorted coset ("invalid tree index"), odd query count, malformed buffers
+        with pytest.raises(ValueError):
+            P.fri_verify_proof_queries(F, variant(m_swap), index, expected)
+        with pytest.raises(_lib.HodorError):
+            ctx.fri_verify_proof(P.fri_proof_to_bytes(variant(m_swap)), index, expected)
+        odd = variant(lambda b: b["queries"].pop())
+        with pytest.raises(_lib.HodorError):
+            ctx.fri_verify_proof(P.fri_proof_to_bytes(odd), index, expected)
+        for cut in (0, 7, 8, 100, len(raw) - 1):
+            with pytest.raises(_lib.HodorError):
+                ctx.fri_verify_proof(raw[:cut] if cut else b"\x00", index, expected)
+        with pytest.raises(_lib.HodorError):
+            ctx.fri_verify_proof(raw + b"\x00", index, expected)
+    # a point of the sub-domain of size n/2 is refused (Err: "not in the LDE domain")
+    proof = P.fri_produce_proof(F, proto, lde, 2, f, 1)
+    with pytest.raises(_lib.HodorError):
+        ctx.fri_verify_proof(P.fri_proof_to_bytes(proof), 2, F.to_mont(lde[2]))
+    ctx.close()

@@ -671,6 +671,12 @@ def test_fri_proof_accepted_by_restated_verifier(gpu_ctxs, oracles, log_deg, lde
         proof = proto.produce_proof(d_lde, index)
         assert P.fri_verify_proof_queries(F, proof, index, ints[index])
         assert not P.fri_verify_proof_queries(F, proof, index, ints[index] ^ 1)      # wrong expected value
+        # the library's own verifier (hodor_fri_verify_proof) and verify_prototype agree
+        assert ctx.fri_verify_proof(proof["raw"], index, ints[index]) is True
+        assert ctx.fri_verify_proof(proof["raw"], index, ints[index] ^ 1) is False
+        flipped = bytearray(proof["raw"]); flipped[8 + 8 + 3] ^= 1                   # first query's value
+        assert ctx.fri_verify_proof(bytes(flipped), index, ints[index]) is False
+        assert proto.verify_prototype(d_lde, index) is True
         bad = dict(proof)
         q = list(proof["queries"])
         q[2] = (q[2][0], q[2][1] ^ 2, q[2][2])                                        # corrupt a round-1 value
@@ -685,6 +691,17 @@ def test_fri_proof_accepted_by_restated_verifier(gpu_ctxs, oracles, log_deg, lde
         bad = dict(proof)
         bad["final_coeffs"] = [proof["final_coeffs"][0] ^ 4]
         assert not P.fri_verify_proof_queries(F, bad, index, ints[index])
+    # verify_prototype (src/fri/verifier.rs:10-129) reads the prover's vectors: a codeword element changed
+    # after the commit breaks the walk through its coset
+    saved = d_lde[3].clone()
+    d_lde[3, 0] ^= 1
+    torch.cuda.synchronize()
+    assert proto.verify_prototype(d_lde, 3) is False
+    d_lde[3] = saved
+    torch.cuda.synchronize()
+    assert proto.verify_prototype(d_lde, 3) is True
+    with pytest.raises(Exception):
+        proto.verify_prototype(d_lde, 2)           # Err: a point of the half-size sub-domain
     proto.free()
 
 
