@@ -40,6 +40,8 @@ hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, uint4 *
                             uint32_t shave_bits, const FrParams &);
 hipError_t fri_round_table_launch(hipStream_t, const uint4 *hi, uint4 *hi_out, uint64_t count,
                                   const uint4 *challenge, const Fr9 &c16, const Fr9Params &);
+hipError_t fri_tail_launch(hipStream_t, const FriTailArgs &, const Fr9 &c16, const Fr &r2, const B2Mid &,
+                           const Fr9Params &, const FrParams &);
 hipError_t fri_fold_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo,
                            const uint4 *hi_beta, uint32_t lo_bits, uint32_t log_stride, const Fr9Params &);
 
@@ -984,7 +986,32 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
 
     const uint4 *values = (const uint4 *)lde_values;
     size_t next_size = n / 2;
+    static int tail_on = -1;   // HODOR_FRI_TAIL=0: every round through the multi-launch path (A/B, debugging)
+    if (tail_on < 0) {
+        const char *e = getenv("HODOR_FRI_TAIL");
+        tail_on = e ? atoi(e) : 1;
+    }
     for (size_t i = 0; i < num_steps; i++) {                                                             // :61
+        if (tail_on && next_size <= (size_t)FRI_TAIL_THREADS && num_steps - i <= (size_t)FRI_TAIL_MAX_ROUNDS) {
+            FriTailArgs T = {};   // the remaining rounds fit one workgroup: one launch for all of them
+            T.src = values;
+            T.rounds = (uint32_t)(num_steps - i);
+            for (uint32_t k = 0; k < T.rounds; k++) {
+                T.values[k] = (uint4 *)p->inter_values[i + k];
+                T.nodes[k] = (uint4 *)p->inter_nodes[i + k];
+            }
+            T.chal = d_chal;
+            T.roots = d_roots;
+            T.lo = winv.lo;
+            T.hi = winv.hi;
+            T.lo_bits = winv.lo_bits;
+            T.first_round = (uint32_t)i;
+            T.half0 = (uint32_t)next_size;
+            T.shave = shave;
+            FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P));
+            values = (const uint4 *)p->inter_values[num_steps - 1];
+            break;
+        }
         void *next = p->inter_values[i], *nodes = p->inter_nodes[i];
         FRICHK(fri_round_table_launch(stream, winv.hi, d_hi_beta, hi_cnt, d_chal + 2 * i, c16, ctx->Q));
         FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits,
@@ -999,13 +1026,15 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
     if (rc) { fri_release(p); return rc; }
 
-    p->roots.resize(32 * (num_steps + 1));
-    p->challenges.resize(num_steps);
-    p->final_coeffs.resize(out_deg);
-    FRICHK(hipMemcpyAsync(p->roots.data(), d_roots, 32 * (num_steps + 1), hipMemcpyDeviceToHost, stream));
-    FRICHK(hipMemcpyAsync(p->challenges.data(), d_chal, 32 * num_steps, hipMemcpyDeviceToHost, stream));
-    FRICHK(hipMemcpyAsync(p->final_coeffs.data(), d_fin, 32 * out_deg, hipMemcpyDeviceToHost, stream));
+    // challenges | roots | final coefficients sit back to back in the slab's small block: one copy
+    std::vector<uint8_t> small(64 * (num_steps + 1) + 32 * out_deg);
+    FRICHK(hipMemcpyAsync(small.data(), d_small, small.size(), hipMemcpyDeviceToHost, stream));
     FRICHK(hipStreamSynchronize(stream));
+    p->roots.assign(small.begin() + 32 * (num_steps + 1), small.begin() + 64 * (num_steps + 1));
+    p->challenges.resize(num_steps);
+    memcpy(p->challenges.data(), small.data(), 32 * num_steps);
+    p->final_coeffs.resize(out_deg);
+    memcpy(p->final_coeffs.data(), small.data() + 64 * (num_steps + 1), 32 * out_deg);
     memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
 #undef FRICHK
     *out = p;

@@ -1,0 +1,93 @@
+// blake2s.cuh — device-side keyed BLAKE2s for the Merkle kernels (merkle.hip) and the fused FRI tail
+// (fri.hip).  Parameters as in /root/reference/src/iop/blake2s_trivial_iop.rs:8-16; the keyed first
+// block's chaining value (B2Mid) is precomputed on the host, so a leaf or node hash is ONE compression.
+// 32-bit ARX integer work: one hash per lane, 16 state + 16 message words in VGPRs, sigma schedule
+// resolved at compile time.
+#pragma once
+#include "fr.cuh"
+
+namespace hodor {
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n)
+{
+    return __builtin_rotateright32(x, n);
+}
+
+#define B2S_G(a, b, c, d, x, y)                                   \
+    do {                                                          \
+        a = a + b + (x); d = rotr32(d ^ a, 16);                   \
+        c = c + d;       b = rotr32(b ^ c, 12);                   \
+        a = a + b + (y); d = rotr32(d ^ a, 8);                    \
+        c = c + d;       b = rotr32(b ^ c, 7);                    \
+    } while (0)
+
+#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    do {                                                                                  \
+        B2S_G(v0, v4, v8, v12, m[s0], m[s1]);                                             \
+        B2S_G(v1, v5, v9, v13, m[s2], m[s3]);                                             \
+        B2S_G(v2, v6, v10, v14, m[s4], m[s5]);                                            \
+        B2S_G(v3, v7, v11, v15, m[s6], m[s7]);                                            \
+        B2S_G(v0, v5, v10, v15, m[s8], m[s9]);                                            \
+        B2S_G(v1, v6, v11, v12, m[s10], m[s11]);                                          \
+        B2S_G(v2, v7, v8, v13, m[s12], m[s13]);                                           \
+        B2S_G(v3, v4, v9, v14, m[s14], m[s15]);                                           \
+    } while (0)
+
+// One final-block compression on top of the key-block midstate.  `t` = total bytes incl. the
+// 64-byte key block (96 for a leaf, 128 for a node).
+__device__ __forceinline__ void b2s_final(const B2Mid &mid, const uint32_t m[16], uint32_t t,
+                                          uint32_t out[8])
+{
+    uint32_t v0 = mid.h[0], v1 = mid.h[1], v2 = mid.h[2], v3 = mid.h[3];
+    uint32_t v4 = mid.h[4], v5 = mid.h[5], v6 = mid.h[6], v7 = mid.h[7];
+    uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+    uint32_t v12 = 0x510E527Fu ^ t, v13 = 0x9B05688Cu, v14 = ~0x1F83D9ABu, v15 = 0x5BE0CD19u;
+    B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    B2S_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3);
+    B2S_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4);
+    B2S_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8);
+    B2S_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13);
+    B2S_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9);
+    B2S_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11);
+    B2S_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10);
+    B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5);
+    B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0);
+    out[0] = mid.h[0] ^ v0 ^ v8;  out[1] = mid.h[1] ^ v1 ^ v9;
+    out[2] = mid.h[2] ^ v2 ^ v10; out[3] = mid.h[3] ^ v3 ^ v11;
+    out[4] = mid.h[4] ^ v4 ^ v12; out[5] = mid.h[5] ^ v5 ^ v13;
+    out[6] = mid.h[6] ^ v6 ^ v14; out[7] = mid.h[7] ^ v7 ^ v15;
+}
+
+// hash of one 32-byte leaf (message words 8..15 are zero and fold away at compile time)
+__device__ __forceinline__ void b2s_leaf(const B2Mid &mid, const uint4 &lo, const uint4 &hi,
+                                         uint32_t out[8])
+{
+    uint32_t m[16] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0, 0, 0, 0, 0, 0, 0, 0};
+    b2s_final(mid, m, 96, out);
+}
+
+__device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], const uint32_t r[8],
+                                         uint32_t out[8])
+{
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { m[i] = l[i]; m[8 + i] = r[i]; }
+    b2s_final(mid, m, 128, out);
+}
+
+// interpret_hash (src/iop/blake2s_trivial_iop.rs:48-60): big-endian read of the digest words `d`,
+// clear the top 256 - CAPACITY bits, convert to Montgomery form (multiply by R^2).
+__device__ __forceinline__ Fr b2s_digest_to_challenge(const uint32_t d[8], const Fr &r2, uint32_t shave_bits,
+                                                      const FrParams &P)
+{
+    Fr x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x.v[i] = __builtin_bswap32(d[7 - i]);   // byte-reverse 32 bytes
+    uint32_t s = shave_bits & 63;   // the reference shifts a 64-bit mask by SHAVE_BITS % 64
+    uint64_t mask = ~0ull >> s;
+    x.v[7] &= (uint32_t)(mask >> 32);
+    x.v[6] &= (uint32_t)mask;
+    return fr_mul(x, r2, P);
+}
+
+}  // namespace hodor

@@ -12,6 +12,7 @@
 //   * (f[i] + f[i+half]) / 2 is an exact halving, not a multiplication;
 //   * arithmetic is the carry-free 9 x 29-bit form (fr9.cuh); beta is read from device memory, so
 //     the 23-round chain at 2^26 never synchronises with the host.
+#include "blake2s.cuh"
 #include "ntt.cuh"
 
 namespace hodor {
@@ -60,6 +61,78 @@ k_fri_fold(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo, const u
         Fr9 even = fr9_halve(fr9_add(a, b), Q);              // (a + b) / 2
         fr_store(dst + 2 * i, fr9_to_canonical(fr9_add(even, odd), Q));
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fri_tail: all remaining rounds of the commit loop once a round's output fits one workgroup
+// (<= 512 values).  Below that size a round is a chain of ~log2(size) + 3 dependent steps (fold,
+// leaf hashes, one compression per tree level, challenge) of a few microseconds each, and running
+// it as 4-5 launches per round costs more in launch-to-launch latency than in work.  One workgroup
+// walks the rounds back to back: the fold keeps its output in registers for the leaf hash, tree
+// levels hand over through LDS, and the challenge of round i reaches round i+1 through the
+// challenge array itself (same workgroup, barrier in between).  Everything the multi-launch path
+// writes (values, trees with nodes[0] = 0, roots, challenges) is written identically.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FRI_TAIL_THREADS)
+k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
+{
+    __shared__ uint4 buf_a[2 * FRI_TAIL_THREADS];         // leaf hashes, then every other level
+    __shared__ uint4 buf_b[FRI_TAIL_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lo_mask = (1ull << A.lo_bits) - 1;
+    const uint4 *src = A.src;
+    for (uint32_t k = 0; k < A.rounds; k++) {
+        const uint32_t h = A.half0 >> k, gi = A.first_round + k;
+        uint4 *dst = A.values[k], *nodes = A.nodes[k];
+        if (tid < h) {
+            // fold (fri_on_values.rs:77-100), same arithmetic as k_fri_round_table + k_fri_fold
+            Fr9 b16 = fr9_mul(fr9_unpack(fr_load(A.chal + 2 * gi)), c16, Q);
+            Fr9 a = fr9_unpack(fr_load(src + 2 * tid)), b = fr9_unpack(fr_load(src + 2 * (tid + h)));
+            uint64_t e = (uint64_t)tid << gi;
+            Fr9 tw = fr9_load48(A.hi + 3 * (e >> A.lo_bits));
+            if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(A.lo + 3 * (e & lo_mask)), Q);
+            tw = fr9_mul(b16, tw, Q);                            // w^-e * beta / 2, R'-form
+            Fr9 odd = fr9_mul(fr9_sub(a, b, Q), tw, Q);
+            Fr9 even = fr9_halve(fr9_add(a, b), Q);
+            Fr y = fr9_to_canonical(fr9_add(even, odd), Q);
+            fr_store(dst + 2 * tid, y);
+            uint32_t out[8];
+            b2s_leaf(mid, make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]), make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]),
+                     out);
+            buf_a[2 * tid] = make_uint4(out[0], out[1], out[2], out[3]);
+            buf_a[2 * tid + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+        }
+        __syncthreads();
+        uint4 *s = buf_a, *d = buf_b;
+        for (uint32_t w = h >> 1; w >= 1; w >>= 1) {             // level of width w at nodes[w .. 2w)
+            if (tid < w) {
+                uint4 a0 = s[4 * tid], a1 = s[4 * tid + 1], b0 = s[4 * tid + 2], b1 = s[4 * tid + 3];
+                uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                uint32_t out[8];
+                b2s_node(mid, l, r, out);
+                uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
+                nodes[2 * (w + tid)] = o0; nodes[2 * (w + tid) + 1] = o1;
+                d[2 * tid] = o0; d[2 * tid + 1] = o1;
+                if (w == 1) {                                    // the root: challenge of the next round
+                    nodes[0] = make_uint4(0, 0, 0, 0);
+                    nodes[1] = make_uint4(0, 0, 0, 0);
+                    A.roots[2 * (gi + 1)] = o0; A.roots[2 * (gi + 1) + 1] = o1;
+                    fr_store(A.chal + 2 * (gi + 1), b2s_digest_to_challenge(out, r2, A.shave, P));
+                }
+            }
+            __syncthreads();
+            uint4 *t = s; s = d; d = t;
+        }
+        src = dst;
+    }
+}
+
+hipError_t fri_tail_launch(hipStream_t s, const FriTailArgs &A, const Fr9 &c16, const Fr &r2, const B2Mid &mid,
+                           const Fr9Params &Q, const FrParams &P)
+{
+    hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P);
+    return hipGetLastError();
 }
 
 hipError_t fri_round_table_launch(hipStream_t s, const uint4 *hi, uint4 *hi_out, uint64_t count,

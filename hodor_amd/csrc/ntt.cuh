@@ -38,4 +38,22 @@ struct PassArgs {
     uint32_t dbg;            // profiling only (HODOR_DBG): 1 skip butterflies, 2 skip twiddles, 4 skip loads, 8 skip stores
 };
 
+// Arguments of the fused FRI tail (fri.hip, k_fri_tail): the rounds whose output is <= FRI_TAIL_THREADS
+// values, run by one workgroup.
+constexpr int FRI_TAIL_THREADS = 512;
+constexpr int FRI_TAIL_MAX_ROUNDS = 10;
+struct FriTailArgs {
+    const uint4 *src;                       // values entering the first fused round (2 * half0 elements)
+    uint4 *values[FRI_TAIL_MAX_ROUNDS];     // output of fused round k: half0 >> k elements
+    uint4 *nodes[FRI_TAIL_MAX_ROUNDS];      // tree over values[k]
+    uint4 *chal;                            // challenges: entry i enters round i; round i's tree writes entry i + 1
+    uint4 *roots;                           // roots: round i's tree writes entry i + 1
+    const uint4 *lo, *hi;                   // two-level table of w^-1 of the initial domain (R'-form)
+    uint32_t lo_bits;
+    uint32_t rounds;                        // number of fused rounds
+    uint32_t first_round;                   // index i of the first fused round
+    uint32_t half0;                         // outputs of the first fused round (power of two, 2 .. FRI_TAIL_THREADS)
+    uint32_t shave;                         // 256 - CAPACITY
+};
+
 }  // namespace hodor
