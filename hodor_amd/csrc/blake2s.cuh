@@ -75,6 +75,75 @@ __device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], 
     b2s_final(mid, m, 128, out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Quad-lane compression: FOUR lanes share one hash.  Lane j of a quad holds column j of the 4 x 4
+// state (a_j, b_j, c_j, d_j), so a round is two G's per lane instead of eight and the dependent
+// instruction chain of a compression shrinks ~3.3x.  The diagonal step reads rows b, c, d from the
+// neighbouring lanes with DPP quad permutes.  It costs more instructions in total (message words are
+// fetched per lane from LDS, state rotations), so it is for the narrow levels at the top of a tree and
+// for small trees, where lanes are idle and the tree's depth — one compression latency per level — is
+// what the commit waits for.  All four lanes of a quad must be active.
+// ---------------------------------------------------------------------------------------------
+struct B2Quad {
+    uint32_t off[40];                     // byte offset, in use order, of the message words this lane feeds to G
+    uint32_t a0, b0, c0, d0_leaf, d0_node;   // this lane's column of the initial state (t = 96 / 128, final block)
+};
+
+__device__ __forceinline__ uint32_t b2q_pick(uint32_t j, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+    return j == 0 ? x0 : (j == 1 ? x1 : (j == 2 ? x2 : x3));
+}
+
+__device__ __forceinline__ void b2q_init(B2Quad &q, const B2Mid &mid, uint32_t j /* lane & 3 */)
+{
+    constexpr uint8_t S[10][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // i = 0,1: column step (words 2j, 2j+1 of the schedule); i = 2,3: diagonal step (8+2j, 9+2j)
+            const int base = (i < 2 ? 0 : 8) + (i & 1);
+            q.off[4 * r + i] = b2q_pick(j, 4u * S[r][base], 4u * S[r][base + 2], 4u * S[r][base + 4], 4u * S[r][base + 6]);
+        }
+    }
+    q.a0 = b2q_pick(j, mid.h[0], mid.h[1], mid.h[2], mid.h[3]);
+    q.b0 = b2q_pick(j, mid.h[4], mid.h[5], mid.h[6], mid.h[7]);
+    q.c0 = b2q_pick(j, 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+    q.d0_leaf = b2q_pick(j, 0x510E527Fu ^ 96u, 0x9B05688Cu, ~0x1F83D9ABu, 0x5BE0CD19u);
+    q.d0_node = b2q_pick(j, 0x510E527Fu ^ 128u, 0x9B05688Cu, ~0x1F83D9ABu, 0x5BE0CD19u);
+}
+
+#define B2Q_DPP(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, 0xf, true))
+
+// `msg`: the 64-byte message block in LDS (the same address in the four lanes).  Returns this lane's
+// two digest words: h_lo = word j, h_hi = word 4 + j.
+__device__ __forceinline__ void b2q_compress(const B2Quad &q, const uint32_t *msg, bool node, uint32_t &h_lo,
+                                             uint32_t &h_hi)
+{
+    uint32_t m[40];
+#pragma unroll
+    for (int i = 0; i < 40; i++)
+        m[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(msg) + q.off[i]);
+    uint32_t a = q.a0, b = q.b0, c = q.c0, d = node ? q.d0_node : q.d0_leaf;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        if (r) {   // back from the diagonal layout: column j's b, c, d sit in lanes j+3, j+2, j+1
+            b = B2Q_DPP(b, 0x93); c = B2Q_DPP(c, 0x4E); d = B2Q_DPP(d, 0x39);
+        }
+        B2S_G(a, b, c, d, m[4 * r], m[4 * r + 1]);
+        b = B2Q_DPP(b, 0x39); c = B2Q_DPP(c, 0x4E); d = B2Q_DPP(d, 0x93);   // lane j: b_(j+1), c_(j+2), d_(j+3)
+        B2S_G(a, b, c, d, m[4 * r + 2], m[4 * r + 3]);
+    }
+    b = B2Q_DPP(b, 0x93); c = B2Q_DPP(c, 0x4E); d = B2Q_DPP(d, 0x39);
+    h_lo = q.a0 ^ a ^ c;
+    h_hi = q.b0 ^ b ^ d;
+}
+
 // interpret_hash (src/iop/blake2s_trivial_iop.rs:48-60): big-endian read of the digest words `d`,
 // clear the top 256 - CAPACITY bits, convert to Montgomery form (multiply by R^2).
 __device__ __forceinline__ Fr b2s_digest_to_challenge(const uint32_t d[8], const Fr &r2, uint32_t shave_bits,

@@ -76,14 +76,19 @@ k_fri_fold(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo, const u
 __global__ void __launch_bounds__(FRI_TAIL_THREADS)
 k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
 {
-    __shared__ uint4 buf_a[2 * FRI_TAIL_THREADS];         // leaf hashes, then every other level
+    constexpr uint32_t QUADS = FRI_TAIL_THREADS / 4;       // hashes per pass in quad-lane mode
+    __shared__ uint4 buf_a[2 * FRI_TAIL_THREADS];          // leaf hashes, then every other level
     __shared__ uint4 buf_b[FRI_TAIL_THREADS];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint4 buf_m[4 * QUADS];                     // leaf message blocks (value | zeros) for quad mode
+    const uint32_t tid = threadIdx.x, quad = tid >> 2, j = tid & 3;
     const uint64_t lo_mask = (1ull << A.lo_bits) - 1;
+    B2Quad bq;
+    b2q_init(bq, mid, j);
     const uint4 *src = A.src;
     for (uint32_t k = 0; k < A.rounds; k++) {
         const uint32_t h = A.half0 >> k, gi = A.first_round + k;
         uint4 *dst = A.values[k], *nodes = A.nodes[k];
+        const bool quad_leafs = h <= QUADS;
         if (tid < h) {
             // fold (fri_on_values.rs:77-100), same arithmetic as k_fri_round_table + k_fri_fold
             Fr9 b16 = fr9_mul(fr9_unpack(fr_load(A.chal + 2 * gi)), c16, Q);
@@ -96,16 +101,39 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
             Fr9 even = fr9_halve(fr9_add(a, b), Q);
             Fr y = fr9_to_canonical(fr9_add(even, odd), Q);
             fr_store(dst + 2 * tid, y);
-            uint32_t out[8];
-            b2s_leaf(mid, make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]), make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]),
-                     out);
-            buf_a[2 * tid] = make_uint4(out[0], out[1], out[2], out[3]);
-            buf_a[2 * tid + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+            const uint4 y0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]), y1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+            if (quad_leafs) {
+                buf_m[4 * tid] = y0; buf_m[4 * tid + 1] = y1;
+                buf_m[4 * tid + 2] = make_uint4(0, 0, 0, 0); buf_m[4 * tid + 3] = make_uint4(0, 0, 0, 0);
+            } else {
+                uint32_t out[8];
+                b2s_leaf(mid, y0, y1, out);
+                buf_a[2 * tid] = make_uint4(out[0], out[1], out[2], out[3]);
+                buf_a[2 * tid + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+            }
         }
         __syncthreads();
+        if (quad_leafs) {
+            if (quad < h) {
+                uint32_t lo, hi;
+                b2q_compress(bq, reinterpret_cast<const uint32_t *>(buf_m + 4 * quad), false, lo, hi);
+                uint32_t *o = reinterpret_cast<uint32_t *>(buf_a + 2 * quad);
+                o[j] = lo; o[4 + j] = hi;
+            }
+            __syncthreads();
+        }
         uint4 *s = buf_a, *d = buf_b;
         for (uint32_t w = h >> 1; w >= 1; w >>= 1) {             // level of width w at nodes[w .. 2w)
-            if (tid < w) {
+            if (w <= QUADS) {
+                if (quad < w) {
+                    uint32_t lo, hi;
+                    b2q_compress(bq, reinterpret_cast<const uint32_t *>(s + 4 * quad), true, lo, hi);
+                    uint32_t *o = reinterpret_cast<uint32_t *>(d + 2 * quad);
+                    o[j] = lo; o[4 + j] = hi;
+                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes + 2 * (w + quad));
+                    g[j] = lo; g[4 + j] = hi;
+                }
+            } else if (tid < w) {
                 uint4 a0 = s[4 * tid], a1 = s[4 * tid + 1], b0 = s[4 * tid + 2], b1 = s[4 * tid + 3];
                 uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -114,16 +142,19 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
                 uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
                 nodes[2 * (w + tid)] = o0; nodes[2 * (w + tid) + 1] = o1;
                 d[2 * tid] = o0; d[2 * tid + 1] = o1;
-                if (w == 1) {                                    // the root: challenge of the next round
-                    nodes[0] = make_uint4(0, 0, 0, 0);
-                    nodes[1] = make_uint4(0, 0, 0, 0);
-                    A.roots[2 * (gi + 1)] = o0; A.roots[2 * (gi + 1) + 1] = o1;
-                    fr_store(A.chal + 2 * (gi + 1), b2s_digest_to_challenge(out, r2, A.shave, P));
-                }
             }
             __syncthreads();
             uint4 *t = s; s = d; d = t;
         }
+        if (tid == 0) {                                          // s[0..1] = the root: challenge of the next round
+            uint4 o0 = s[0], o1 = s[1];
+            uint32_t out[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            nodes[0] = make_uint4(0, 0, 0, 0);
+            nodes[1] = make_uint4(0, 0, 0, 0);
+            A.roots[2 * (gi + 1)] = o0; A.roots[2 * (gi + 1) + 1] = o1;
+            fr_store(A.chal + 2 * (gi + 1), b2s_digest_to_challenge(out, r2, A.shave, P));
+        }
+        __syncthreads();
         src = dst;
     }
 }

@@ -26,17 +26,24 @@ namespace hodor {
 // k_merkle_subtree: one workgroup builds the complete subtree over a chunk of CH = 2^log_ch inputs
 // (leaves when LEAF, digests of tree level `m` otherwise): every level of the chunk is written to its
 // place in the heap array and handed to the next level through LDS, so each leaf / digest is read
-// from HBM once and a 2^25-leaf tree takes 3 launches instead of 17.
+// from HBM once and a 2^25-leaf tree takes 4 launches instead of 25.
 //
 //   level k of the chunk (k = 1 .. log_ch) has CH >> k nodes at nodes[(m >> k) + chunk*(CH >> k) ..)
 //
-// Phase 0 pairs two adjacent inputs per lane (64 contiguous bytes; a wave reads 4 KiB contiguous);
-// later levels re-map the surviving nodes densely onto the lanes, so the waves stay full until the
-// level is narrower than the workgroup.
+// Two schedules:
+//   throughput (LAT = false, big levels): 2048 inputs per workgroup; phase 0 pairs two adjacent inputs
+//     per lane (64 contiguous bytes; a wave reads 4 KiB contiguous) and hashes leaf, leaf, node in one
+//     go; later levels re-map the surviving nodes densely onto the lanes.  The launcher stops a chunk
+//     before its levels get narrower than a wave.
+//   latency (LAT = true, levels that cannot fill the chip anyway): <= 256 inputs per workgroup, one
+//     input per lane first (a leaf hash, or a plain copy into LDS), then one tree level per step with
+//     the quad-lane compression (blake2s.cuh) as soon as a level has fewer nodes than the workgroup
+//     has quads — the commit waits for depth x compression latency here, not for throughput.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t MERKLE_LOG_CH = 11;   // 2048 inputs per workgroup: 32 KiB + 16 KiB of LDS
+constexpr uint32_t MERKLE_LOG_CH = 11;       // throughput: 2048 inputs per workgroup, 32 KiB + 16 KiB of LDS
+constexpr uint32_t MERKLE_LAT_LOG_CH = 8;    // latency: 256 inputs per workgroup
 
-template <bool LEAF>
+template <bool LEAF, bool LAT>
 __global__ void __launch_bounds__(256)
 k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint32_t levels, uint64_t n,
                  B2Mid mid)
@@ -44,47 +51,80 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
     // blockIdx.y selects one of several independent trees over n leaves each (batched commit)
     leafs += 2 * (uint64_t)blockIdx.y * n;
     nodes += 2 * (uint64_t)blockIdx.y * n;
-    __shared__ uint4 buf_a[2 * (1u << (MERKLE_LOG_CH - 1))];   // up to 1024 digests
-    __shared__ uint4 buf_b[2 * (1u << (MERKLE_LOG_CH - 2))];   // up to 512 digests
-    const uint32_t tid = threadIdx.x;
+    // throughput: level 1 (1024 digests) | level 2 (512); latency: the inputs (256 digests) | level 1 (128)
+    constexpr uint32_t CAP_A = LAT ? (1u << MERKLE_LAT_LOG_CH) : (1u << (MERKLE_LOG_CH - 1));
+    __shared__ uint4 buf_a[2 * CAP_A];
+    __shared__ uint4 buf_b[CAP_A];
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t ch = 1u << log_ch;
     const uint64_t chunk = blockIdx.x;
-
-    // level 1: pairs of inputs
     const uint4 *in = LEAF ? leafs + 2 * (chunk << log_ch) : nodes + 2 * (m + (chunk << log_ch));
-    uint4 *lvl_out = nodes + 2 * ((m >> 1) + chunk * (ch >> 1));
-    for (uint32_t p = tid; p < (ch >> 1); p += 256) {
-        const uint4 *q = in + 4 * p;
-        uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
-        uint32_t l[8], r[8], out[8];
-        if (LEAF) {
-            b2s_leaf(mid, a0, a1, l);
-            b2s_leaf(mid, b0, b1, r);
-        } else {
-            l[0] = a0.x; l[1] = a0.y; l[2] = a0.z; l[3] = a0.w; l[4] = a1.x; l[5] = a1.y; l[6] = a1.z; l[7] = a1.w;
-            r[0] = b0.x; r[1] = b0.y; r[2] = b0.z; r[3] = b0.w; r[4] = b1.x; r[5] = b1.y; r[6] = b1.z; r[7] = b1.w;
+    uint4 *src = buf_a, *dst = buf_b;
+    uint32_t k0;
+
+    if (LAT) {
+        // one input per lane into LDS: leaf hash (LEAF) or the digest itself
+        for (uint32_t p = tid; p < ch; p += nthreads) {
+            uint4 a0 = in[2 * p], a1 = in[2 * p + 1];
+            if (LEAF) {
+                uint32_t out[8];
+                b2s_leaf(mid, a0, a1, out);
+                a0 = make_uint4(out[0], out[1], out[2], out[3]);
+                a1 = make_uint4(out[4], out[5], out[6], out[7]);
+            }
+            buf_a[2 * p] = a0; buf_a[2 * p + 1] = a1;
         }
-        b2s_node(mid, l, r, out);
-        uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
-        lvl_out[2 * p] = o0; lvl_out[2 * p + 1] = o1;
-        buf_a[2 * p] = o0; buf_a[2 * p + 1] = o1;
+        k0 = 1;
+    } else {
+        // level 1: pairs of inputs
+        uint4 *lvl_out = nodes + 2 * ((m >> 1) + chunk * (ch >> 1));
+        for (uint32_t p = tid; p < (ch >> 1); p += nthreads) {
+            const uint4 *q = in + 4 * p;
+            uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
+            uint32_t l[8], r[8], out[8];
+            if (LEAF) {
+                b2s_leaf(mid, a0, a1, l);
+                b2s_leaf(mid, b0, b1, r);
+            } else {
+                l[0] = a0.x; l[1] = a0.y; l[2] = a0.z; l[3] = a0.w; l[4] = a1.x; l[5] = a1.y; l[6] = a1.z; l[7] = a1.w;
+                r[0] = b0.x; r[1] = b0.y; r[2] = b0.z; r[3] = b0.w; r[4] = b1.x; r[5] = b1.y; r[6] = b1.z; r[7] = b1.w;
+            }
+            b2s_node(mid, l, r, out);
+            uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
+            lvl_out[2 * p] = o0; lvl_out[2 * p + 1] = o1;
+            buf_a[2 * p] = o0; buf_a[2 * p + 1] = o1;
+        }
+        k0 = 2;
     }
     __syncthreads();
 
-    // levels 2 .. log_ch: ping-pong between the two LDS buffers
-    uint4 *src = buf_a, *dst = buf_b;
-    for (uint32_t k = 2; k <= levels; k++) {
+    B2Quad bq;
+    if (LAT) b2q_init(bq, mid, tid & 3);
+    // remaining levels: ping-pong between the two LDS buffers
+    for (uint32_t k = k0; k <= levels; k++) {
         const uint32_t w = ch >> k;
-        lvl_out = nodes + 2 * ((m >> k) + chunk * w);
-        for (uint32_t g = tid; g < w; g += 256) {
-            uint4 a0 = src[4 * g], a1 = src[4 * g + 1], b0 = src[4 * g + 2], b1 = src[4 * g + 3];
-            uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            uint32_t out[8];
-            b2s_node(mid, l, r, out);
-            uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
-            lvl_out[2 * g] = o0; lvl_out[2 * g + 1] = o1;
-            dst[2 * g] = o0; dst[2 * g + 1] = o1;
+        uint4 *lvl_out = nodes + 2 * ((m >> k) + chunk * w);
+        if (LAT && 4 * w <= nthreads) {
+            const uint32_t quad = tid >> 2, j = tid & 3;
+            if (quad < w) {
+                uint32_t lo, hi;
+                b2q_compress(bq, reinterpret_cast<const uint32_t *>(src + 4 * quad), true, lo, hi);
+                uint32_t *o = reinterpret_cast<uint32_t *>(dst + 2 * quad);
+                o[j] = lo; o[4 + j] = hi;
+                uint32_t *g = reinterpret_cast<uint32_t *>(lvl_out + 2 * quad);
+                g[j] = lo; g[4 + j] = hi;
+            }
+        } else {
+            for (uint32_t g = tid; g < w; g += nthreads) {
+                uint4 a0 = src[4 * g], a1 = src[4 * g + 1], b0 = src[4 * g + 2], b1 = src[4 * g + 3];
+                uint32_t l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                uint32_t r[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                uint32_t out[8];
+                b2s_node(mid, l, r, out);
+                uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
+                lvl_out[2 * g] = o0; lvl_out[2 * g + 1] = o1;
+                dst[2 * g] = o0; dst[2 * g + 1] = o1;
+            }
         }
         __syncthreads();
         uint4 *t = src; src = dst; dst = t;
@@ -156,28 +196,41 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
                                const B2Mid &mid, uint32_t batch)
 {
     // n >= 2, power of two (checked by the caller); `batch` trees back to back
+    static int tail_log = -1, lat_log = -1;
+    if (tail_log < 0) {
+        const char *e = getenv("HODOR_MERKLE_TAIL_LOG");
+        tail_log = e ? atoi(e) : 6;
+        e = getenv("HODOR_MERKLE_LAT_LOG");
+        lat_log = e ? atoi(e) : 19;
+    }
     uint64_t m = n;
     bool first = true;
     while (m > 1) {
-        uint32_t log_ch = 0;
-        while ((1ull << (log_ch + 1)) <= m && log_ch + 1 <= MERKLE_LOG_CH) log_ch++;
+        uint32_t log_m = 0;
+        while ((1ull << (log_m + 1)) <= m) log_m++;
+        // levels of at most 2^lat_log inputs (per tree) cannot fill the chip: latency schedule
+        const bool lat = log_m <= (uint32_t)lat_log;
+        uint32_t log_ch = log_m < (lat ? MERKLE_LAT_LOG_CH : MERKLE_LOG_CH) ? log_m : (lat ? MERKLE_LAT_LOG_CH : MERKLE_LOG_CH);
         uint64_t chunks = m >> log_ch;
         // A chunk's last levels are narrower than a wave: each is one compression's latency with the
-        // rest of the workgroup idle.  When many chunks follow anyway, stop at level width `tail_w`
+        // rest of the workgroup idle.  When many chunks follow anyway, stop at level width 2^tail_log
         // and let the next launch (whose chunks are again full) pick the survivors up.
-        static int tail_log = -1;
-        if (tail_log < 0) {
-            const char *e = getenv("HODOR_MERKLE_TAIL_LOG");
-            tail_log = e ? atoi(e) : 6;
-        }
         uint32_t levels = log_ch;
-        if (chunks >= 512 && log_ch > (uint32_t)tail_log) levels = log_ch - (uint32_t)tail_log;
-        if (first)
-            hipLaunchKernelGGL(k_merkle_subtree<true>, dim3((unsigned)chunks, batch), dim3(256), 0, s, leafs, nodes,
-                               m, log_ch, levels, n, mid);
+        if (!lat && chunks >= 512 && log_ch > (uint32_t)tail_log) levels = log_ch - (uint32_t)tail_log;
+        unsigned threads = 256;
+        if (lat) {   // one lane per input, at least one wave
+            threads = 1u << log_ch;
+            if (threads < 64) threads = 64;
+        }
+        dim3 grid((unsigned)chunks, batch);
+        if (first && lat)
+            hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
+        else if (first)
+            hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
+        else if (lat)
+            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
         else
-            hipLaunchKernelGGL(k_merkle_subtree<false>, dim3((unsigned)chunks, batch), dim3(256), 0, s, leafs, nodes,
-                               m, log_ch, levels, n, mid);
+            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
         m >>= levels;
         first = false;
     }
