@@ -33,17 +33,18 @@ hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr 
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
                               const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
 hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &,
-                               uint32_t batch = 1);
+                               uint32_t batch = 1, const FoldArgs *fold = nullptr, const Fr9Params *Q = nullptr);
+bool merkle_fuses_fold(uint64_t n);
 hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &);
 hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, uint4 *root_out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &);
-hipError_t fri_round_table_launch(hipStream_t, const uint4 *hi, uint4 *hi_out, uint64_t count,
-                                  const uint4 *challenge, const Fr9 &c16, const Fr9Params &);
+hipError_t fri_round_table_launch(hipStream_t, const uint4 *nodes, uint4 *chal_out, uint4 *root_out,
+                                  const uint4 *hi, uint4 *hi_out, uint64_t count, const Fr9 &c16, const Fr &r2,
+                                  uint32_t shave, const Fr9Params &, const FrParams &);
 hipError_t fri_tail_launch(hipStream_t, const FriTailArgs &, const Fr9 &c16, const Fr &r2, const B2Mid &,
                            const Fr9Params &, const FrParams &);
-hipError_t fri_fold_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo,
-                           const uint4 *hi_beta, uint32_t lo_bits, uint32_t log_stride, const Fr9Params &);
+hipError_t fri_fold_launch(hipStream_t, const FoldArgs &, const Fr9Params &);
 
 static Fr to_dev(const HFr &a)
 {
@@ -982,7 +983,6 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     Fr r2 = to_dev(ctx->F.r2);
 
     FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
-    FRICHK(challenge_launch(stream, (const uint4 *)p->l0_nodes, d_chal, d_roots, r2, shave, ctx->P));    // :51
 
     const uint4 *values = (const uint4 *)lde_values;
     size_t next_size = n / 2;
@@ -991,9 +991,13 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
         const char *e = getenv("HODOR_FRI_TAIL");
         tail_on = e ? atoi(e) : 1;
     }
+    // the challenge of round i (:51, :109) is derived from tree i-1 at the start of round i
+    const uint4 *prev_nodes = (const uint4 *)p->l0_nodes;
+    bool tail_done = false;
     for (size_t i = 0; i < num_steps; i++) {                                                             // :61
         if (tail_on && next_size <= (size_t)FRI_TAIL_THREADS && num_steps - i <= (size_t)FRI_TAIL_MAX_ROUNDS) {
             FriTailArgs T = {};   // the remaining rounds fit one workgroup: one launch for all of them
+            FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, r2, shave, ctx->P));
             T.src = values;
             T.rounds = (uint32_t)(num_steps - i);
             for (uint32_t k = 0; k < T.rounds; k++) {
@@ -1010,18 +1014,23 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
             T.shave = shave;
             FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P));
             values = (const uint4 *)p->inter_values[num_steps - 1];
+            tail_done = true;
             break;
         }
         void *next = p->inter_values[i], *nodes = p->inter_nodes[i];
-        FRICHK(fri_round_table_launch(stream, winv.hi, d_hi_beta, hi_cnt, d_chal + 2 * i, c16, ctx->Q));
-        FRICHK(fri_fold_launch(stream, values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits,
-                               (uint32_t)i, ctx->Q));                                                    // :70-104
-        FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid));   // :106
-        FRICHK(challenge_launch(stream, (const uint4 *)nodes, d_chal + 2 * (i + 1), d_roots + 2 * (i + 1), r2,
-                                shave, ctx->P));
+        FRICHK(fri_round_table_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, winv.hi, d_hi_beta, hi_cnt,
+                                      c16, r2, shave, ctx->Q, ctx->P));
+        FoldArgs fold = {values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits, (uint32_t)i};
+        const bool fused = merkle_fuses_fold(next_size);   // small rounds: fold inside the tree's leaf launch
+        if (!fused) FRICHK(fri_fold_launch(stream, fold, ctx->Q));                                        // :70-104
+        FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid, 1,
+                                   fused ? &fold : nullptr, &ctx->Q));                                   // :106
+        prev_nodes = (const uint4 *)nodes;
         values = (const uint4 *)next;
         next_size >>= 1;
     }
+    if (!tail_done)   // the last tree's root (and the challenge the reference computes and pops, :120)
+        FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * num_steps, d_roots + 2 * num_steps, r2, shave, ctx->P));
     // final: values -> ifft -> truncate (:130-145)
     rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
     if (rc) { fri_release(p); return rc; }

@@ -17,50 +17,45 @@
 
 namespace hodor {
 
-// hi'[j] = hi[j] * beta / 2   (all R'-form, normalized).  `c16` = 16 in R'-form: the product of the
-// R-form challenge with an R'-form entry is R-form, i.e. short by 2^5; 2^5 / 2 = 16.
+// Start of a round: the previous tree's root -> challenge beta (interpret_hash, K8), then
+// hi'[j] = hi[j] * beta / 2 (all R'-form, normalized).  Every workgroup derives beta from the root
+// itself (one Montgomery product) instead of waiting for a separate one-lane kernel; workgroup 0 also
+// records beta and the root.  `c16` = 16 in R'-form: the product of the R-form challenge with an
+// R'-form entry is R-form, i.e. short by 2^5; 2^5 / 2 = 16.
 __global__ void __launch_bounds__(256)
-k_fri_round_table(const uint4 *hi, uint4 *hi_out, uint64_t count, const uint4 *challenge, Fr9 c16,
-                  Fr9Params Q)
+k_fri_round_table(const uint4 *nodes, uint4 *chal_out, uint4 *root_out, const uint4 *hi, uint4 *hi_out,
+                  uint64_t count, Fr9 c16, Fr r2, uint32_t shave, Fr9Params Q, FrParams P)
 {
+    __shared__ uint32_t beta_w[8];
+    if (threadIdx.x == 0) {
+        const uint4 r0 = nodes[2], r1 = nodes[3];   // nodes[1] = the root
+        const uint32_t d[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        Fr beta = b2s_digest_to_challenge(d, r2, shave, P);
+#pragma unroll
+        for (int i = 0; i < 8; i++) beta_w[i] = beta.v[i];
+        if (blockIdx.x == 0) {
+            fr_store(chal_out, beta);
+            root_out[0] = r0;
+            root_out[1] = r1;
+        }
+    }
+    __syncthreads();
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    Fr9 beta = fr9_unpack(fr_load(challenge));
-    Fr9 b16 = fr9_mul(beta, c16, Q);                       // beta * 16, R-form, normalized, < 2p
+    Fr beta;
+#pragma unroll
+    for (int i = 0; i < 8; i++) beta.v[i] = beta_w[i];
+    Fr9 b16 = fr9_mul(fr9_unpack(beta), c16, Q);           // beta * 16, R-form, normalized, < 2p
     Fr9 h = fr9_mul(b16, fr9_load48(hi + 3 * j), Q);       // beta * 16 * h_j * 2^256 = (beta h_j / 2) 2^261
     fr9_store48(hi_out + 3 * j, h);
 }
 
-// exact halving of a lazy value: add p when odd, shift right one bit across the 29-bit limbs
-__device__ __forceinline__ Fr9 fr9_halve(Fr9 a, const Fr9Params &Q)
-{
-    fr9_normalize(a);
-    uint32_t odd = a.v[0] & 1;
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.v[i] += odd ? Q.p[i] : 0u;
-    fr9_normalize(a);
-    Fr9 r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = (a.v[i] >> 1) | ((a.v[i + 1] & 1) << 28);
-    r.v[8] = a.v[8] >> 1;
-    return r;
-}
-
 __global__ void __launch_bounds__(256)
-k_fri_fold(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo, const uint4 *hi_beta,
-           uint32_t lo_bits, uint32_t log_stride, Fr9Params Q)
+k_fri_fold(FoldArgs F, Fr9Params Q)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t lo_mask = (1ull << lo_bits) - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
-        Fr9 a = fr9_unpack(fr_load(src + 2 * i)), b = fr9_unpack(fr_load(src + 2 * (i + half)));
-        uint64_t e = i << log_stride;
-        Fr9 tw = fr9_load48(hi_beta + 3 * (e >> lo_bits));
-        if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(lo + 3 * (e & lo_mask)), Q);
-        Fr9 odd = fr9_mul(fr9_sub(a, b, Q), tw, Q);          // (a - b) * beta * w^-e / 2
-        Fr9 even = fr9_halve(fr9_add(a, b), Q);              // (a + b) / 2
-        fr_store(dst + 2 * i, fr9_to_canonical(fr9_add(even, odd), Q));
-    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < F.half; i += stride)
+        fr_store(F.dst + 2 * i, fri_fold_one(F, i, Q));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,21 +161,20 @@ hipError_t fri_tail_launch(hipStream_t s, const FriTailArgs &A, const Fr9 &c16, 
     return hipGetLastError();
 }
 
-hipError_t fri_round_table_launch(hipStream_t s, const uint4 *hi, uint4 *hi_out, uint64_t count,
-                                  const uint4 *challenge, const Fr9 &c16, const Fr9Params &Q)
+hipError_t fri_round_table_launch(hipStream_t s, const uint4 *nodes, uint4 *chal_out, uint4 *root_out,
+                                  const uint4 *hi, uint4 *hi_out, uint64_t count, const Fr9 &c16, const Fr &r2,
+                                  uint32_t shave, const Fr9Params &Q, const FrParams &P)
 {
-    hipLaunchKernelGGL(k_fri_round_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, hi, hi_out,
-                       count, challenge, c16, Q);
+    hipLaunchKernelGGL(k_fri_round_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, nodes, chal_out,
+                       root_out, hi, hi_out, count, c16, r2, shave, Q, P);
     return hipGetLastError();
 }
 
-hipError_t fri_fold_launch(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *lo,
-                           const uint4 *hi_beta, uint32_t lo_bits, uint32_t log_stride, const Fr9Params &Q)
+hipError_t fri_fold_launch(hipStream_t s, const FoldArgs &F, const Fr9Params &Q)
 {
-    uint64_t blocks = (half + 255) / 256;
+    uint64_t blocks = (F.half + 255) / 256;
     unsigned grid = (unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
-    hipLaunchKernelGGL(k_fri_fold, dim3(grid), dim3(256), 0, s, src, dst, half, lo, hi_beta, lo_bits,
-                       log_stride, Q);
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid), dim3(256), 0, s, F, Q);
     return hipGetLastError();
 }
 

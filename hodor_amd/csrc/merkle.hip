@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "blake2s.cuh"
+#include "ntt.cuh"
 
 namespace hodor {
 
@@ -43,10 +44,13 @@ namespace hodor {
 constexpr uint32_t MERKLE_LOG_CH = 11;       // throughput: 2048 inputs per workgroup, 32 KiB + 16 KiB of LDS
 constexpr uint32_t MERKLE_LAT_LOG_CH = 8;    // latency: 256 inputs per workgroup
 
-template <bool LEAF, bool LAT>
+// FOLD (latency schedule, leaf launch only): the leaves do not exist yet — leaf i is the FRI fold of the
+// previous round's values (fri_fold_one), computed here, stored to `fold.dst` and hashed from registers,
+// which saves the separate fold launch and its round trip through memory.
+template <bool LEAF, bool LAT, bool FOLD = false>
 __global__ void __launch_bounds__(256)
 k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint32_t levels, uint64_t n,
-                 B2Mid mid)
+                 B2Mid mid, FoldArgs fold = FoldArgs(), Fr9Params Q = Fr9Params())
 {
     // blockIdx.y selects one of several independent trees over n leaves each (batched commit)
     leafs += 2 * (uint64_t)blockIdx.y * n;
@@ -65,7 +69,17 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
     if (LAT) {
         // one input per lane into LDS: leaf hash (LEAF) or the digest itself
         for (uint32_t p = tid; p < ch; p += nthreads) {
-            uint4 a0 = in[2 * p], a1 = in[2 * p + 1];
+            uint4 a0, a1;
+            if (FOLD) {
+                const uint64_t i = (chunk << log_ch) + p;
+                Fr y = fri_fold_one(fold, i, Q);
+                fr_store(fold.dst + 2 * i, y);
+                a0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+                a1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+            } else {
+                a0 = in[2 * p];
+                a1 = in[2 * p + 1];
+            }
             if (LEAF) {
                 uint32_t out[8];
                 b2s_leaf(mid, a0, a1, out);
@@ -192,17 +206,35 @@ hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *
     return hipGetLastError();
 }
 
+// `fold` (optional, batch == 1): the leaves are fold->dst, still to be computed from fold->src; when the
+// tree is small enough for the latency schedule the first launch folds and hashes in one go, otherwise
+// the caller must have run the fold already (merkle_fuses_fold tells which).
+static int g_tail_log = -1, g_lat_log = -1;
+static void merkle_knobs()
+{
+    if (g_tail_log >= 0) return;
+    const char *e = getenv("HODOR_MERKLE_TAIL_LOG");
+    g_tail_log = e ? atoi(e) : 6;
+    e = getenv("HODOR_MERKLE_LAT_LOG");
+    g_lat_log = e ? atoi(e) : 19;
+}
+bool merkle_fuses_fold(uint64_t n)
+{
+    merkle_knobs();
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("HODOR_FRI_FUSE_FOLD");
+        on = e ? atoi(e) : 1;
+    }
+    return on && n <= (1ull << g_lat_log);
+}
+
 hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,
-                               const B2Mid &mid, uint32_t batch)
+                               const B2Mid &mid, uint32_t batch, const FoldArgs *fold, const Fr9Params *Q)
 {
     // n >= 2, power of two (checked by the caller); `batch` trees back to back
-    static int tail_log = -1, lat_log = -1;
-    if (tail_log < 0) {
-        const char *e = getenv("HODOR_MERKLE_TAIL_LOG");
-        tail_log = e ? atoi(e) : 6;
-        e = getenv("HODOR_MERKLE_LAT_LOG");
-        lat_log = e ? atoi(e) : 19;
-    }
+    merkle_knobs();
+    const int tail_log = g_tail_log, lat_log = g_lat_log;
     uint64_t m = n;
     bool first = true;
     while (m > 1) {
@@ -223,14 +255,16 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
             if (threads < 64) threads = 64;
         }
         dim3 grid((unsigned)chunks, batch);
-        if (first && lat)
-            hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
+        if (first && lat && fold)
+            hipLaunchKernelGGL((k_merkle_subtree<true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
+        else if (first && lat)
+            hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
         else if (first)
-            hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
+            hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
         else if (lat)
-            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
+            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
         else
-            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid);
+            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
         m >>= levels;
         first = false;
     }

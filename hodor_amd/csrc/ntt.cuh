@@ -38,6 +38,45 @@ struct PassArgs {
     uint32_t dbg;            // profiling only (HODOR_DBG): 1 skip butterflies, 2 skip twiddles, 4 skip loads, 8 skip stores
 };
 
+// One FRI folding step (src/fri/fri_on_values.rs:77-100), shared by k_fri_fold (fri.hip) and the fused
+// fold + leaf-hash phase of the latency-schedule Merkle kernel (merkle.hip).
+struct FoldArgs {
+    const uint4 *src;        // 2 * half values of the current round
+    uint4 *dst;              // half values of the next round
+    uint64_t half;
+    const uint4 *lo;         // two-level table of w^-1 of the initial domain (R'-form) ...
+    const uint4 *hi_beta;    // ... its `hi` half scaled by beta / 2 for this round (k_fri_round_table)
+    uint32_t lo_bits;
+    uint32_t log_stride;     // round index: element i pairs with exponent i << log_stride
+};
+
+// exact halving of a lazy value: add p when odd, shift right one bit across the 29-bit limbs
+__device__ __forceinline__ Fr9 fr9_halve(Fr9 a, const Fr9Params &Q)
+{
+    fr9_normalize(a);
+    uint32_t odd = a.v[0] & 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.v[i] += odd ? Q.p[i] : 0u;
+    fr9_normalize(a);
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (a.v[i] >> 1) | ((a.v[i + 1] & 1) << 28);
+    r.v[8] = a.v[8] >> 1;
+    return r;
+}
+
+// next[i] = (f[i] + f[i+half]) / 2 + (f[i] - f[i+half]) * w^-(i << log_stride) * beta / 2, canonical
+__device__ __forceinline__ Fr fri_fold_one(const FoldArgs &F, uint64_t i, const Fr9Params &Q)
+{
+    Fr9 a = fr9_unpack(fr_load(F.src + 2 * i)), b = fr9_unpack(fr_load(F.src + 2 * (i + F.half)));
+    const uint64_t e = i << F.log_stride, lo_mask = (1ull << F.lo_bits) - 1;
+    Fr9 tw = fr9_load48(F.hi_beta + 3 * (e >> F.lo_bits));
+    if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(F.lo + 3 * (e & lo_mask)), Q);
+    Fr9 odd = fr9_mul(fr9_sub(a, b, Q), tw, Q);          // (a - b) * beta * w^-e / 2
+    Fr9 even = fr9_halve(fr9_add(a, b), Q);              // (a + b) / 2
+    return fr9_to_canonical(fr9_add(even, odd), Q);
+}
+
 // Arguments of the fused FRI tail (fri.hip, k_fri_tail): the rounds whose output is <= FRI_TAIL_THREADS
 // values, run by one workgroup.
 constexpr int FRI_TAIL_THREADS = 512;
