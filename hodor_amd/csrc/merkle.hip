@@ -27,12 +27,12 @@ namespace hodor {
 // k_merkle_subtree: one workgroup builds the complete subtree over a chunk of CH = 2^log_ch inputs
 // (leaves when LEAF, digests of tree level `m` otherwise): every level of the chunk is written to its
 // place in the heap array and handed to the next level through LDS, so each leaf / digest is read
-// from HBM once and a 2^25-leaf tree takes 4 launches instead of 25.
+// from HBM once and a 2^25-leaf tree takes 5 launches instead of 25.
 //
 //   level k of the chunk (k = 1 .. log_ch) has CH >> k nodes at nodes[(m >> k) + chunk*(CH >> k) ..)
 //
 // Two schedules:
-//   throughput (LAT = false, big levels): 2048 inputs per workgroup; phase 0 pairs two adjacent inputs
+//   throughput (LAT = false, big levels): 1024 inputs per workgroup; phase 0 pairs two adjacent inputs
 //     per lane (64 contiguous bytes; a wave reads 4 KiB contiguous) and hashes leaf, leaf, node in one
 //     go; later levels re-map the surviving nodes densely onto the lanes.  The launcher stops a chunk
 //     before its levels get narrower than a wave.
@@ -41,7 +41,10 @@ namespace hodor {
 //     the quad-lane compression (blake2s.cuh) as soon as a level has fewer nodes than the workgroup
 //     has quads — the commit waits for depth x compression latency here, not for throughput.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t MERKLE_LOG_CH = 11;       // throughput: 2048 inputs per workgroup, 32 KiB + 16 KiB of LDS
+#ifndef HODOR_MERKLE_LOG_CH
+#define HODOR_MERKLE_LOG_CH 10
+#endif
+constexpr uint32_t MERKLE_LOG_CH = HODOR_MERKLE_LOG_CH;   // throughput: 1024 inputs per workgroup, 16 KiB + 8 KiB of LDS (6 workgroups per CU)
 constexpr uint32_t MERKLE_LAT_LOG_CH = 8;    // latency: 256 inputs per workgroup
 
 // FOLD (latency schedule, leaf launch only): the leaves do not exist yet — leaf i is the FRI fold of the
