@@ -388,6 +388,115 @@ __global__ void k_add_dpp(uint64_t *out, uint32_t a, uint32_t b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+__global__ void k_pk_swap(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_add_e64(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_add_u32_e64 %0, %1, %2" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_xor_e64(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_xor_b32_e64 %0, %1, %2" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_pk_add(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_pk_add_u16 %0, %1, %2" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_lshl_or(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_bfi(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint32_t r;
+            asm volatile("v_bfi_b32 %0, %1, %2, %1" : "=&v"(r) : "v"(acc[i]), "v"(y));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 #define MUL_ITERS 256
 __global__ void k_frmul(uint64_t *out, FrParams P, uint32_t seed)
 {
@@ -530,6 +639,12 @@ int main()
     RUN("v_xad_u32", k_xad)
     RUN("v_xor_b32_dpp", k_xor_dpp)
     RUN("v_add_u32_dpp", k_add_dpp)
+    RUN("v_pk_add_u16 opsel", k_pk_swap)
+    RUN("v_add_u32_e64", k_add_e64)
+    RUN("v_xor_b32_e64", k_xor_e64)
+    RUN("v_pk_add_u16", k_pk_add)
+    RUN("v_lshl_or_b32", k_lshl_or)
+    RUN("v_bfi_b32", k_bfi)
     FrParams P;
     // BLS12-381 Fr (the field in src/bn256.rs)
     const uint32_t p[8] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753};
