@@ -245,6 +245,39 @@ def test_fri_commit_matches_oracle(gpu_ctxs, oracles, field_name, log_deg, lde_f
     got.free()
 
 
+@pytest.mark.parametrize("log_deg,lde_factor", [(7, 8), (11, 16), (14, 8)])
+def test_fri_by_values_equals_through_coefficients_on_device(gpu_ctxs, oracles, log_deg, lde_factor):
+    """The reference's own cross-check (src/fri/mod.rs:338-343): proof_from_lde_by_values equals
+    proof_from_lde_through_coefficients (src/fri/mod.rs:156-248) — here with both sides on the device:
+    each round's vector must be lde(a_even + beta * a_odd) of the previous round's coefficients (:194-203),
+    built from the library's ifft / add_assign_scaled / lde, and the final coefficients must be that chain's
+    last fold."""
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n0 = 1 << log_deg
+    coeffs = O.random_elements(n0, 5 + log_deg)
+    d_coeffs = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    n = n0 * lde_factor
+    d_lde = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.poly_lde_dev(d_coeffs, d_lde, log_deg, lde_factor)
+    proto = ctx.fri_commit_dev(d_lde, n, lde_factor, 1)
+    assert proto.num_steps == log_deg
+    cur = d_coeffs
+    for step in range(proto.num_steps):
+        pairs = cur.view(-1, 2, 4)
+        folded, odd = pairs[:, 0, :].contiguous(), pairs[:, 1, :].contiguous()
+        ctx.poly_add_scaled_dev(folded, odd, folded.shape[0], proto.challenges[step])     # a_even + beta * a_odd
+        m = folded.shape[0]
+        d_next = torch.empty((m * lde_factor, 4), dtype=torch.int64, device="cuda")
+        ctx.poly_lde_dev(folded, d_next, m.bit_length() - 1, lde_factor)
+        torch.cuda.synchronize()
+        got = proto.intermediate_values(step, m * lde_factor)
+        assert np.array_equal(got, d_next.cpu().numpy().view(np.uint64)), step
+        cur = folded
+    assert np.array_equal(proto.final_coeffs, cur.cpu().numpy().view(np.uint64))
+    proto.free()
+
+
 def test_fri_commit_rejects_zero_steps(gpu_ctxs, oracles):
     import hodor_amd
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
