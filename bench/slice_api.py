@@ -14,3 +14,25 @@ for log_n in (16, 20, 22, 24):
         t = time.perf_counter(); ctx.poly_fft(a); best = min(best, time.perf_counter() - t)
     print("slice poly_fft 2^%d: %.3f ms  (%.2e elems/s, %.1f GB/s over PCIe both ways)" %
           (log_n, best * 1e3, n / best, 2 * n * 32 / best / 1e9))
+
+# concurrent callers on one context (the reference calls best_fft from several scoped threads,
+# src/arp/per_register/mod.rs:43-49): uploads, kernels and downloads of different callers overlap
+import threading
+for log_n in (20, 24):
+    n = 1 << log_n
+    for nthreads in (1, 2, 3, 4):
+        arrays = [rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64) for _ in range(nthreads)]
+        reps = 4
+        def work(a):
+            for _ in range(reps):
+                ctx.poly_fft(a)
+        for a in arrays:
+            ctx.poly_fft(a)              # warm-up (first touch of every lane's staging buffers)
+        ts = [threading.Thread(target=work, args=(a,)) for a in arrays]
+        t = time.perf_counter()
+        for th in ts: th.start()
+        for th in ts: th.join()
+        dt = time.perf_counter() - t
+        total = nthreads * reps
+        print("slice poly_fft 2^%d, %d threads: %.3f ms per transform (%.2e elems/s aggregate)" %
+              (log_n, nthreads, dt / total * 1e3, total * n / dt))

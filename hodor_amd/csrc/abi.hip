@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -167,8 +168,20 @@ struct hodor_ctx {
     std::vector<RadixTable> radix_tables;
     void *scratch[2] = {nullptr, nullptr};
     size_t scratch_bytes[2] = {0, 0};
-    void *io[2] = {nullptr, nullptr};       // grow-only device staging of the slice API (in / out)
-    size_t io_bytes[2] = {0, 0};
+    // slice API staging: IO_LANES independent (copy stream, in/out device buffers) sets, so that
+    // concurrent callers (src/arp/per_register/mod.rs:43-49 calls best_fft from several scoped threads)
+    // overlap one caller's upload with another's kernels and a third's download; see with_device_copy
+    struct IoLane {
+        hipStream_t stream = nullptr;
+        hipEvent_t uploaded = nullptr, computed = nullptr;
+        void *buf[2] = {nullptr, nullptr};   // grow-only (in / out)
+        size_t bytes[2] = {0, 0};
+        bool busy = false;
+    };
+    static constexpr int IO_LANES = 3;
+    IoLane lanes[IO_LANES];
+    std::mutex lane_mu;
+    std::condition_variable lane_cv;
     void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
     size_t fri_slab_bytes = 0;
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
@@ -306,18 +319,37 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
 
 // staging buffers of the slice API: kept across calls so a caller looping over registers
 // (src/arp/per_register/mod.rs:43-49) pays hipMalloc once, not per call
-static int ensure_io(hodor_ctx *ctx, int which, size_t bytes)
+static hodor_ctx::IoLane *lane_acquire(hodor_ctx *ctx)
 {
-    if (ctx->io_bytes[which] >= bytes) return HODOR_OK;
-    if (ctx->io[which]) {
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipFree(ctx->io[which]));
-        ctx->io[which] = nullptr;
-        ctx->io_bytes[which] = 0;
+    std::unique_lock<std::mutex> lk(ctx->lane_mu);
+    for (;;) {
+        for (auto &L : ctx->lanes)
+            if (!L.busy) { L.busy = true; return &L; }
+        ctx->lane_cv.wait(lk);
     }
-    HIPCHK(hipMalloc(&ctx->io[which], bytes));
-    ctx->io_bytes[which] = bytes;
-    return HODOR_OK;
+}
+static void lane_release(hodor_ctx *ctx, hodor_ctx::IoLane *L)
+{
+    { std::lock_guard<std::mutex> lk(ctx->lane_mu); L->busy = false; }
+    ctx->lane_cv.notify_one();
+}
+static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
+{
+    hipError_t e;
+    if (!L->stream) {
+        if ((e = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&L->uploaded, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&L->computed, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    if (L->bytes[which] >= bytes) return hipSuccess;
+    if (L->buf[which]) {   // the lane is idle (its last call synchronised its stream) — safe to free
+        if ((e = hipFree(L->buf[which])) != hipSuccess) return e;
+        L->buf[which] = nullptr;
+        L->bytes[which] = 0;
+    }
+    if ((e = hipMalloc(&L->buf[which], bytes)) != hipSuccess) return e;
+    L->bytes[which] = bytes;
+    return hipSuccess;
 }
 
 static int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes)
@@ -545,8 +577,13 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         for (int i = 0; i < 2; i++)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
         if (ctx->fri_slab) (void)hipFree(ctx->fri_slab);
-        for (int i = 0; i < 2; i++)
-            if (ctx->io[i]) (void)hipFree(ctx->io[i]);
+        for (auto &L : ctx->lanes) {
+            for (int i = 0; i < 2; i++)
+                if (L.buf[i]) (void)hipFree(L.buf[i]);
+            if (L.uploaded) (void)hipEventDestroy(L.uploaded);
+            if (L.computed) (void)hipEventDestroy(L.computed);
+            if (L.stream) (void)hipStreamDestroy(L.stream);
+        }
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1055,21 +1092,50 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
 // ------------------------------------------------------------------------------------------------
 
 // run `op` on a device copy of a[0..n_in) producing n_out elements back into `out`
+// Host slice in -> device -> `op` -> device -> host slice out.  The copies run on the caller's lane
+// (its own stream and buffers) WITHOUT the context mutex; only the enqueue of `op` on the context's
+// compute stream is serialised (twiddle caches and pass scratch are shared).  Events chain
+// upload -> compute -> download, so with several threads inside the library the PCIe link is busy in
+// both directions while the kernels of a third caller run.  `separate_out`: `op` may not work in place.
 template <class Op>
-static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *out, size_t n_out, Op op)
+static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *out, size_t n_out, Op op,
+                            bool separate_out = false)
 {
-    int rc = ensure_io(ctx, 0, (n_in ? n_in : 1) * 32);
-    if (rc) return rc;
-    void *din = ctx->io[0], *dptr_out = din;
-    if (n_out != n_in) {
-        if ((rc = ensure_io(ctx, 1, (n_out ? n_out : 1) * 32))) return rc;
-        dptr_out = ctx->io[1];
+    hodor_ctx::IoLane *L = lane_acquire(ctx);
+    auto fail = [&](hipError_t e, const char *what) {
+        (void)hipStreamSynchronize(L->stream);
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        }
+        lane_release(ctx, L);
+        return HODOR_ERR_DEVICE;
+    };
+    hipError_t e;
+    if ((e = lane_prepare(L, 0, (n_in ? n_in : 1) * 32)) != hipSuccess) return fail(e, "slice staging (in)");
+    void *din = L->buf[0], *dptr_out = din;
+    if (n_out != n_in || separate_out) {
+        if ((e = lane_prepare(L, 1, (n_out ? n_out : 1) * 32)) != hipSuccess) return fail(e, "slice staging (out)");
+        dptr_out = L->buf[1];
     }
-    HIPCHK(hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, ctx->stream));
-    rc = op((const uint4 *)din, (uint4 *)dptr_out);
-    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    HIPCHK(hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, L->stream)) != hipSuccess ||
+        (e = hipEventRecord(L->uploaded, L->stream)) != hipSuccess)
+        return fail(e, "slice upload");
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        e = hipStreamWaitEvent(ctx->stream, L->uploaded, 0);
+        rc = e == hipSuccess ? op((const uint4 *)din, (uint4 *)dptr_out) : HODOR_ERR_DEVICE;
+        if (e == hipSuccess) e = hipEventRecord(L->computed, ctx->stream);
+        if (rc || e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (rc) { (void)hipStreamSynchronize(L->stream); lane_release(ctx, L); return rc; }
+    if (e != hipSuccess) return fail(e, "slice compute");
+    if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess ||
+        (e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(L->stream)) != hipSuccess)
+        return fail(e, "slice download");
+    lane_release(ctx, L);
     return HODOR_OK;
 }
 
@@ -1078,7 +1144,6 @@ extern "C" int hodor_fft(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *
     NEED_DEVICE();
     if (!a || !omega) return HODOR_ERR_INVALID;
     if (log_n > 40 || n != ((size_t)1 << log_n)) { ctx->err = "fft: n != 1 << log_n"; return HODOR_ERR_SIZE; }   // assert_eq at src/fft/fft.rs:34
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HFr w = to_h(omega);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
         return ntt_exec(ctx, ctx->stream, s, d, log_n, w, n, nullptr, nullptr, nullptr);
@@ -1091,7 +1156,6 @@ extern "C" int hodor_lde(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *
     NEED_DEVICE();
     if (!a || !omega) return HODOR_ERR_INVALID;
     if (log_n > 40 || n != ((size_t)1 << log_n) || !is_pow2(lde_factor) || lde_factor > n) return HODOR_ERR_SIZE;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HFr w = to_h(omega);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
         return ntt_exec(ctx, ctx->stream, s, d, log_n, w, n / lde_factor, nullptr, nullptr, nullptr);
@@ -1102,7 +1166,6 @@ extern "C" int hodor_distribute_powers(hodor_ctx *ctx, hodor_fr *a, size_t n, co
 {
     NEED_DEVICE();
     if (!a || !g) return HODOR_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     Fr gd = to_dev(to_h(g));
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) -> int {
         (void)s;
@@ -1116,7 +1179,6 @@ static int poly_slice(hodor_ctx *ctx, hodor_fr *a, size_t n, PolyOp op)
     NEED_DEVICE();
     if (!a) return HODOR_ERR_INVALID;
     if (!is_pow2(n)) { ctx->err = "polynomial size must be a power of two"; return HODOR_ERR_SIZE; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
     uint32_t log_n = log2u(n);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
         return poly_transform(ctx, ctx->stream, s, d, log_n, op);
@@ -1133,7 +1195,6 @@ static int poly_lde_slice(hodor_ctx *ctx, const hodor_fr *coeffs, size_t n, size
     NEED_DEVICE();
     if (!coeffs || !out) return HODOR_ERR_INVALID;
     if (!is_pow2(n) || !is_pow2(factor)) return HODOR_ERR_SIZE;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     uint32_t log_n = log2u(n);
     return with_device_copy(ctx, coeffs, n, out, n * factor, [&](const uint4 *s, uint4 *d) {
         return poly_lde_exec(ctx, ctx->stream, s, d, log_n, factor, coset);
@@ -1149,14 +1210,10 @@ extern "C" int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n,
     NEED_DEVICE();
     if (!leafs || !nodes) return HODOR_ERR_INVALID;
     if (!is_pow2(n) || n < 2) { ctx->err = "iop_create: n must be a power of two >= 2"; return HODOR_ERR_SIZE; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    int rc = ensure_io(ctx, 0, n * 32);
-    if (rc || (rc = ensure_io(ctx, 1, n * 32))) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->io[0], leafs, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(merkle_build_launch(ctx->stream, (const uint4 *)ctx->io[0], (uint4 *)ctx->io[1], n, ctx->mid));
-    HIPCHK(hipMemcpyAsync(nodes, ctx->io[1], n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return HODOR_OK;
+    return with_device_copy(ctx, leafs, n, nodes, n, [&](const uint4 *s, uint4 *d) -> int {
+        HIPCHK(merkle_build_launch(ctx->stream, s, d, n, ctx->mid));
+        return HODOR_OK;
+    }, true);
 }
 
 extern "C" int hodor_iop_challenge(const hodor_ctx *ctx, const uint8_t root[32], hodor_fr *out)
