@@ -217,6 +217,57 @@ def test_iop_tree_matches_hashlib(gpu_ctxs):
     assert [bytes(x) for x in nodes[1:]] == P.iop_create(leafs)[1:]
 
 
+@pytest.mark.parametrize("log_n", [17, 19, 20, 21])
+def test_iop_tree_large_matches_oracle(gpu_ctxs, oracles, log_n):
+    """The schedules of merkle.hip by size: latency only (<= 2^19), one throughput launch then latency
+    (2^20, 2^21) — every node against the CPU oracle."""
+    import torch
+    from bench import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    d_l = random_elements(torch, n, 77 + log_n)
+    d_n = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    ctx.iop_create_dev(d_l, n, d_n)
+    ctx.synchronize()
+    exp = O.iop_create(d_l.cpu().numpy().view(np.uint64))
+    assert np.array_equal(d_n.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("log_n,log_sub", [(22, 16), (24, 19), (25, 19), (26, 20)])
+def test_iop_tree_benchmark_sizes_are_made_of_their_subtrees(gpu_ctxs, oracles, log_n, log_sub):
+    """BASELINE config[2]/[3] sizes (two throughput launches + latency tail), checked through a
+    size-independent property: the tree over n leaves contains, level by level, the trees over its
+    aligned blocks of 2^log_sub leaves (built by the smaller-size schedules, which the oracle pins), and
+    its top is the hash chain over the block roots."""
+    import torch
+    from bench import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n, s = 1 << log_n, 1 << log_sub
+    blocks = n // s
+    d_l = random_elements(torch, n, 99 + log_n)
+    d_n = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    ctx.iop_create_dev(d_l, n, d_n)
+    sub = torch.empty((s, 32), dtype=torch.uint8, device="cuda")
+    for j in sorted({0, 1, blocks // 2, blocks - 1}):
+        ctx.iop_create_dev(d_l[j * s:(j + 1) * s], s, sub)
+        ctx.synchronize()
+        w = s // 2
+        while w >= 1:
+            assert torch.equal(d_n[w * blocks + j * w: w * blocks + (j + 1) * w], sub[w:2 * w]), (j, w)
+            w //= 2
+    # the top log2(blocks) levels from the block roots, hashed on the host
+    level = [bytes(x) for x in d_n[blocks:2 * blocks].cpu().numpy()]
+    top = d_n[:blocks].cpu().numpy()
+    w = blocks // 2
+    while w >= 1:
+        level = [ctx.hash_node(level[2 * i], level[2 * i + 1]) for i in range(w)]
+        assert level == [bytes(x) for x in top[w:2 * w]], w
+        w //= 2
+    assert not top[0].any()
+    del d_l, d_n, sub
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------- FRI commit phase
 @pytest.mark.parametrize("log_deg,lde_factor,out_deg", [(2, 4, 2), (3, 4, 1), (6, 8, 1), (8, 16, 2), (11, 8, 1), (13, 8, 4)])
 def test_fri_commit_matches_oracle(gpu_ctxs, oracles, field_name, log_deg, lde_factor, out_deg):
