@@ -706,6 +706,35 @@ def test_large_transforms_roundtrip_and_points(gpu_ctxs, oracles, log_n):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("coset", [False, True])
+def test_lde_benchmark_size_points_and_subgrid(gpu_ctxs, oracles, coset):
+    """BASELINE config[2]: lde(8) of 2^22 coefficients.  out[idx] = P(W^idx) (resp. P(g W^idx)) checked by
+    direct evaluation (evaluate_at: a different kernel and a Horner-free sum), and the sub-grid idx = 8k is
+    the plain (coset) transform of the coefficients (src/polynomials/mod.rs:466-479 interleave)."""
+    import torch
+    from bench import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n, f = 22, 8
+    n = 1 << log_n
+    d_c = random_elements(torch, n, 2024)
+    d_out = torch.empty((n * f, 4), dtype=torch.int64, device="cuda")
+    ctx.poly_lde_dev(d_c, d_out, log_n, f, coset=coset)
+    _, _, W = O.domain(n * f)
+    g = O.const("generator")
+    for idx in (0, 1, 7, 8, n * f - 1, (n * f // 3) | 1):
+        point = O.pow(W, idx)
+        if coset:
+            point = O.mul(point, g)
+        got = array_to_ints(d_out[idx:idx + 1].cpu().numpy().view(np.uint64))[0]
+        assert got == ctx.poly_evaluate_at_dev(d_c, n, point), idx
+    plain = torch.empty_like(d_c)
+    (ctx.poly_coset_fft_dev if coset else ctx.poly_fft_dev)(d_c, plain, log_n)
+    ctx.synchronize()
+    assert torch.equal(d_out[::f], plain)
+    del d_c, d_out, plain
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("log_n", [28, 30])
 def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
     """2^30 is BASELINE config[4]'s size and two doublings short of the field's 2-adicity (S = 32);
