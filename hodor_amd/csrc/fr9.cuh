@@ -107,8 +107,14 @@ __device__ __forceinline__ Fr9 fr9_sub(const Fr9 &a, const Fr9 &b, const Fr9Para
     return r;
 }
 
-// Montgomery product a * b / 2^261 mod p (not fully reduced, see header).  Plain C++: the compiler
-// emits one v_mad_u64_u32 per limb product (162) and no carry instructions.
+// Montgomery product a * b / 2^261 mod p (not fully reduced, see header): one v_mad_u64_u32 per limb
+// product (162) and no carry instructions.
+// The empty asm pins the accumulator after every product.  Left alone, the compiler sums each column
+// in its own chain starting from 0 and joins the carry of the previous column with a separate 64-bit
+// add (v_lshl_add_u64 — half rate, like the mads): 19 extra issue slots per product for instruction
+// level parallelism this kernel does not need (the other waves of the SIMD hide the mad latency).
+// Pinned: 162 mads in one dependent chain, +6 % products/s in bench/microbench.hip.
+#define FR9_MAD(acc, x, y) do { acc += (uint64_t)(x) * (y); asm("" : "+v"(acc)); } while (0)
 __device__ __forceinline__ Fr9 fr9_mul(const Fr9 &a, const Fr9 &b, const Fr9Params &P)
 {
     uint32_t m[9];
@@ -117,19 +123,19 @@ __device__ __forceinline__ Fr9 fr9_mul(const Fr9 &a, const Fr9 &b, const Fr9Para
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int j = 0; j <= k; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+        for (int j = 0; j <= k; j++) FR9_MAD(acc, a.v[j], b.v[k - j]);
 #pragma unroll
-        for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * P.p[k - j];
+        for (int j = 0; j < k; j++) FR9_MAD(acc, m[j], P.p[k - j]);
         m[k] = ((uint32_t)acc * P.pinv) & HODOR_M29;
-        acc += (uint64_t)m[k] * P.p[0];
+        FR9_MAD(acc, m[k], P.p[0]);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int j = k - 8; j < 9; j++) acc += (uint64_t)a.v[j] * b.v[k - j];
+        for (int j = k - 8; j < 9; j++) FR9_MAD(acc, a.v[j], b.v[k - j]);
 #pragma unroll
-        for (int j = k - 8; j < 9; j++) acc += (uint64_t)m[j] * P.p[k - j];
+        for (int j = k - 8; j < 9; j++) FR9_MAD(acc, m[j], P.p[k - j]);
         t.v[k - 9] = (uint32_t)acc & HODOR_M29;
         acc >>= 29;
     }
