@@ -22,13 +22,17 @@ namespace hodor {
 hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr9 *scale, const Fr9Params &);
 hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
                             uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
-hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
+hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &);
+hipError_t distribute_powers_small_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
 hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
 hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
 hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
 hipError_t unary_launch(hipStream_t, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &);
-hipError_t batchinv_products_launch(hipStream_t, const uint4 *a, uint64_t n, uint32_t *zero_flag, const FrParams &);
-hipError_t batchinv_apply_launch(hipStream_t, uint4 *a, uint4 *prefix, uint64_t n, const FrParams &);
+hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod,
+                                   uint32_t *zero_flag, const FrParams &);
+hipError_t batchinv_backward_launch(hipStream_t, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,
+                                    const uint4 *prod_inv, const FrParams &);
+hipError_t batchinv_fermat_launch(hipStream_t, uint4 *a, uint64_t n, uint32_t *zero_flag, const FrParams &);
 hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
                               uint32_t *ticket, uint4 *out, const FrParams &);
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
@@ -769,13 +773,31 @@ extern "C" int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const ho
     return HODOR_OK;
 }
 
+// a[i] *= g^i through the cached two-level table of g (caller holds ctx->mu)
+static int distribute_powers_exec(hodor_ctx *ctx, hipStream_t stream, uint4 *a, size_t n, const HFr &g)
+{
+    if (n == 0) return HODOR_OK;
+    if (n < ((size_t)1 << 16)) {   // not worth a table (two allocations and a generation kernel)
+        HIPCHK(distribute_powers_small_launch(stream, a, n, to_dev(g), ctx->P));
+        return HODOR_OK;
+    }
+    uint32_t log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    int rc = trim_table_cache(ctx);
+    if (rc) return rc;
+    TwoLevel t;
+    if ((rc = get_pow_table(ctx, g, log_n, &t, 1))) return rc;
+    HIPCHK(distribute_powers_launch(stream, a, n, t, ctx->Q));
+    return HODOR_OK;
+}
+
 extern "C" int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n,
                                            const hodor_fr *g)
 {
     NEED_DEVICE();
     if (!a || !g) return HODOR_ERR_INVALID;
-    HIPCHK(distribute_powers_launch(pick_stream(ctx, stream), (uint4 *)a, n, to_dev(to_h(g)), ctx->P));
-    return HODOR_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return distribute_powers_exec(ctx, pick_stream(ctx, stream), (uint4 *)a, n, to_h(g));
 }
 
 extern "C" int hodor_precomputed_omegas_dev(hodor_ctx *ctx, void *stream, uint32_t log_n, hodor_fr *omegas,
@@ -868,19 +890,56 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     if (n == 0) return HODOR_OK;
     hipStream_t stream = pick_stream(ctx, stream_);
     std::lock_guard<std::mutex> lk(ctx->mu);
-    int rc = ensure_scratch(ctx, 0, n * 32 + 256);
-    if (rc) return rc;
-    uint32_t *flag = (uint32_t *)((uint8_t *)ctx->scratch[0] + n * 32);
-    HIPCHK(hipMemsetAsync(flag, 0, 4, stream));
-    HIPCHK(batchinv_products_launch(stream, (const uint4 *)a, n, flag, ctx->P));
-    uint32_t host_flag = 0;
-    HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    if (host_flag) {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
-        ctx->err = "batch_inversion: zero element";
-        return HODOR_ERR_INVALID;
+    // levels: n -> T0 = n/32 subsequence products -> T1 = T0/32 -> ... -> at most 1024 (one Fermat each)
+    struct Level { uint64_t n, T; size_t prefix_off, prod_off; };
+    std::vector<Level> levels;
+    size_t off = 0;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    for (uint64_t m = n; m > 1024;) {
+        uint64_t T = (m + 31) / 32;
+        Level L = {m, T, off, 0};
+        off += up(m * 32);
+        L.prod_off = off;
+        off += up(T * 32);
+        levels.push_back(L);
+        m = T;
     }
-    HIPCHK(batchinv_apply_launch(stream, (uint4 *)a, (uint4 *)ctx->scratch[0], n, ctx->P));
+    if (levels.empty()) off = 2 * up(n * 32);   // small input: room for the zero-check pass below
+    int rc = ensure_scratch(ctx, 0, off + 256);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)ctx->scratch[0];
+    uint32_t *flag = (uint32_t *)(base + off);
+    HIPCHK(hipMemsetAsync(flag, 0, 4, stream));
+    auto check_zero = [&]() -> int {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
+        uint32_t host_flag = 0;
+        HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (host_flag) { ctx->err = "batch_inversion: zero element"; return HODOR_ERR_INVALID; }
+        return HODOR_OK;
+    };
+    if (levels.empty()) {   // small input: one Fermat inversion per element, after the zero check
+        HIPCHK(batchinv_forward_launch(stream, (const uint4 *)a, n, n, (uint4 *)base, (uint4 *)(base + up(n * 32)),
+                                       flag, ctx->P));   // T = n: flags zeros, the products are the elements themselves
+        if ((rc = check_zero())) return rc;
+        HIPCHK(batchinv_fermat_launch(stream, (uint4 *)a, n, nullptr, ctx->P));
+        return HODOR_OK;
+    }
+    const uint4 *cur = (const uint4 *)a;
+    for (size_t l = 0; l < levels.size(); l++) {
+        const Level &L = levels[l];
+        HIPCHK(batchinv_forward_launch(stream, cur, L.n, L.T, (uint4 *)(base + L.prefix_off), (uint4 *)(base + L.prod_off),
+                                       l == 0 ? flag : nullptr, ctx->P));
+        if (l == 0 && (rc = check_zero())) return rc;   // no element is zero => no product above is
+        cur = (const uint4 *)(base + L.prod_off);
+    }
+    const Level &top = levels.back();
+    HIPCHK(batchinv_fermat_launch(stream, (uint4 *)(base + top.prod_off), top.T, nullptr, ctx->P));
+    for (size_t l = levels.size(); l-- > 0;) {
+        const Level &L = levels[l];
+        uint4 *target = l == 0 ? (uint4 *)a : (uint4 *)(base + levels[l - 1].prod_off);
+        HIPCHK(batchinv_backward_launch(stream, target, L.n, L.T, (const uint4 *)(base + L.prefix_off),
+                                        (const uint4 *)(base + L.prod_off), ctx->P));
+    }
     return HODOR_OK;
 }
 
@@ -1166,11 +1225,10 @@ extern "C" int hodor_distribute_powers(hodor_ctx *ctx, hodor_fr *a, size_t n, co
 {
     NEED_DEVICE();
     if (!a || !g) return HODOR_ERR_INVALID;
-    Fr gd = to_dev(to_h(g));
+    HFr gh = to_h(g);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) -> int {
         (void)s;
-        HIPCHK(distribute_powers_launch(ctx->stream, d, n, gd, ctx->P));
-        return HODOR_OK;
+        return distribute_powers_exec(ctx, ctx->stream, d, n, gh);
     });
 }
 

@@ -7,14 +7,15 @@
 //                         either side of every LDE in ALI (src/polynomials/mod.rs:657-711, 744-954)
 //
 // HBM-streaming kernels: grid-stride over 32-byte elements, one element per lane per iteration so a
-// wave touches 2 KiB of contiguous memory; powers are a per-thread running product (one
-// square-and-multiply at entry, then one multiply by g^stride per iteration).
+// wave touches 2 KiB of contiguous memory; powers come from the cached two-level tables (abi.hip).
 #include "ntt.cuh"
 
 namespace hodor {
 
+// small inputs: per-thread running product (one square-and-multiply at entry, then one multiply by
+// g^stride per iteration) — no table to build for a generator that may never come back
 __global__ void __launch_bounds__(256)
-k_distribute_powers(uint4 *a, uint64_t n, Fr g, FrParams P)
+k_distribute_powers_small(uint4 *a, uint64_t n, Fr g, FrParams P)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -25,6 +26,22 @@ k_distribute_powers(uint4 *a, uint64_t n, Fr g, FrParams P)
         Fr x = fr_load(a + 2 * i);
         fr_store(a + 2 * i, fr_mul(x, u, P));
         u = fr_mul(u, step, P);
+    }
+}
+
+// g^i from the cached two-level table of g (lo[i & mask] * hi[i >> bits], L2-resident, R'-form): two
+// products per element in the 9 x 29 arithmetic, no per-thread square-and-multiply and no dependent
+// running product.
+__global__ void __launch_bounds__(256)
+k_distribute_powers(uint4 *a, uint64_t n, TwoLevel t, Fr9Params Q)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t lo_mask = (1ull << t.lo_bits) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fr9 w = fr9_load48(t.hi + 3 * (i >> t.lo_bits));
+        if (i & lo_mask) w = fr9_mul(w, fr9_load48(t.lo + 3 * (i & lo_mask)), Q);
+        Fr9 x = fr9_mul(fr9_unpack(fr_load(a + 2 * i)), w, Q);
+        fr_store(a + 2 * i, fr9_to_canonical<true>(x, Q));
     }
 }
 
@@ -123,41 +140,62 @@ __device__ inline Fr fr_inverse_fermat(const Fr &a, const FrParams &P)
     return r;
 }
 
-// Polynomial<F, Values>::batch_inversion (src/polynomials/mod.rs:889-954).  Each thread owns the
-// strided subsequence a[t], a[t+T], ... (coalesced across lanes) the way a CPU worker owns a chunk:
-// pass 1 (k_batchinv_products): products only, and a flag if any element is zero — the reference
-// errors out before touching the data (:909).  Pass 2 (k_batchinv_apply): prefix products to
-// scratch, ONE Fermat inversion per thread, backward substitution (3 products per element).
+// Polynomial<F, Values>::batch_inversion (src/polynomials/mod.rs:889-954).  Montgomery's trick, but
+// hierarchical so that every level runs with as many threads as the chip holds instead of one long
+// dependent product chain per CPU-style worker:
+//   forward (k_batchinv_forward): thread t of T owns the strided subsequence a[t], a[t+T], ...
+//     (coalesced across lanes; about 32 elements), writes the running prefix product of each element
+//     to scratch and the product of the whole subsequence to prod[t]; flags zero elements — the
+//     reference errors out before touching the data (:909), and so does the caller here;
+//   the T subsequence products are inverted by the same procedure (T/32 threads, ...) until at most
+//     1024 are left, which take one Fermat inversion each (k_batchinv_fermat);
+//   backward (k_batchinv_backward): a[i] = inv * prefix[i], inv *= old a[i], walking the subsequence
+//     from its end.
+// Three products per element plus ~1/32 for the upper levels; 160 bytes of traffic per element.
 __global__ void __launch_bounds__(256)
-k_batchinv_products(const uint4 *a, uint64_t n, uint32_t *zero_flag, FrParams P)
+k_batchinv_forward(const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod, uint32_t *zero_flag,
+                   FrParams P)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    Fr run = fr_one(P);
     bool zero = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        zero |= fr_is_zero(fr_load(a + 2 * i));
-    if (zero) atomicOr(zero_flag, 1u);
+    for (uint64_t i = t; i < n; i += T) {           // prefix[i] = product of this thread's elements before i
+        Fr x = fr_load(a + 2 * i);
+        zero |= fr_is_zero(x);
+        fr_store(prefix + 2 * i, run);
+        run = fr_mul(run, x, P);
+    }
+    fr_store(prod + 2 * t, run);
+    if (zero && zero_flag) atomicOr(zero_flag, 1u);
 }
 
 __global__ void __launch_bounds__(256)
-k_batchinv_apply(uint4 *a, uint4 *prefix, uint64_t n, FrParams P)
+k_batchinv_backward(uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix, const uint4 *prod_inv, FrParams P)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    Fr run = fr_one(P);
-    uint64_t last = t;
-    for (uint64_t i = t; i < n; i += stride) {     // prefix[i] = product of this thread's elements before i
-        fr_store(prefix + 2 * i, run);
-        run = fr_mul(run, fr_load(a + 2 * i), P);
-        last = i;
-    }
-    Fr inv = fr_inverse_fermat(run, P);             // (product of the whole subsequence)^-1
-    for (uint64_t i = last;; i -= stride) {
+    if (t >= T || t >= n) return;
+    Fr inv = fr_load(prod_inv + 2 * t);             // (product of the whole subsequence)^-1
+    const uint64_t last = t + ((n - 1 - t) / T) * T;
+    for (uint64_t i = last;; i -= T) {
         Fr x = fr_load(a + 2 * i);
         fr_store(a + 2 * i, fr_mul(inv, fr_load(prefix + 2 * i), P));
         inv = fr_mul(inv, x, P);
-        if (i < stride + t || i == t) break;
+        if (i == t) break;
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_batchinv_fermat(uint4 *a, uint64_t n, uint32_t *zero_flag, FrParams P)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fr x = fr_load(a + 2 * t);
+    if (fr_is_zero(x)) {
+        if (zero_flag) atomicOr(zero_flag, 1u);
+        return;
+    }
+    fr_store(a + 2 * t, fr_inverse_fermat(x, P));
 }
 
 // Polynomial<F, Coefficients>::evaluate_at (src/polynomials/mod.rs:685-711): sum a[i] g^i.
@@ -219,10 +257,17 @@ static unsigned stream_grid(uint64_t n)
     return (unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
 }
 
-hipError_t distribute_powers_launch(hipStream_t s, uint4 *a, uint64_t n, const Fr &g, const FrParams &P)
+hipError_t distribute_powers_small_launch(hipStream_t s, uint4 *a, uint64_t n, const Fr &g, const FrParams &P)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_distribute_powers, dim3(stream_grid(n)), dim3(256), 0, s, a, n, g, P);
+    hipLaunchKernelGGL(k_distribute_powers_small, dim3(stream_grid(n)), dim3(256), 0, s, a, n, g, P);
+    return hipGetLastError();
+}
+
+hipError_t distribute_powers_launch(hipStream_t s, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &Q)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_distribute_powers, dim3(stream_grid(n)), dim3(256), 0, s, a, n, t, Q);
     return hipGetLastError();
 }
 
@@ -247,25 +292,26 @@ hipError_t unary_launch(hipStream_t s, uint4 *a, uint64_t n, int op, const Fr &c
     return hipGetLastError();
 }
 
-// batch inversion: threads = min(n, 2^16) so that one Fermat inversion is amortised over >= 256
-// elements at 2^24
-unsigned batchinv_threads(uint64_t n)
+// batch inversion launchers (the level recursion lives in abi.hip, which owns the scratch)
+hipError_t batchinv_forward_launch(hipStream_t s, const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod,
+                                   uint32_t *zero_flag, const FrParams &P)
 {
-    uint64_t blocks = (n + 255) / 256;
-    if (blocks > 256) blocks = 256;
-    return (unsigned)(blocks ? blocks : 1);
-}
-
-hipError_t batchinv_products_launch(hipStream_t s, const uint4 *a, uint64_t n, uint32_t *zero_flag,
-                                    const FrParams &P)
-{
-    hipLaunchKernelGGL(k_batchinv_products, dim3(stream_grid(n)), dim3(256), 0, s, a, n, zero_flag, P);
+    hipLaunchKernelGGL(k_batchinv_forward, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, a, n, T, prefix, prod,
+                       zero_flag, P);
     return hipGetLastError();
 }
 
-hipError_t batchinv_apply_launch(hipStream_t s, uint4 *a, uint4 *prefix, uint64_t n, const FrParams &P)
+hipError_t batchinv_backward_launch(hipStream_t s, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,
+                                    const uint4 *prod_inv, const FrParams &P)
 {
-    hipLaunchKernelGGL(k_batchinv_apply, dim3(batchinv_threads(n)), dim3(256), 0, s, a, prefix, n, P);
+    hipLaunchKernelGGL(k_batchinv_backward, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, a, n, T, prefix,
+                       prod_inv, P);
+    return hipGetLastError();
+}
+
+hipError_t batchinv_fermat_launch(hipStream_t s, uint4 *a, uint64_t n, uint32_t *zero_flag, const FrParams &P)
+{
+    hipLaunchKernelGGL(k_batchinv_fermat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, zero_flag, P);
     return hipGetLastError();
 }
 

@@ -108,15 +108,21 @@ def test_poly_transforms(gpu_ctxs, oracles, field_name, log_n):
     assert np.array_equal(b, a)
 
 
-@pytest.mark.parametrize("n", [1, 2, 7 * 0 + 8, 1 << 10, 1 << 13])
+@pytest.mark.parametrize("n", [1, 2, 7 * 0 + 8, 1 << 10, 1 << 13, 1 << 16, (1 << 17) + 5, 1 << 20])
 def test_distribute_powers(gpu_ctxs, oracles, field_name, n):
+    """Below 2^16 elements a running-product kernel, from there on the cached two-level table of g."""
+    import torch
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
     a = O.random_elements(n, 3)
-    g = O.const("generator")
-    exp, got = a.copy(), a.copy()
-    O.distribute_powers(exp, g)
-    ctx.distribute_powers(got, g)
-    assert np.array_equal(got, exp)
+    for g in (O.const("generator"), array_to_ints(O.random_elements(1, 11))[0]):
+        exp, got = a.copy(), a.copy()
+        O.distribute_powers(exp, g)
+        ctx.distribute_powers(got, g)
+        assert np.array_equal(got, exp)
+        d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        ctx.distribute_powers_dev(d, n, g)
+        ctx.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), exp)
 
 
 @pytest.mark.parametrize("log_n", [0, 1, 5, 12])
@@ -611,7 +617,7 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
 
 
 # ---------------------------------------------------------------- value-form polynomial ops (§8 f.1)
-@pytest.mark.parametrize("n", [1, 5, 1 << 10, (1 << 16) + 3, 1 << 18])
+@pytest.mark.parametrize("n", [1, 5, 1 << 10, 1025, (1 << 16) + 3, 1 << 18, (1 << 21) + 1])
 def test_value_form_ops_dev(gpu_ctxs, oracles, field_name, n):
     import torch
     import hodor_amd
