@@ -32,7 +32,6 @@ hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint
                                    uint32_t *zero_flag, const FrParams &);
 hipError_t batchinv_backward_launch(hipStream_t, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,
                                     const uint4 *prod_inv, const FrParams &);
-hipError_t batchinv_fermat_launch(hipStream_t, uint4 *a, uint64_t n, uint32_t *zero_flag, const FrParams &);
 hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
                               uint32_t *ticket, uint4 *out, const FrParams &);
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
@@ -890,13 +889,23 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     if (n == 0) return HODOR_OK;
     hipStream_t stream = pick_stream(ctx, stream_);
     std::lock_guard<std::mutex> lk(ctx->mu);
-    // levels: n -> T0 = n/32 subsequence products -> T1 = T0/32 -> ... -> at most 1024 (one Fermat each)
+    // levels: n -> T0 = n/8 subsequence products -> T1 = T0/8 -> ... until at most TOP are left.  Those
+    // come to the host together with the zero flag (one synchronisation, needed anyway to leave the data
+    // untouched on error) and are inverted there: a Fermat inversion is ~380 dependent products, 20 us on
+    // a CPU core but 0.4 ms of latency for a lone GPU lane.
+    constexpr uint64_t TOP = 16;
     struct Level { uint64_t n, T; size_t prefix_off, prod_off; };
     std::vector<Level> levels;
     size_t off = 0;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    for (uint64_t m = n; m > 1024;) {
-        uint64_t T = (m + 31) / 32;
+    static int seq = -1;   // elements per thread and level
+    if (seq < 0) {
+        const char *e = getenv("HODOR_BATCHINV_SEQ");
+        seq = e ? atoi(e) : 8;
+        if (seq < 2) seq = 2;
+    }
+    for (uint64_t m = n; m > TOP || levels.empty();) {
+        uint64_t T = (m + seq - 1) / seq;
         Level L = {m, T, off, 0};
         off += up(m * 32);
         L.prod_off = off;
@@ -904,42 +913,41 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
         levels.push_back(L);
         m = T;
     }
-    if (levels.empty()) off = 2 * up(n * 32);   // small input: room for the zero-check pass below
     int rc = ensure_scratch(ctx, 0, off + 256);
     if (rc) return rc;
     uint8_t *base = (uint8_t *)ctx->scratch[0];
     uint32_t *flag = (uint32_t *)(base + off);
     HIPCHK(hipMemsetAsync(flag, 0, 4, stream));
-    auto check_zero = [&]() -> int {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
-        uint32_t host_flag = 0;
-        HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        if (host_flag) { ctx->err = "batch_inversion: zero element"; return HODOR_ERR_INVALID; }
-        return HODOR_OK;
-    };
-    if (levels.empty()) {   // small input: one Fermat inversion per element, after the zero check
-        HIPCHK(batchinv_forward_launch(stream, (const uint4 *)a, n, n, (uint4 *)base, (uint4 *)(base + up(n * 32)),
-                                       flag, ctx->P));   // T = n: flags zeros, the products are the elements themselves
-        if ((rc = check_zero())) return rc;
-        HIPCHK(batchinv_fermat_launch(stream, (uint4 *)a, n, nullptr, ctx->P));
-        return HODOR_OK;
-    }
     const uint4 *cur = (const uint4 *)a;
-    for (size_t l = 0; l < levels.size(); l++) {
+    for (size_t l = 0; l < levels.size(); l++) {   // forward: nothing of `a` is modified yet
         const Level &L = levels[l];
         HIPCHK(batchinv_forward_launch(stream, cur, L.n, L.T, (uint4 *)(base + L.prefix_off), (uint4 *)(base + L.prod_off),
                                        l == 0 ? flag : nullptr, ctx->P));
-        if (l == 0 && (rc = check_zero())) return rc;   // no element is zero => no product above is
         cur = (const uint4 *)(base + L.prod_off);
     }
     const Level &top = levels.back();
-    HIPCHK(batchinv_fermat_launch(stream, (uint4 *)(base + top.prod_off), top.T, nullptr, ctx->P));
+    hodor_fr top_prod[TOP];
+    uint32_t host_flag = 0;
+    HIPCHK(hipMemcpyAsync(top_prod, base + top.prod_off, top.T * 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (host_flag) {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
+        ctx->err = "batch_inversion: zero element";
+        return HODOR_ERR_INVALID;
+    }
+    for (uint64_t i = 0; i < top.T; i++) {
+        HFr inv;
+        if (!ctx->F.inverse(to_h(&top_prod[i]), &inv)) { ctx->err = "batch_inversion: zero product"; return HODOR_ERR_INVALID; }
+        from_h(inv, &top_prod[i]);
+    }
+    HIPCHK(hipMemcpyAsync(base + top.prod_off, top_prod, top.T * 32, hipMemcpyHostToDevice, stream));
     for (size_t l = levels.size(); l-- > 0;) {
         const Level &L = levels[l];
         uint4 *target = l == 0 ? (uint4 *)a : (uint4 *)(base + levels[l - 1].prod_off);
         HIPCHK(batchinv_backward_launch(stream, target, L.n, L.T, (const uint4 *)(base + L.prefix_off),
                                         (const uint4 *)(base + L.prod_off), ctx->P));
     }
+    HIPCHK(hipStreamSynchronize(stream));   // top_prod is a stack buffer the upload reads from
     return HODOR_OK;
 }
 

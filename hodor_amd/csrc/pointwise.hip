@@ -120,38 +120,18 @@ k_unary(uint4 *a, uint64_t n, int op, Fr c, uint64_t e, FrParams P)
     }
 }
 
-// base^(p-2) by square-and-multiply over the 256-bit exponent held in SGPRs
-__device__ inline Fr fr_inverse_fermat(const Fr &a, const FrParams &P)
-{
-    // exponent = p - 2, with the borrow propagated (p[0] is 1 for both reference fields)
-    uint32_t e[8];
-    uint64_t borrow = 2;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        uint64_t d = (uint64_t)P.p[k] - borrow;
-        e[k] = (uint32_t)d;
-        borrow = (d >> 63) & 1;
-    }
-    Fr r = fr_one(P);
-    for (int i = 255; i >= 0; i--) {
-        r = fr_sqr(r, P);
-        if ((e[i >> 5] >> (i & 31)) & 1) r = fr_mul(r, a, P);
-    }
-    return r;
-}
-
 // Polynomial<F, Values>::batch_inversion (src/polynomials/mod.rs:889-954).  Montgomery's trick, but
 // hierarchical so that every level runs with as many threads as the chip holds instead of one long
 // dependent product chain per CPU-style worker:
 //   forward (k_batchinv_forward): thread t of T owns the strided subsequence a[t], a[t+T], ...
-//     (coalesced across lanes; about 32 elements), writes the running prefix product of each element
+//     (coalesced across lanes; 8 elements), writes the running prefix product of each element
 //     to scratch and the product of the whole subsequence to prod[t]; flags zero elements — the
 //     reference errors out before touching the data (:909), and so does the caller here;
-//   the T subsequence products are inverted by the same procedure (T/32 threads, ...) until at most
-//     1024 are left, which take one Fermat inversion each (k_batchinv_fermat);
+//   the T subsequence products are inverted by the same procedure (T/8 threads, ...) until at most
+//     16 are left, which the host inverts (it has to look at the zero flag at that point anyway);
 //   backward (k_batchinv_backward): a[i] = inv * prefix[i], inv *= old a[i], walking the subsequence
 //     from its end.
-// Three products per element plus ~1/32 for the upper levels; 160 bytes of traffic per element.
+// Three products per element plus ~1/8 for the upper levels; 160 bytes of traffic per element.
 __global__ void __launch_bounds__(256)
 k_batchinv_forward(const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod, uint32_t *zero_flag,
                    FrParams P)
@@ -183,19 +163,6 @@ k_batchinv_backward(uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix, const
         inv = fr_mul(inv, x, P);
         if (i == t) break;
     }
-}
-
-__global__ void __launch_bounds__(256)
-k_batchinv_fermat(uint4 *a, uint64_t n, uint32_t *zero_flag, FrParams P)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    Fr x = fr_load(a + 2 * t);
-    if (fr_is_zero(x)) {
-        if (zero_flag) atomicOr(zero_flag, 1u);
-        return;
-    }
-    fr_store(a + 2 * t, fr_inverse_fermat(x, P));
 }
 
 // Polynomial<F, Coefficients>::evaluate_at (src/polynomials/mod.rs:685-711): sum a[i] g^i.
@@ -306,12 +273,6 @@ hipError_t batchinv_backward_launch(hipStream_t s, uint4 *a, uint64_t n, uint64_
 {
     hipLaunchKernelGGL(k_batchinv_backward, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, a, n, T, prefix,
                        prod_inv, P);
-    return hipGetLastError();
-}
-
-hipError_t batchinv_fermat_launch(hipStream_t s, uint4 *a, uint64_t n, uint32_t *zero_flag, const FrParams &P)
-{
-    hipLaunchKernelGGL(k_batchinv_fermat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, zero_flag, P);
     return hipGetLastError();
 }
 
