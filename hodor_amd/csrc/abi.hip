@@ -32,6 +32,9 @@ hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint
                                    uint32_t *zero_flag, const FrParams &);
 hipError_t batchinv_backward_launch(hipStream_t, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,
                                     const uint4 *prod_inv, const FrParams &);
+unsigned evaluate_at_table_blocks(uint32_t log_n);
+hipError_t evaluate_at_table_launch(hipStream_t, const uint4 *a, uint64_t n, uint32_t log_n, const TwoLevel &t,
+                                    uint4 *partials, uint32_t *ticket, uint4 *out, const Fr9Params &, const FrParams &);
 hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
                               uint32_t *ticket, uint4 *out, const FrParams &);
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
@@ -958,13 +961,23 @@ extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const h
     if (!coeffs || !g || !out) return HODOR_ERR_INVALID;
     hipStream_t stream = pick_stream(ctx, stream_);
     std::lock_guard<std::mutex> lk(ctx->mu);
-    int rc = ensure_scratch(ctx, 0, 32 * 258 + 64);
+    uint32_t log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    const bool table = n >= ((size_t)1 << 16);   // below that a table is not worth its two allocations
+    const size_t blocks = table ? evaluate_at_table_blocks(log_n) : 256;
+    int rc = ensure_scratch(ctx, 0, 32 * (blocks + 2) + 64);
     if (rc) return rc;
     uint4 *partials = (uint4 *)ctx->scratch[0];
-    uint4 *res = partials + 2 * 256;
+    uint4 *res = partials + 2 * blocks;
     uint32_t *ticket = (uint32_t *)(res + 2);
     HIPCHK(hipMemsetAsync(ticket, 0, 4, stream));
-    HIPCHK(evaluate_at_launch(stream, (const uint4 *)coeffs, n, to_dev(to_h(g)), partials, ticket, res, ctx->P));
+    if (table) {
+        TwoLevel t;
+        if ((rc = trim_table_cache(ctx)) || (rc = get_pow_table(ctx, to_h(g), log_n, &t, 1))) return rc;
+        HIPCHK(evaluate_at_table_launch(stream, (const uint4 *)coeffs, n, log_n, t, partials, ticket, res, ctx->Q, ctx->P));
+    } else {
+        HIPCHK(evaluate_at_launch(stream, (const uint4 *)coeffs, n, to_dev(to_h(g)), partials, ticket, res, ctx->P));
+    }
     HIPCHK(hipMemcpyAsync(out, res, 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     return HODOR_OK;

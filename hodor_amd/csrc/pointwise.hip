@@ -166,23 +166,13 @@ k_batchinv_backward(uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix, const
 }
 
 // Polynomial<F, Coefficients>::evaluate_at (src/polynomials/mod.rs:685-711): sum a[i] g^i.
-// Per-thread strided partial sums with a running power, then a workgroup tree in LDS; one partial
-// per workgroup goes to `partials`, the last workgroup to finish (ticket) folds them into out[0].
-__global__ void __launch_bounds__(256)
-k_evaluate_at(const uint4 *a, uint64_t n, Fr g, uint4 *partials, uint32_t *ticket, uint4 *out, FrParams P)
+// Per-thread strided partial sums, then a workgroup tree in LDS; one partial per workgroup goes to
+// `partials`, the last workgroup to finish (ticket) folds them into out[0].
+__device__ __forceinline__ void evaluate_reduce(Fr acc, uint4 *partials, uint32_t *ticket, uint4 *out,
+                                                const FrParams &P)
 {
     __shared__ uint4 red[2 * 256];
     __shared__ bool is_last;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Fr acc = fr_zero();
-    if (i < n) {
-        Fr u = fr_pow(g, i, P), step = fr_pow(g, stride, P);
-        for (; i < n; i += stride) {
-            acc = fr_add(acc, fr_mul(fr_load(a + 2 * i), u, P), P);
-            u = fr_mul(u, step, P);
-        }
-    }
     fr_store(red + 2 * threadIdx.x, acc);
     __syncthreads();
     for (uint32_t w = 128; w >= 1; w >>= 1) {
@@ -216,6 +206,47 @@ k_evaluate_at(const uint4 *a, uint64_t n, Fr g, uint4 *partials, uint32_t *ticke
         __syncthreads();
     }
     if (threadIdx.x == 0) fr_store(out, fr_load(red));
+}
+
+// small inputs: running power per thread (one square-and-multiply at entry)
+__global__ void __launch_bounds__(256)
+k_evaluate_at(const uint4 *a, uint64_t n, Fr g, uint4 *partials, uint32_t *ticket, uint4 *out, FrParams P)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr acc = fr_zero();
+    if (i < n) {
+        Fr u = fr_pow(g, i, P), step = fr_pow(g, stride, P);
+        for (; i < n; i += stride) {
+            acc = fr_add(acc, fr_mul(fr_load(a + 2 * i), u, P), P);
+            u = fr_mul(u, step, P);
+        }
+    }
+    evaluate_reduce(acc, partials, ticket, out, P);
+}
+
+// large inputs: g^i = lo[i & mask] * hi[i >> bits] from the cached two-level table.  The thread count T
+// is a multiple of 2^bits, so a thread's elements i0, i0 + T, ... share their `lo` factor: one product
+// per element with the `hi` entry, lazily accumulated (9 x 29 limbs, at most 64 terms), and a single
+// product with lo[i0 & mask] at the end.
+__global__ void __launch_bounds__(256)
+k_evaluate_at_table(const uint4 *a, uint64_t n, TwoLevel t, uint4 *partials, uint32_t *ticket, uint4 *out,
+                    Fr9Params Q, FrParams P)
+{
+    const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr9 acc;
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc.v[k] = 0;
+    uint32_t pending = 0;
+    for (uint64_t i = i0; i < n; i += T) {
+        Fr9 term = fr9_mul(fr9_unpack(fr_load(a + 2 * i)), fr9_load48(t.hi + 3 * (i >> t.lo_bits)), Q);
+        acc = fr9_add(acc, term);                           // terms are normalized and < 2p
+        if (++pending == 4) { fr9_normalize(acc); pending = 0; }
+    }
+    fr9_normalize(acc);
+    acc = fr9_mul(acc, fr9_load48(t.lo + 3 * (i0 & ((1ull << t.lo_bits) - 1))), Q);
+    evaluate_reduce(fr9_to_canonical<true>(acc, Q), partials, ticket, out, P);
 }
 
 static unsigned stream_grid(uint64_t n)
@@ -273,6 +304,17 @@ hipError_t batchinv_backward_launch(hipStream_t s, uint4 *a, uint64_t n, uint64_
 {
     hipLaunchKernelGGL(k_batchinv_backward, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, a, n, T, prefix,
                        prod_inv, P);
+    return hipGetLastError();
+}
+
+// one partial per workgroup; `n >> 5` threads (a multiple of 2^lo_bits for n >= 2^16), <= 32 terms each
+unsigned evaluate_at_table_blocks(uint32_t log_n) { return 1u << (log_n - 5 - 8); }
+hipError_t evaluate_at_table_launch(hipStream_t s, const uint4 *a, uint64_t n, uint32_t log_n, const TwoLevel &t,
+                                    uint4 *partials, uint32_t *ticket, uint4 *out, const Fr9Params &Q,
+                                    const FrParams &P)
+{
+    hipLaunchKernelGGL(k_evaluate_at_table, dim3(evaluate_at_table_blocks(log_n)), dim3(256), 0, s, a, n, t, partials,
+                       ticket, out, Q, P);
     return hipGetLastError();
 }
 
