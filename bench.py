@@ -25,6 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MAD_PEAK_TOPS = 30.0     # v_mad_u64_u32 lane-ops/s, 256 CUs x 48.8 per clock x 2.4 GHz (profiles/r01/microbench_gfx950.txt)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 LOG_N = 24                # BASELINE.json config[1]
 LDE_LOG_N, LDE_FACTOR = 22, 8   # BASELINE.json config[2]
@@ -200,6 +201,19 @@ def main():
                               "launches_per_transform": passes,
                               "alg_bytes_per_launch": alg_bytes_per_launch,
                               "note": "integer-ALU-bound kernel (v_mad_u64_u32); HBM fraction reported as required"}
+        # the resource that actually binds: v_mad_u64_u32 issue.  Products per element and transform =
+        # butterflies (0.5 per stage, minus the trivial twiddles of each pass's first two stages) +
+        # inter-pass twiddles (1 for the second pass, 2 from the third on); 162 mads per 9 x 29 product,
+        # 9 more per element where a pass reduces its output.  Peak = bench/microbench.hip on this part.
+        base, rem = divmod(log_n, passes)
+        radices = [base + (1 if i < rem else 0) for i in range(passes)]
+        products = sum(0.5 * r - (0.75 if r % 2 == 0 else 0.5) for r in radices) + sum(min(i, 2) for i in range(passes))
+        mads_per_launch = n * (products * 162 + 9 * passes) / passes
+        result["roofline"]["valu"] = {
+            "bound": "v_mad_u64_u32 issue", "products_per_element": products,
+            "achieved": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
+            "frac": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12 / MAD_PEAK_TOPS,
+            "note": "mads are ~64 % of the kernel's VALU cycles; the VALU as a whole is ~92 % busy (profiles/r01/pmc_summary.md)"}
         if not args.no_extra and world == 1:
             result["extra"] = extra_lde_commit(ctx, torch, stream)
         if not args.no_cpu_baseline and world == 1:
