@@ -10,6 +10,12 @@ The global heap layout is preserved: local node `w + j` of a local level of widt
 
 `lde_commit_distributed`: zero-padded 6-step transform (`sixstep_ntt`) followed by the distributed
 commit — BASELINE config[2]'s shape across a node.
+
+`lde_by_cosets_distributed`: the reference's own LDE schedule (`lde_using_multiple_cosets`,
+src/polynomials/mod.rs:418-482: coset i of `factor` is an independent size-n transform of
+coeffs * (W^i)^j) with the cosets dealt round-robin to the ranks — no communication until the
+interleave `out[idx] = res[idx % f][idx / f]` (:466-479), which is ONE all-to-all (the 6-step route
+needs three).  The coefficients (n elements, 1/f of the output) are replicated on every rank.
 """
 import torch
 import torch.distributed as dist
@@ -67,5 +73,45 @@ def lde_commit_distributed(ntt_backend, tree_backend, coeffs_block, log_n, facto
     (lde_block, root, local_nodes, top)."""
     log_big = log_n + (factor.bit_length() - 1)
     lde_block = sixstep_ntt(ntt_backend, coeffs_block, log_big, omega_big, rank, world, group)
+    root, local_nodes, top = merkle_commit_distributed(tree_backend, lde_block, rank, world, group)
+    return lde_block, root, local_nodes, top
+
+
+def lde_by_cosets_distributed(backend, coeffs, log_n, factor, omega_big, rank, world, group=None, coset_shift=None):
+    """`coeffs`: all n = 1 << log_n coefficients (replicated on every rank), shape (n, 4).  `omega_big`:
+    generator W of the size n*factor domain.  `coset_shift`: g for coset_lde (values at g * W^idx), None
+    for lde.  Needs world | factor and world | n.  Returns this rank's natural block of the n*factor
+    values, shape (n*factor/world, 4) — what `merkle_commit_distributed` takes."""
+    n, f, P = 1 << log_n, factor, world
+    assert f % P == 0 and n % P == 0, "world size must divide the LDE factor and the polynomial size"
+    fp, kb = f // P, n // P
+    omega = backend.pow(omega_big, f)                    # generator of the size-n domain
+    res = []
+    for t in range(fp):
+        i = rank + t * P                                 # my cosets: i = rank, rank + P, ...
+        gen = backend.pow(omega_big, i)
+        if coset_shift is not None:
+            gen = backend.mul(gen, coset_shift)
+        buf = coeffs.clone()
+        if i != 0 or coset_shift is not None:
+            backend.distribute_powers(buf, gen)          # c_j * (g W^i)^j
+        res.append(backend.batched_ntt(buf, 1, log_n, omega))   # res[t][k] = out[k*f + i]
+    a = torch.stack(res)                                 # (fp, n, 4)
+    # rank d owns idx in [d*n*f/P, ...) = k in [d*kb, (d+1)*kb), every coset: slab d = my cosets on that k range
+    send = a.view(fp, P, kb, 4).permute(1, 0, 2, 3).contiguous().view(P, fp * kb, 4)
+    if P == 1:
+        recv = send
+    else:
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+    # slab s came from rank s and holds cosets i = s + t*P: out_local[(k - k0)*f + t*P + s]
+    return recv.view(P, fp, kb, 4).permute(2, 1, 0, 3).contiguous().view(kb * f, 4)
+
+
+def lde_commit_by_cosets_distributed(ntt_backend, tree_backend, coeffs, log_n, factor, omega_big, rank, world,
+                                     group=None, coset_shift=None):
+    """LDE by cosets (one all-to-all) + distributed Merkle commit (one 32-byte all-gather)."""
+    lde_block = lde_by_cosets_distributed(ntt_backend, coeffs, log_n, factor, omega_big, rank, world, group,
+                                          coset_shift)
     root, local_nodes, top = merkle_commit_distributed(tree_backend, lde_block, rank, world, group)
     return lde_block, root, local_nodes, top

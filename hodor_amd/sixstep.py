@@ -36,8 +36,15 @@ class HipBackend:
         self.ctx.twiddle_mul_dev(buf, rows, cols, row0, omega, log_order, scale=scale, stream=self.stream)
         return buf
 
+    def distribute_powers(self, buf, g):
+        self.ctx.distribute_powers_dev(buf, buf.shape[0], g, stream=self.stream)
+        return buf
+
     def pow(self, a, e):
         return self.ctx.pow(a, e)
+
+    def mul(self, a, b):
+        return self.ctx.mul(a, b)
 
     def inverse(self, a):
         return self.ctx.inverse(a)

@@ -791,6 +791,32 @@ def test_distributed_commit_single_rank_on_device(gpu_ctxs, oracles):
     assert ctx.hash_leaf(array_to_ints(exp[:1])[0]) == O.hash_leaf(array_to_ints(exp[:1])[0])
 
 
+@pytest.mark.parametrize("coset", [False, True])
+def test_lde_by_cosets_single_rank_on_device(gpu_ctxs, oracles, coset):
+    """hodor_amd/distributed.py, the coset-dealt LDE (src/polynomials/mod.rs:418-482 schedule, one
+    all-to-all) with the HIP backends at world = 1: == fused single-transform LDE == oracle."""
+    import torch
+    from hodor_amd.distributed import HipTreeBackend, lde_commit_by_cosets_distributed
+    from hodor_amd.sixstep import HipBackend
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n, factor = 17, 8                                  # large enough for the table-driven distribute_powers
+    n = 1 << log_n
+    coeffs = O.random_elements(n, 2718)
+    d = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    _, _, Omega = O.domain(n * factor)
+    shift = O.const("generator") if coset else None
+    lde, root, nodes, top = lde_commit_by_cosets_distributed(HipBackend(ctx), HipTreeBackend(ctx), d, log_n, factor,
+                                                             Omega, 0, 1, coset_shift=shift)
+    fused = torch.empty((n * factor, 4), dtype=torch.int64, device="cuda")
+    ctx.poly_lde_dev(d, fused, log_n, factor, coset=coset)
+    ctx.synchronize()
+    assert torch.equal(lde, fused)
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), coeffs)          # input untouched
+    exp = O.poly_lde(coeffs, factor, coset)
+    assert np.array_equal(lde.cpu().numpy().view(np.uint64), exp)
+    assert root == bytes(O.iop_create(exp)[1])
+
+
 # ---------------------------------------------------------------- batched multi-column LDE + commit (§8 f.4)
 @pytest.mark.parametrize("log_n,factor,batch", [(4, 4, 3), (10, 8, 5), (13, 16, 4)])
 def test_batched_lde_and_commit(gpu_ctxs, oracles, log_n, factor, batch):

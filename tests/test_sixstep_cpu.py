@@ -48,8 +48,17 @@ class OracleBackend:
         arr[:] = ints_to_array(vals)
         return buf
 
+    def distribute_powers(self, buf, g):
+        arr = np.ascontiguousarray(self._np(buf))
+        self.O.distribute_powers(arr, g)
+        self._np(buf)[:] = arr
+        return buf
+
     def pow(self, a, e):
         return self.O.pow(a, e)
+
+    def mul(self, a, b):
+        return self.O.mul(a, b)
 
     def inverse(self, a):
         return self.O.inverse(a)
@@ -153,6 +162,50 @@ def test_distributed_lde_commit_matches_single_device(world, log_n, factor):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_commit_worker, args=(world, _free_port(), log_n, factor, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r] == (True, True, True, True), (r, ret[r])
+
+
+# ---------------------------------------------------------------- LDE dealt by cosets (one all-to-all) + commit
+def _coset_worker(rank, world, port, log_n, factor, coset, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hodor_amd.distributed import global_node_index, lde_commit_by_cosets_distributed
+        be = OracleBackend()
+        O = be.O
+        n = 1 << log_n
+        big = n * factor
+        coeffs = O.random_elements(n, 991)                    # replicated: same seed on every rank
+        _, _, Omega = O.domain(big)
+        shift = O.const("generator") if coset else None
+        d = torch.from_numpy(coeffs.copy().view(np.int64))
+        lde_block, root, local_nodes, top = lde_commit_by_cosets_distributed(
+            be, OracleTreeBackend(O), d, log_n, factor, Omega, rank, world, coset_shift=shift)
+        full = O.poly_lde(coeffs, factor, coset)              # lde_using_multiple_cosets / coset_lde (:418-482, :544-609)
+        nodes = O.iop_create(full)
+        blk = big // world
+        ok_lde = np.array_equal(lde_block.numpy().view(np.uint64), full[rank * blk:(rank + 1) * blk])
+        ok_root = root == bytes(nodes[1])
+        ln = local_nodes.numpy()
+        ok_nodes = True
+        w = blk // 2
+        while w >= 1:
+            for j in range(w):
+                ok_nodes &= bytes(ln[w + j]) == bytes(nodes[global_node_index(w + j, w, rank, world)])
+            w //= 2
+        ret[rank] = (ok_lde, ok_root, ok_nodes, np.array_equal(d.numpy().view(np.uint64), coeffs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,factor,coset", [(2, 5, 4, False), (2, 4, 8, True), (4, 6, 8, False), (4, 5, 4, True)])
+def test_lde_by_cosets_distributed_matches_single_device(world, log_n, factor, coset):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_coset_worker, args=(world, _free_port(), log_n, factor, coset, ret), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
         assert ret[r] == (True, True, True, True), (r, ret[r])
