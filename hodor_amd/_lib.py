@@ -5,6 +5,7 @@ anything exposing `.data_ptr()` (torch int64/uint64 CUDA tensors of shape (n, 4)
 address.  No compute happens in Python and there is no CPU fallback.
 """
 import ctypes as C
+import weakref
 import os
 import subprocess
 
@@ -135,6 +136,7 @@ class FriPrototype:
 
     def __init__(self, ctx, handle):
         self.ctx, self.h = ctx, handle
+        ctx._protos.add(self)            # a prototype must not outlive its context (hodor_fri_free uses it)
         L = ctx.L
         self.num_steps = int(L.hodor_fri_num_steps(handle))
         roots = np.zeros((self.num_steps + 1, 32), dtype=np.uint8)
@@ -214,7 +216,8 @@ class FriPrototype:
 
     def free(self):
         if self.h:
-            self.ctx.L.hodor_fri_free(self.h)
+            if self.ctx.h:               # the context frees the prototypes it still holds when it closes
+                self.ctx.L.hodor_fri_free(self.h)
             self.h = None
 
     def __del__(self):
@@ -263,6 +266,7 @@ class Context:
     def __init__(self, modulus=BN256_FR_MODULUS, generator=BN256_FR_GENERATOR, device=0):
         self.L = lib()
         self.h = C.c_void_p()
+        self._protos = weakref.WeakSet()
         mod = (C.c_uint64 * 4)(*_limbs(modulus))
         rc = self.L.hodor_ctx_create(mod, C.c_uint64(generator), C.c_int(device), C.byref(self.h))
         if rc != OK:
@@ -277,6 +281,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for proto in list(self._protos):
+                proto.free()
             self.L.hodor_ctx_destroy(self.h)
             self.h = None
 

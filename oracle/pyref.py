@@ -55,6 +55,9 @@ class Field:
 
 BN256 = Field(BN256_FR_MODULUS, BN256_FR_GENERATOR)
 EXPERIMENTS = Field(EXPERIMENTS_FR_MODULUS, EXPERIMENTS_FR_GENERATOR)
+# not a field of the reference: the BN254 scalar field (2-adicity 28, p mod 2^29 != 1), a third modulus
+# for the tests so that "the modulus is a parameter" is exercised beyond the two fields with S >= 32
+BN254 = Field(21888242871839275222246405745257275088548364400416034343698204186575808495617, 5)
 
 
 def mont_to_bytes(m):

@@ -15,10 +15,13 @@ def pytest_configure(config):
 FIELDS = {
     "bn256": (52435875175126190479447740508185965837690552500527637822603658699938581184513, 7),
     "experiments": (3618502788666131213697322783095070105623107215331596699973092056135872020481, 3),
+    # not a field of the reference: the BN254 scalar field (254 bits, 2-adicity 28, p mod 2^29 != 1) keeps
+    # the "modulus is a run-time parameter" claim honest — both reference fields have S >= 32
+    "bn254": (21888242871839275222246405745257275088548364400416034343698204186575808495617, 5),
 }
 
 
-@pytest.fixture(scope="session", params=["bn256", "experiments"])
+@pytest.fixture(scope="session", params=["bn256", "experiments", "bn254"])
 def field_name(request):
     return request.param
 

@@ -22,7 +22,7 @@ def hx(v):
 def main():
     out = {"_provenance": "oracle/pyref.py (Python big-int + hashlib.blake2s restatement); "
                           "NOT produced by the Rust reference"}
-    for name, F in (("bn256", P.BN256), ("experiments", P.EXPERIMENTS)):
+    for name, F in (("bn256", P.BN256), ("experiments", P.EXPERIMENTS), ("bn254", P.BN254)):
         rng = random.Random(0x484F444F52 + len(name))
         fld = {"modulus": hx(F.p), "generator": F.g, "S": F.S, "R": hx(F.R),
                "root_of_unity": hx(F.root_of_unity), "cases": {}}

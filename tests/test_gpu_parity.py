@@ -13,7 +13,7 @@ from oracle.oracle import array_to_ints, ints_to_array
 
 pytestmark = pytest.mark.gpu
 
-PYF = {"bn256": P.BN256, "experiments": P.EXPERIMENTS}
+PYF = {"bn256": P.BN256, "experiments": P.EXPERIMENTS, "bn254": P.BN254}
 
 
 def _digest(a):

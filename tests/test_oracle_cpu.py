@@ -12,7 +12,7 @@ import pytest
 from oracle import pyref as P
 from oracle.oracle import array_to_ints, ints_to_array
 
-PYF = {"bn256": P.BN256, "experiments": P.EXPERIMENTS}
+PYF = {"bn256": P.BN256, "experiments": P.EXPERIMENTS, "bn254": P.BN254}
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hodor_golden.json")))
 
 
