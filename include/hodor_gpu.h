@@ -54,6 +54,8 @@ typedef struct {
  * `modulus` must be an odd prime with 2^239 < p < 2^255 (4-limb ff_ce field, R = 2^256; the reference's
  * two 4-limb fields have 255 and 252 bits). */
 int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
+/* Destroy after every prototype obtained from this context has been freed (hodor_fri_free hands the
+ * prototype's device slab back to its context) and no call on it is in flight. */
 void hodor_ctx_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
@@ -117,7 +119,7 @@ int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_f
  * The result mirrors FRIProofPrototype field for field (src/fri/mod.rs:106-117). */
 int  hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
                       size_t output_coeffs_at_degree_plus_one, hodor_fri_proto **out);
-void hodor_fri_free(hodor_fri_proto *p);
+void hodor_fri_free(hodor_fri_proto *p);   /* before hodor_ctx_destroy of the context it came from */
 size_t hodor_fri_num_steps(const hodor_fri_proto *p);
 /* roots: l0 root followed by the intermediate roots -> (num_steps + 1) x 32 bytes (get_roots, src/fri/mod.rs:120-128) */
 int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots);
