@@ -376,6 +376,28 @@ def test_fri_commit_benchmark_size_is_accepted_by_the_verifiers(gpu_ctxs, oracle
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("log_code", [6, 10, 13, 17])
+def test_repeated_commits_are_identical(gpu_ctxs, oracles, log_code):
+    """The fused kernels hand data between phases through LDS and global memory inside one workgroup; a
+    missing barrier would show as run-to-run differences (bench/soak.py is the long version)."""
+    import torch
+    from bench import random_elements
+    ctx = gpu_ctxs["bn256"]
+    f, log_deg = 8, log_code - 3
+    n = 1 << log_code
+    d_c = random_elements(torch, 1 << log_deg, 31 + log_code)
+    d_lde = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.poly_lde_dev(d_c, d_lde, log_deg, f)
+    seen = set()
+    for _ in range(25):
+        p = ctx.fri_commit_dev(d_lde, n, f, 1)
+        step = p.num_steps // 2
+        seen.add((p.serialized, p.intermediate_values(step, n >> (step + 1)).tobytes(),
+                  p.tree_nodes(step, n >> (step + 1)).tobytes()))
+        p.free()
+    assert len(seen) == 1
+
+
 def test_fri_commit_rejects_zero_steps(gpu_ctxs, oracles):
     import hodor_amd
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
