@@ -1,88 +1,9 @@
 // abi.hip — implementation of include/hodor_gpu.h: context, twiddle cache, NTT planning, and the
 // C entry points that stand where the reference's L2/L3 Rust functions stand.  No CPU fallback: a
 // context without a device refuses every compute call with HODOR_ERR_DEVICE.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <condition_variable>
-#include <cstdlib>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/hodor_gpu.h"
-#include "host_blake2s.hpp"
-#include "host_field.hpp"
-#include "ntt.cuh"
+#include "ctx.hpp"
 
 namespace hodor {
-
-// kernels' host launchers (ntt.hip, pointwise.hip, merkle.hip, fri.hip)
-hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr9 *scale, const Fr9Params &);
-hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
-                            uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
-hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &);
-hipError_t distribute_powers_small_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
-hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
-hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
-hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
-hipError_t unary_launch(hipStream_t, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &);
-hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod,
-                                   uint32_t *zero_flag, const FrParams &);
-hipError_t batchinv_backward_launch(hipStream_t, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,
-                                    const uint4 *prod_inv, const FrParams &);
-unsigned evaluate_at_table_blocks(uint32_t log_n);
-hipError_t evaluate_at_table_launch(hipStream_t, const uint4 *a, uint64_t n, uint32_t log_n, const TwoLevel &t,
-                                    uint4 *partials, uint32_t *ticket, uint4 *out, const Fr9Params &, const FrParams &);
-hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
-                              uint32_t *ticket, uint4 *out, const FrParams &);
-hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
-                              const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
-hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &,
-                               uint32_t batch = 1, const FoldArgs *fold = nullptr, const Fr9Params *Q = nullptr);
-bool merkle_fuses_fold(uint64_t n);
-hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
-                            uint64_t index, uint4 *out, const B2Mid &);
-hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, uint4 *root_out, const Fr &r2,
-                            uint32_t shave_bits, const FrParams &);
-hipError_t fri_round_table_launch(hipStream_t, const uint4 *nodes, uint4 *chal_out, uint4 *root_out,
-                                  const uint4 *hi, uint4 *hi_out, uint64_t count, const Fr9 &c16, const Fr &r2,
-                                  uint32_t shave, const Fr9Params &, const FrParams &);
-hipError_t fri_tail_launch(hipStream_t, const FriTailArgs &, const Fr9 &c16, const Fr &r2, const B2Mid &,
-                           const Fr9Params &, const FrParams &);
-hipError_t fri_fold_launch(hipStream_t, const FoldArgs &, const Fr9Params &);
-
-static Fr to_dev(const HFr &a)
-{
-    Fr r;
-    for (int i = 0; i < 4; i++) {
-        r.v[2 * i] = (uint32_t)a.l[i];
-        r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
-    }
-    return r;
-}
-
-// split a 256-bit integer (4 x u64) into 9 limbs of 29 bits
-static void split29(const uint64_t l[4], uint32_t out[9])
-{
-    for (int i = 0; i < 9; i++) {
-        int bit = 29 * i, w = bit >> 6, s = bit & 63;
-        uint64_t v = l[w] >> s;
-        if (s > 35 && w < 3) v |= l[w + 1] << (64 - s);
-        out[i] = (uint32_t)(v & 0x1fffffffu);
-    }
-}
-
-// R-form host element (x * 2^256) -> R'-form 9 x 29-bit multiplier operand (x * 2^261 mod p)
-static Fr9 to_dev9(const HostField &F, const HFr &a)
-{
-    HFr t = a;
-    for (int i = 0; i < 5; i++) t = F.add(t, t);
-    Fr9 r;
-    split29(t.l, r.v);
-    return r;
-}
 
 // constants of fr9.cuh for this modulus
 static void make_params9(const HostField &F, Fr9Params *Q)
@@ -143,110 +64,7 @@ static void make_params9(const HostField &F, Fr9Params *Q)
     Q->mu = mu;
 }
 
-struct PowTable {
-    HFr base;
-    uint32_t log_n;
-    uint32_t lo_bits;
-    uint32_t fmt;          // 0: 32-byte R-form entries, 1: 48-byte 9 x 29-bit R'-form entries
-    HFr hi_mult;           // every `hi` entry is multiplied by this (one, or n^-1 for the last iNTT pass)
-    uint4 *lo, *hi;
-};
-
-struct RadixTable {
-    HFr omega;
-    uint32_t log_n, log_r;
-    uint4 *rtw;
-};
-
 }  // namespace hodor
-
-using namespace hodor;
-
-struct hodor_ctx {
-    int device = -1;
-    HostField F;
-    FrParams P;
-    Fr9Params Q;
-    B2Mid mid;
-    hipStream_t stream = nullptr;
-    std::mutex mu;
-    std::vector<PowTable> pow_tables;
-    std::vector<RadixTable> radix_tables;
-    void *scratch[2] = {nullptr, nullptr};
-    size_t scratch_bytes[2] = {0, 0};
-    // slice API staging: IO_LANES independent (copy stream, in/out device buffers) sets, so that
-    // concurrent callers (src/arp/per_register/mod.rs:43-49 calls best_fft from several scoped threads)
-    // overlap one caller's upload with another's kernels and a third's download; see with_device_copy
-    struct IoLane {
-        hipStream_t stream = nullptr;
-        hipEvent_t uploaded = nullptr, computed = nullptr;
-        void *buf[2] = {nullptr, nullptr};   // grow-only (in / out)
-        size_t bytes[2] = {0, 0};
-        bool busy = false;
-    };
-    static constexpr int IO_LANES = 3;
-    IoLane lanes[IO_LANES];
-    std::mutex lane_mu;
-    std::condition_variable lane_cv;
-    void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
-    size_t fri_slab_bytes = 0;
-    uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
-    uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
-    std::string err;
-};
-
-struct hodor_fri_proto {
-    hodor_ctx *ctx;
-    size_t n, num_steps, lde_factor, out_deg, initial_degree_plus_one;
-    void *slab = nullptr;                     // one device allocation holding everything below
-    size_t slab_bytes = 0;
-    void *l0_nodes = nullptr;                 // device, n*32
-    std::vector<void *> inter_values;         // device
-    std::vector<void *> inter_nodes;          // device
-    std::vector<size_t> inter_sizes;
-    std::vector<uint8_t> roots;               // host: (num_steps+1)*32
-    std::vector<hodor_fr> challenges;         // host: num_steps
-    std::vector<hodor_fr> final_coeffs;       // host
-    uint8_t final_root[32];
-};
-
-#define HIPCHK(expr)                                                                  \
-    do {                                                                              \
-        hipError_t e__ = (expr);                                                      \
-        if (e__ != hipSuccess) {                                                      \
-            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);            \
-            return HODOR_ERR_DEVICE;                                                  \
-        }                                                                             \
-    } while (0)
-
-#define NEED_DEVICE()                                                                 \
-    do {                                                                              \
-        if (!ctx) return HODOR_ERR_INVALID;                                           \
-        if (ctx->device < 0) { ctx->err = "context has no HIP device"; return HODOR_ERR_DEVICE; } \
-        HIPCHK(hipSetDevice(ctx->device));                                            \
-    } while (0)
-
-static inline HFr to_h(const hodor_fr *a)
-{
-    HFr r;
-    memcpy(r.l, a->l, 32);
-    return r;
-}
-static inline void from_h(const HFr &a, hodor_fr *out) { memcpy(out->l, a.l, 32); }
-static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
-static inline uint32_t log2u(size_t n)
-{
-    uint32_t r = 0;
-    while (n > 1) { n >>= 1; r++; }
-    return r;
-}
-
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // tables
@@ -263,7 +81,7 @@ static int free_tables(hodor_ctx *ctx)
 
 // Cache eviction happens only here, at the start of an operation and before it has looked up any
 // table: evicting later would free tables the same operation already holds pointers to.
-static int trim_table_cache(hodor_ctx *ctx)
+int trim_table_cache(hodor_ctx *ctx)
 {
     if (ctx->pow_tables.size() > 40 || ctx->radix_tables.size() > 80) return free_tables(ctx);
     return HODOR_OK;
@@ -271,8 +89,8 @@ static int trim_table_cache(hodor_ctx *ctx)
 
 // base^e = lo[e & mask] * hi[e >> lo_bits] for e < 2^log_n
 // fmt 1 = 9 x 29-bit R'-form entries for k_ntt_pass, fmt 0 = 32-byte R-form entries (fold, twiddle_mul)
-static int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
-                         uint32_t lo_bits = 0xffffffffu, const HFr *hi_mult_p = nullptr)
+int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt, uint32_t lo_bits,
+                  const HFr *hi_mult_p)
 {
     if (lo_bits > log_n) lo_bits = (log_n + 1) / 2;
     const HFr hi_mult = hi_mult_p ? *hi_mult_p : ctx->F.one;
@@ -358,7 +176,7 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
     return hipSuccess;
 }
 
-static int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes)
+int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes)
 {
     if (ctx->scratch_bytes[which] >= bytes) return HODOR_OK;
     if (ctx->scratch[which]) {
@@ -477,7 +295,7 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
     return HODOR_OK;
 }
 
-static int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega)
+int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega)
 {
     uint64_t sz;
     uint32_t k;
@@ -488,10 +306,7 @@ static int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega)
     return HODOR_OK;
 }
 
-enum PolyOp { OP_FFT, OP_COSET_FFT, OP_IFFT, OP_ICOSET_FFT };
-
-static int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
-                          uint32_t log_n, PolyOp op)
+int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op)
 {
     HFr omega;
     int rc = poly_domain(ctx, log_n, &omega);
@@ -618,66 +433,6 @@ extern "C" int hodor_ctx_synchronize(hodor_ctx *ctx)
 }
 
 // ------------------------------------------------------------------------------------------------
-// host scalar helpers
-// ------------------------------------------------------------------------------------------------
-extern "C" int hodor_fr_mul(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
-{
-    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
-    from_h(ctx->F.mul(to_h(a), to_h(b)), out);
-    return HODOR_OK;
-}
-extern "C" int hodor_fr_add(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
-{
-    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
-    from_h(ctx->F.add(to_h(a), to_h(b)), out);
-    return HODOR_OK;
-}
-extern "C" int hodor_fr_sub(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
-{
-    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
-    from_h(ctx->F.sub(to_h(a), to_h(b)), out);
-    return HODOR_OK;
-}
-extern "C" int hodor_fr_pow(const hodor_ctx *ctx, const hodor_fr *a, uint64_t e, hodor_fr *out)
-{
-    if (!ctx || !a || !out) return HODOR_ERR_INVALID;
-    from_h(ctx->F.pow(to_h(a), e), out);
-    return HODOR_OK;
-}
-extern "C" int hodor_fr_inverse(const hodor_ctx *ctx, const hodor_fr *a, hodor_fr *out)
-{
-    if (!ctx || !a || !out) return HODOR_ERR_INVALID;
-    HFr r;
-    if (!ctx->F.inverse(to_h(a), &r)) return HODOR_ERR_INVALID;
-    from_h(r, out);
-    return HODOR_OK;
-}
-extern "C" int hodor_fr_from_repr(const hodor_ctx *ctx, const uint64_t c[4], hodor_fr *out)
-{
-    if (!ctx || !c || !out) return HODOR_ERR_INVALID;
-    HFr r;
-    if (!ctx->F.from_repr(c, &r)) return HODOR_ERR_INVALID;
-    from_h(r, out);
-    return HODOR_OK;
-}
-extern "C" int hodor_fr_into_repr(const hodor_ctx *ctx, const hodor_fr *a, uint64_t c[4])
-{
-    if (!ctx || !a || !c) return HODOR_ERR_INVALID;
-    ctx->F.into_repr(to_h(a), c);
-    return HODOR_OK;
-}
-
-extern "C" int hodor_domain_new_for_size(const hodor_ctx *ctx, uint64_t size, uint64_t *out_size,
-                                         uint32_t *out_log_n, hodor_fr *out_generator)
-{
-    if (!ctx || !out_size || !out_log_n || !out_generator) return HODOR_ERR_INVALID;
-    HFr g;
-    if (!ctx->F.domain(size, out_size, out_log_n, &g)) return HODOR_ERR_SIZE;
-    from_h(g, out_generator);
-    return HODOR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 // device API
 // ------------------------------------------------------------------------------------------------
 extern "C" int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr)
@@ -704,12 +459,6 @@ extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *de
     NEED_DEVICE();
     HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
     return HODOR_OK;
-}
-
-static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
-{
-    (void)ctx;
-    return (hipStream_t)stream;   // NULL selects the HIP default (null) stream, as for any HIP API
 }
 
 extern "C" int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
@@ -993,180 +742,6 @@ extern "C" int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr
     return HODOR_OK;
 }
 
-// The prototype's device buffers (l0 tree, every intermediate vector and tree, the small result block)
-// are carved from ONE slab; a freed slab is parked on the context and reused by the next commit of a
-// size that fits, so a prover committing polynomial after polynomial pays hipMalloc once.
-extern "C" void hodor_fri_free(hodor_fri_proto *p)
-{
-    if (!p) return;
-    hodor_ctx *ctx = p->ctx;
-    if (ctx && ctx->device >= 0 && p->slab) {
-        (void)hipSetDevice(ctx->device);
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (!ctx->fri_slab) {
-            ctx->fri_slab = p->slab;
-            ctx->fri_slab_bytes = p->slab_bytes;
-        } else if (p->slab_bytes > ctx->fri_slab_bytes) {
-            (void)hipFree(ctx->fri_slab);
-            ctx->fri_slab = p->slab;
-            ctx->fri_slab_bytes = p->slab_bytes;
-        } else {
-            (void)hipFree(p->slab);
-        }
-    }
-    delete p;
-}
-
-extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
-                                    size_t lde_factor, size_t out_deg, hodor_fri_proto **out)
-{
-    NEED_DEVICE();
-    if (!lde_values || !out) return HODOR_ERR_INVALID;
-    if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;
-    size_t initial_degree_plus_one = n / lde_factor;
-    if (initial_degree_plus_one < 2 * out_deg) {   // num_steps == 0: the reference panics at roots.pop() (:124)
-        ctx->err = "fri_commit: needs at least one folding step";
-        return HODOR_ERR_SIZE;
-    }
-    size_t num_steps = log2u(initial_degree_plus_one / out_deg);
-    if ((n >> num_steps) < 2) return HODOR_ERR_SIZE;
-    uint32_t log_n = log2u(n);
-    HFr omega, omega_inv;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    int rc = poly_domain(ctx, log_n, &omega);
-    if (rc) return rc;
-    ctx->F.inverse(omega, &omega_inv);
-    hipStream_t stream = pick_stream(ctx, stream_);
-
-    hodor_fri_proto *p = new (std::nothrow) hodor_fri_proto();
-    if (!p) return HODOR_ERR_INVALID;
-    p->ctx = ctx;
-    p->n = n;
-    p->num_steps = num_steps;
-    p->lde_factor = lde_factor;
-    p->out_deg = out_deg;
-    p->initial_degree_plus_one = initial_degree_plus_one;
-
-#define FRICHK(expr)                                                                   \
-    do {                                                                               \
-        hipError_t e__ = (expr);                                                       \
-        if (e__ != hipSuccess) {                                                       \
-            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);             \
-            fri_release(p);                                                            \
-            return HODOR_ERR_DEVICE;                                                   \
-        }                                                                              \
-    } while (0)
-
-    // slab layout: l0 tree | per step: values, tree | small block (challenges, roots, final coeffs)
-    size_t fin_n = n >> num_steps;
-    size_t small_bytes = 32 * (num_steps + 1) * 2 + 32 * fin_n * 2;
-    const uint32_t winv_lo_bits = (log_n + 1) / 2;
-    const size_t hi_cnt = (size_t)1 << (log_n - winv_lo_bits);
-    small_bytes += 48 * hi_cnt;   // per-round copy of the w^-1 `hi` table scaled by beta/2
-    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    size_t need = up(n * 32) + up(small_bytes);
-    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
-    auto fri_release = [&](hodor_fri_proto *q) {   // error path: the ctx mutex is already held
-        if (q->slab) (void)hipFree(q->slab);
-        delete q;
-    };
-    if (ctx->fri_slab && ctx->fri_slab_bytes >= need) {
-        p->slab = ctx->fri_slab;
-        p->slab_bytes = ctx->fri_slab_bytes;
-        ctx->fri_slab = nullptr;
-        ctx->fri_slab_bytes = 0;
-    } else {
-        FRICHK(hipMalloc(&p->slab, need));
-        p->slab_bytes = need;
-    }
-    uint8_t *cursor = (uint8_t *)p->slab;
-    auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
-    p->l0_nodes = carve(n * 32);
-    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) {
-        p->inter_values.push_back(carve(sz * 32));
-        p->inter_nodes.push_back(carve(sz * 32));
-        p->inter_sizes.push_back(sz);
-    }
-    uint8_t *d_small = (uint8_t *)carve(small_bytes);
-    uint4 *d_chal = (uint4 *)d_small;
-    uint4 *d_roots = (uint4 *)(d_small + 32 * (num_steps + 1));
-    uint4 *d_fin = (uint4 *)(d_small + 64 * (num_steps + 1));
-    uint4 *d_hi_beta = (uint4 *)(d_small + 64 * (num_steps + 1) + 64 * fin_n);
-    const Fr9 c16 = to_dev9(ctx->F, ctx->F.from_u64(16));
-
-    TwoLevel winv;
-    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv, 1, winv_lo_bits))) { fri_release(p); return rc; }
-    uint32_t shave = 256 - ctx->F.capacity;
-    Fr r2 = to_dev(ctx->F.r2);
-
-    FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
-
-    const uint4 *values = (const uint4 *)lde_values;
-    size_t next_size = n / 2;
-    static int tail_on = -1;   // HODOR_FRI_TAIL=0: every round through the multi-launch path (A/B, debugging)
-    if (tail_on < 0) {
-        const char *e = getenv("HODOR_FRI_TAIL");
-        tail_on = e ? atoi(e) : 1;
-    }
-    // the challenge of round i (:51, :109) is derived from tree i-1 at the start of round i
-    const uint4 *prev_nodes = (const uint4 *)p->l0_nodes;
-    bool tail_done = false;
-    for (size_t i = 0; i < num_steps; i++) {                                                             // :61
-        if (tail_on && next_size <= (size_t)FRI_TAIL_THREADS && num_steps - i <= (size_t)FRI_TAIL_MAX_ROUNDS) {
-            FriTailArgs T = {};   // the remaining rounds fit one workgroup: one launch for all of them
-            FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, r2, shave, ctx->P));
-            T.src = values;
-            T.rounds = (uint32_t)(num_steps - i);
-            for (uint32_t k = 0; k < T.rounds; k++) {
-                T.values[k] = (uint4 *)p->inter_values[i + k];
-                T.nodes[k] = (uint4 *)p->inter_nodes[i + k];
-            }
-            T.chal = d_chal;
-            T.roots = d_roots;
-            T.lo = winv.lo;
-            T.hi = winv.hi;
-            T.lo_bits = winv.lo_bits;
-            T.first_round = (uint32_t)i;
-            T.half0 = (uint32_t)next_size;
-            T.shave = shave;
-            FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P));
-            values = (const uint4 *)p->inter_values[num_steps - 1];
-            tail_done = true;
-            break;
-        }
-        void *next = p->inter_values[i], *nodes = p->inter_nodes[i];
-        FRICHK(fri_round_table_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, winv.hi, d_hi_beta, hi_cnt,
-                                      c16, r2, shave, ctx->Q, ctx->P));
-        FoldArgs fold = {values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits, (uint32_t)i};
-        const bool fused = merkle_fuses_fold(next_size);   // small rounds: fold inside the tree's leaf launch
-        if (!fused) FRICHK(fri_fold_launch(stream, fold, ctx->Q));                                        // :70-104
-        FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid, 1,
-                                   fused ? &fold : nullptr, &ctx->Q));                                   // :106
-        prev_nodes = (const uint4 *)nodes;
-        values = (const uint4 *)next;
-        next_size >>= 1;
-    }
-    if (!tail_done)   // the last tree's root (and the challenge the reference computes and pops, :120)
-        FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * num_steps, d_roots + 2 * num_steps, r2, shave, ctx->P));
-    // final: values -> ifft -> truncate (:130-145)
-    rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
-    if (rc) { fri_release(p); return rc; }
-
-    // challenges | roots | final coefficients sit back to back in the slab's small block: one copy
-    std::vector<uint8_t> small(64 * (num_steps + 1) + 32 * out_deg);
-    FRICHK(hipMemcpyAsync(small.data(), d_small, small.size(), hipMemcpyDeviceToHost, stream));
-    FRICHK(hipStreamSynchronize(stream));
-    p->roots.assign(small.begin() + 32 * (num_steps + 1), small.begin() + 64 * (num_steps + 1));
-    p->challenges.resize(num_steps);
-    memcpy(p->challenges.data(), small.data(), 32 * num_steps);
-    p->final_coeffs.resize(out_deg);
-    memcpy(p->final_coeffs.data(), small.data() + 64 * (num_steps + 1), 32 * out_deg);
-    memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
-#undef FRICHK
-    *out = p;
-    return HODOR_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // slice API: host memory in, host memory out
 // ------------------------------------------------------------------------------------------------
@@ -1293,495 +868,4 @@ extern "C" int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n,
         HIPCHK(merkle_build_launch(ctx->stream, s, d, n, ctx->mid));
         return HODOR_OK;
     }, true);
-}
-
-extern "C" int hodor_iop_challenge(const hodor_ctx *ctx, const uint8_t root[32], hodor_fr *out)
-{
-    if (!ctx || !root || !out) return HODOR_ERR_INVALID;
-    uint64_t repr[4];
-    for (int i = 0; i < 4; i++) {   // read_be
-        uint64_t w = 0;
-        for (int b = 0; b < 8; b++) w = (w << 8) | root[8 * i + b];
-        repr[3 - i] = w;
-    }
-    uint32_t shave = 256 - ctx->F.capacity;
-    repr[3] &= 0xffffffffffffffffull >> (shave % 64);
-    HFr r;
-    if (!ctx->F.from_repr(repr, &r)) return HODOR_ERR_INVALID;   // "in a field" expect
-    from_h(r, out);
-    return HODOR_OK;
-}
-
-static void host_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32])
-{
-    HostBlake2s::finish(ctx->mid.h, (const uint8_t *)leaf->l, 32, out);   // LE limbs == memory image
-}
-static void host_hash_node(const hodor_ctx *ctx, const uint8_t *l, const uint8_t *r, uint8_t out[32])
-{
-    uint8_t buf[64];
-    memcpy(buf, l, 32);
-    memcpy(buf + 32, r, 32);
-    HostBlake2s::finish(ctx->mid.h, buf, 64, out);
-}
-
-// IopTreeHasher::{hash_leaf, hash_node} (src/iop/blake2s_trivial_iop.rs:81-104) for single digests on
-// the host: the top log2(P) levels of a tree whose subtrees live on P GPUs, path checks, ...
-extern "C" int hodor_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32])
-{
-    if (!ctx || !leaf || !out) return HODOR_ERR_INVALID;
-    host_hash_leaf(ctx, leaf, out);
-    return HODOR_OK;
-}
-extern "C" int hodor_hash_node(const hodor_ctx *ctx, const uint8_t left[32], const uint8_t right[32], uint8_t out[32])
-{
-    if (!ctx || !left || !right || !out) return HODOR_ERR_INVALID;
-    host_hash_node(ctx, left, right, out);
-    return HODOR_OK;
-}
-
-extern "C" int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
-                              size_t tree_index, uint8_t *path, size_t *path_len)
-{
-    if (!ctx || !nodes || !leafs || !path || !path_len) return HODOR_ERR_INVALID;
-    if (!is_pow2(n) || n < 2 || tree_index >= n) return HODOR_ERR_SIZE;
-    size_t cnt = 0;
-    host_hash_leaf(ctx, &leafs[tree_index ^ 1], path);
-    cnt++;
-    size_t idx = tree_index >> 1;
-    for (size_t w = n / 2; w >= 2; w /= 2) {
-        memcpy(path + 32 * cnt, nodes + 32 * (w + (idx ^ 1)), 32);
-        cnt++;
-        idx >>= 1;
-    }
-    *path_len = cnt;
-    return HODOR_OK;
-}
-
-extern "C" int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *leaf,
-                                const uint8_t *path, size_t path_len, size_t tree_index, int *ok)
-{
-    if (!ctx || !root || !leaf || (!path && path_len) || !ok) return HODOR_ERR_INVALID;
-    uint8_t h[32], t[32];
-    host_hash_leaf(ctx, leaf, h);
-    size_t idx = tree_index;
-    for (size_t i = 0; i < path_len; i++) {
-        if ((idx & 1) == 0) host_hash_node(ctx, h, path + 32 * i, t);
-        else host_hash_node(ctx, path + 32 * i, h, t);
-        memcpy(h, t, 32);
-        idx >>= 1;
-    }
-    *ok = memcmp(h, root, 32) == 0;
-    return HODOR_OK;
-}
-
-extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
-                                size_t out_deg, hodor_fri_proto **out)
-{
-    NEED_DEVICE();
-    if (!lde_values || !out) return HODOR_ERR_INVALID;
-    if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
-    DevBuf dv;
-    HIPCHK(hipMalloc(&dv.p, n * 32));
-    HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
-    return hodor_fri_commit_dev(ctx, nullptr, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
-}
-
-// IOP::query on device-resident leaves and tree (src/iop/blake2s_trivial_iop.rs:324-338)
-extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *leafs, const uint8_t *nodes,
-                                   size_t n, size_t natural_index, hodor_fr *value, uint8_t *path,
-                                   size_t *path_len)
-{
-    NEED_DEVICE();
-    if (!leafs || !nodes || !value || !path || !path_len) return HODOR_ERR_INVALID;
-    if (!is_pow2(n) || n < 2 || natural_index >= n) return HODOR_ERR_SIZE;   // asserts at :325-326
-    hipStream_t stream = pick_stream(ctx, stream_);
-    size_t entries = log2u(n) + 1;
-    DevBuf stage;
-    HIPCHK(hipMalloc(&stage.p, entries * 32));
-    HIPCHK(iop_query_launch(stream, (const uint4 *)(leafs + (natural_index & ~(size_t)1)), (const uint4 *)nodes, n,
-                            natural_index, (uint4 *)stage.p, ctx->mid));
-    std::vector<uint8_t> host(entries * 32);
-    HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    memcpy(value, host.data(), 32);
-    memcpy(path, host.data() + 32, (entries - 1) * 32);
-    *path_len = entries - 1;
-    return HODOR_OK;
-}
-
-// FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53): for the l0 oracle and every
-// intermediate oracle, the two queries of the coset {idx, idx + size/2} (sorted), idx halving as the
-// domain does (Domain::index_and_size_for_next_domain).  Serialised FRIProof (src/fri/mod.rs:139-147):
-//   u64 num_queries | per query: u64 natural_index, value (32 B), u64 path_len, path |
-//   u64 num_roots | roots | u64 n_final | final_coefficients |
-//   u64 initial_degree_plus_one | u64 output_coeffs_at_degree_plus_one | u64 lde_factor
-extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
-                                          size_t natural_first_element_index, uint8_t *buf, size_t cap)
-{
-    if (!p || !lde_values_dev) return 0;
-    hodor_ctx *ctx = p->ctx;
-    if (!ctx || ctx->device < 0 || natural_first_element_index >= p->n) return 0;
-    const size_t rounds = p->num_steps + 1;
-    size_t need = 8, stage_bytes = 0;
-    for (size_t r = 0, sz = p->n; r < rounds; r++, sz >>= 1) {
-        size_t entries = log2u(sz) + 1;
-        need += 2 * (8 + 32 + 8 + (entries - 1) * 32);
-        stage_bytes += 2 * entries * 32;
-    }
-    need += 8 + rounds * 32 + 8 + p->out_deg * 32 + 24;
-    if (!buf || cap < need) return need;
-    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DevBuf stage;
-    if (hipMalloc(&stage.p, stage_bytes) != hipSuccess) return 0;
-    std::vector<size_t> q_index, q_entries;
-    size_t domain_size = p->n, domain_idx = natural_first_element_index, off = 0;
-    for (size_t r = 0; r < rounds; r++) {
-        const hodor_fr *leafs = r == 0 ? lde_values_dev : (const hodor_fr *)p->inter_values[r - 1];
-        const uint4 *nodes = (const uint4 *)(r == 0 ? p->l0_nodes : p->inter_nodes[r - 1]);
-        size_t pair = (domain_idx + domain_size / 2) % domain_size;
-        size_t coset[2] = {domain_idx < pair ? domain_idx : pair, domain_idx < pair ? pair : domain_idx};
-        size_t entries = log2u(domain_size) + 1;
-        for (int k = 0; k < 2; k++) {
-            if (iop_query_launch(ctx->stream, (const uint4 *)(leafs + (coset[k] & ~(size_t)1)), nodes, domain_size,
-                                 coset[k], (uint4 *)((uint8_t *)stage.p + off), ctx->mid) != hipSuccess)
-                return 0;
-            q_index.push_back(coset[k]);
-            q_entries.push_back(entries);
-            off += entries * 32;
-        }
-        size_t next = domain_size / 2;                       // index_and_size_for_next_domain
-        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
-        domain_size = next;
-    }
-    std::vector<uint8_t> host(stage_bytes);
-    if (hipMemcpyAsync(host.data(), stage.p, stage_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess)
-        return 0;
-    size_t o = 0, h = 0;
-    auto put64 = [&](uint64_t v) { memcpy(buf + o, &v, 8); o += 8; };
-    put64(q_index.size());
-    for (size_t q = 0; q < q_index.size(); q++) {
-        put64(q_index[q]);
-        memcpy(buf + o, host.data() + h, 32); o += 32;
-        put64(q_entries[q] - 1);
-        memcpy(buf + o, host.data() + h + 32, (q_entries[q] - 1) * 32); o += (q_entries[q] - 1) * 32;
-        h += q_entries[q] * 32;
-    }
-    put64(rounds);
-    memcpy(buf + o, p->roots.data(), rounds * 32); o += rounds * 32;
-    put64(p->out_deg);
-    memcpy(buf + o, p->final_coeffs.data(), p->out_deg * 32); o += p->out_deg * 32;
-    put64(p->initial_degree_plus_one);
-    put64(p->out_deg);
-    put64(p->lde_factor);
-    return o;
-}
-
-// NaiveFriIop::verify_proof_queries (src/fri/verifier.rs:131-289) over the serialised FRIProof that
-// hodor_fri_produce_proof writes.  Host-only (log n hashes and a handful of field operations per
-// round): works on a ctx without a device.  *valid = Ok(true/false); the reference's Err(..) cases
-// (point outside the LDE domain, query count not a multiple of DEGREE = 2, wrong tree index) and a
-// malformed buffer return HODOR_ERR_INVALID.
-extern "C" int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len,
-                                      size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
-                                      int *valid)
-{
-    if (!ctx || !proof || !expected_value_from_oracle || !valid) return HODOR_ERR_INVALID;
-    *valid = 0;
-    size_t o = 0;
-    bool bad = false;
-    auto get64 = [&]() -> uint64_t {
-        uint64_t v = 0;
-        if (o > len || len - o < 8) { bad = true; return 0; }
-        memcpy(&v, proof + o, 8);
-        o += 8;
-        return v;
-    };
-    auto take = [&](uint64_t count) -> const uint8_t * {   // count 32-byte entries
-        if (bad || count > (len - o) / 32) { bad = true; return nullptr; }
-        const uint8_t *r = proof + o;
-        o += (size_t)count * 32;
-        return r;
-    };
-    struct Query { uint64_t index; const uint8_t *value; uint64_t path_len; const uint8_t *path; };
-    uint64_t nq = get64();
-    if (bad || nq > len / 48) return HODOR_ERR_INVALID;
-    std::vector<Query> queries((size_t)nq);
-    for (auto &q : queries) {
-        q.index = get64();
-        q.value = take(1);
-        q.path_len = get64();
-        q.path = take(q.path_len);
-        if (bad) return HODOR_ERR_INVALID;
-    }
-    uint64_t n_roots = get64();
-    const uint8_t *roots = take(n_roots);
-    uint64_t n_final = get64();
-    const uint8_t *final_coeffs = take(n_final);
-    uint64_t initial_degree_plus_one = get64();
-    (void)get64();   // output_coeffs_at_degree_plus_one: carried by the proof, unused by the verifier
-    uint64_t lde_factor = get64();
-    if (bad || o != len) return HODOR_ERR_INVALID;
-
-    const HostField &F = ctx->F;
-    HFr two_inv, omega, omega_inv;
-    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
-    uint64_t size;
-    uint32_t log_size;
-    if (lde_factor && initial_degree_plus_one > ~0ull / lde_factor) return HODOR_ERR_SIZE;
-    if (!F.domain(initial_degree_plus_one * lde_factor, &size, &log_size, &omega)) return HODOR_ERR_SIZE;
-    HFr x = F.pow(omega, natural_element_index);
-    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) return HODOR_ERR_INVALID;
-    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
-    if (queries.size() % 2 != 0) return HODOR_ERR_INVALID;
-
-    auto value_of = [&](const Query &q) { hodor_fr v; memcpy(v.l, q.value, 32); return to_h(&v); };
-    bool have_expected = false;
-    HFr expected = F.one;
-    uint64_t domain_size = size, domain_idx = natural_element_index;
-    const HFr oracle_value = to_h(expected_value_from_oracle);
-    const size_t rounds = std::min<size_t>((size_t)n_roots, queries.size() / 2);   // zip(roots, chunks_exact)
-    for (size_t rnd = 0; rnd < rounds; rnd++) {
-        if (domain_size < 2) return HODOR_ERR_INVALID;
-        const Query *qs = &queries[2 * rnd];
-        const uint8_t *root = roots + 32 * rnd;
-        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
-        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
-        for (int k = 0; k < 2; k++)
-            if (qs[k].index != coset[0] && qs[k].index != coset[1]) return HODOR_OK;          // Ok(false)
-        if (rnd == 0)
-            for (int k = 0; k < 2; k++)
-                if (qs[k].index == natural_element_index && !(value_of(qs[k]) == oracle_value)) return HODOR_OK;
-        for (int k = 0; k < 2; k++)
-            if (qs[k].index != coset[k]) return HODOR_ERR_INVALID;                            // "invalid tree index"
-        for (int k = 0; k < 2; k++) {
-            int ok = 0;
-            hodor_fr leaf;
-            memcpy(leaf.l, qs[k].value, 32);
-            hodor_iop_verify(ctx, root, &leaf, qs[k].path, (size_t)qs[k].path_len, (size_t)qs[k].index, &ok);
-            if (!ok) return HODOR_OK;
-        }
-        hodor_fr ch;
-        if (hodor_iop_challenge(ctx, root, &ch)) return HODOR_ERR_INVALID;
-        const HFr challenge = to_h(&ch);
-        const HFr f_at_omega = value_of(qs[0]), f_at_minus_omega = value_of(qs[1]);
-        if (have_expected) {
-            int hits = 0;
-            HFr supplied = F.one;
-            for (int k = 0; k < 2; k++)
-                if (qs[k].index == domain_idx) { hits++; supplied = value_of(qs[k]); }
-            if (hits != 1 || !(supplied == expected)) return HODOR_OK;
-        }
-        HFr divisor = F.pow(omega_inv, coset[0]);
-        HFr even = F.add(f_at_omega, f_at_minus_omega);
-        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
-        expected = F.mul(F.add(F.mul(odd, challenge), even), two_inv);
-        have_expected = true;
-        uint64_t next = domain_size / 2;                      // index_and_size_for_next_domain
-        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
-        domain_size = next;
-        omega = F.sqr(omega);
-        omega_inv = F.sqr(omega_inv);
-    }
-    if (!have_expected) return HODOR_ERR_INVALID;             // expect("is some")
-    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
-    for (uint64_t i = 0; i < n_final; i++) {
-        hodor_fr c;
-        memcpy(c.l, final_coeffs + 32 * i, 32);
-        acc = F.add(acc, F.mul(power, to_h(&c)));
-        power = F.mul(power, point);
-    }
-    *valid = (acc == expected) ? 1 : 0;
-    return HODOR_OK;
-}
-
-// NaiveFriIop::verify_prototype (src/fri/verifier.rs:10-129): the same folding walk against the
-// prover's own (device-resident) vectors instead of Merkle queries — two elements per round are
-// fetched from the device.  `lde_values_dev` is the codeword the prototype was committed from.
-extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
-                                          size_t natural_element_index, int *valid)
-{
-    if (!p || !lde_values_dev || !valid) return HODOR_ERR_INVALID;
-    hodor_ctx *ctx = p->ctx;
-    NEED_DEVICE();
-    *valid = 0;
-    const HostField &F = ctx->F;
-    HFr two_inv, omega, omega_inv;
-    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
-    uint64_t size;
-    uint32_t log_size;
-    if (!F.domain((uint64_t)p->initial_degree_plus_one * p->lde_factor, &size, &log_size, &omega))
-        return HODOR_ERR_SIZE;
-    HFr x = F.pow(omega, natural_element_index);
-    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) {
-        ctx->err = "initial challenge value is not in the LDE domain";
-        return HODOR_ERR_INVALID;
-    }
-    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    bool have_expected = false;
-    HFr expected = F.one;
-    uint64_t domain_size = size, domain_idx = natural_element_index;
-    auto fetch = [&](const hodor_fr *base, uint64_t i, HFr *out) -> bool {
-        hodor_fr v;
-        if (hipMemcpy(&v, base + i, 32, hipMemcpyDeviceToHost) != hipSuccess) return false;
-        *out = to_h(&v);
-        return true;
-    };
-    // zip(leaf_values ++ intermediate_values, challenges): num_steps rounds
-    for (size_t rnd = 0; rnd < p->num_steps; rnd++) {
-        const hodor_fr *values = rnd == 0 ? lde_values_dev : (const hodor_fr *)p->inter_values[rnd - 1];
-        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
-        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
-        HFr f_at_omega, f_at_minus_omega;
-        if (!fetch(values, coset[0], &f_at_omega) || !fetch(values, coset[1], &f_at_minus_omega)) {
-            ctx->err = "verify_prototype: device read failed";
-            return HODOR_ERR_DEVICE;
-        }
-        if (have_expected) {
-            const HFr &supplied = domain_idx == coset[0] ? f_at_omega : f_at_minus_omega;
-            if (!(supplied == expected)) return HODOR_OK;     // Ok(false)
-        }
-        hodor_fr ch = p->challenges[rnd];
-        HFr divisor = F.pow(omega_inv, coset[0]);
-        HFr even = F.add(f_at_omega, f_at_minus_omega);
-        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
-        expected = F.mul(F.add(F.mul(odd, to_h(&ch)), even), two_inv);
-        have_expected = true;
-        uint64_t next = domain_size / 2;
-        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
-        domain_size = next;
-        omega = F.sqr(omega);
-        omega_inv = F.sqr(omega_inv);
-    }
-    if (!have_expected) return HODOR_ERR_INVALID;
-    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
-    for (size_t i = 0; i < p->final_coeffs.size(); i++) {
-        hodor_fr c = p->final_coeffs[i];
-        acc = F.add(acc, F.mul(power, to_h(&c)));
-        power = F.mul(power, point);
-    }
-    *valid = (acc == expected) ? 1 : 0;
-    return HODOR_OK;
-}
-
-// ---- Blake2sTranscript (src/transcript/mod.rs:10-80): host-side, sequential, O(#roots) ----
-struct hodor_transcript {
-    const hodor_ctx *ctx;
-    HostBlake2sStream state;
-    hodor_transcript(const hodor_ctx *c)
-        : ctx(c), state((const uint8_t *)"Squeamish Ossifrage", 19, (const uint8_t *)"Shaftoe", 7) {}
-};
-
-extern "C" int hodor_transcript_new(const hodor_ctx *ctx, hodor_transcript **out)
-{
-    if (!ctx || !out) return HODOR_ERR_INVALID;
-    if (ctx->F.num_bits >= 256) return HODOR_ERR_INVALID;   // assert!(F::NUM_BITS < 256), :41
-    *out = new (std::nothrow) hodor_transcript(ctx);
-    return *out ? HODOR_OK : HODOR_ERR_INVALID;
-}
-extern "C" void hodor_transcript_free(hodor_transcript *t) { delete t; }
-extern "C" int hodor_transcript_commit_bytes(hodor_transcript *t, const uint8_t *bytes, size_t len)
-{
-    if (!t || (!bytes && len)) return HODOR_ERR_INVALID;
-    t->state.update(bytes, len);
-    return HODOR_OK;
-}
-extern "C" int hodor_transcript_commit_field_element(hodor_transcript *t, const hodor_fr *e)
-{
-    if (!t || !e) return HODOR_ERR_INVALID;
-    uint64_t repr[4];
-    t->ctx->F.into_repr(to_h(e), repr);                    // into_repr(): canonical, then write_be (:52-57)
-    uint8_t be[32];
-    for (int i = 0; i < 4; i++)
-        for (int b = 0; b < 8; b++) be[8 * i + b] = (uint8_t)(repr[3 - i] >> (56 - 8 * b));
-    t->state.update(be, 32);
-    return HODOR_OK;
-}
-extern "C" int hodor_transcript_get_challenge_bytes(hodor_transcript *t, uint8_t out[32])
-{
-    if (!t || !out) return HODOR_ERR_INVALID;
-    t->state.finalize(out);
-    t->state.update(out, 32);                               // the digest is re-absorbed (:61-62)
-    return HODOR_OK;
-}
-extern "C" int hodor_transcript_get_challenge(hodor_transcript *t, hodor_fr *out)
-{
-    if (!t || !out) return HODOR_ERR_INVALID;
-    uint8_t v[32];
-    t->state.finalize(v);
-    t->state.update(v, 32);
-    return hodor_iop_challenge(t->ctx, v, out);             // same read_be + shave + from_repr as interpret_hash
-}
-// Verifier::bytes_to_challenge_index (src/verifier/mod.rs:246-263)
-extern "C" size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t lde_size, size_t lde_factor)
-{
-    if (!bytes || len < 8 || !lde_size || !lde_factor) return 0;
-    uint64_t x = 0;
-    for (size_t i = len - 8; i < len; i++) x = (x << 8) | bytes[i];   // BigEndian::read_u64 of the last 8 bytes
-    size_t idx = (size_t)x % lde_size;
-    if (idx % lde_factor == 0) idx = (idx + 1) % lde_size;
-    if (idx % 2 == 0) idx = (idx + 1) % lde_size;
-    return idx;
-}
-
-extern "C" size_t hodor_fri_num_steps(const hodor_fri_proto *p) { return p ? p->num_steps : 0; }
-
-extern "C" int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots)
-{
-    if (!p || !roots) return HODOR_ERR_INVALID;
-    memcpy(roots, p->roots.data(), p->roots.size());
-    return HODOR_OK;
-}
-extern "C" int hodor_fri_final_root(const hodor_fri_proto *p, uint8_t root[32])
-{
-    if (!p || !root) return HODOR_ERR_INVALID;
-    memcpy(root, p->final_root, 32);
-    return HODOR_OK;
-}
-extern "C" int hodor_fri_challenges(const hodor_fri_proto *p, hodor_fr *c)
-{
-    if (!p || !c) return HODOR_ERR_INVALID;
-    memcpy(c, p->challenges.data(), 32 * p->num_steps);
-    return HODOR_OK;
-}
-extern "C" int hodor_fri_final_coefficients(const hodor_fri_proto *p, hodor_fr *c)
-{
-    if (!p || !c) return HODOR_ERR_INVALID;
-    memcpy(c, p->final_coeffs.data(), 32 * p->out_deg);
-    return HODOR_OK;
-}
-extern "C" int hodor_fri_intermediate_values(hodor_fri_proto *p, size_t step, hodor_fr *values)
-{
-    if (!p || !values || step >= p->num_steps) return HODOR_ERR_INVALID;
-    hodor_ctx *ctx = p->ctx;
-    NEED_DEVICE();
-    HIPCHK(hipMemcpy(values, p->inter_values[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
-    return HODOR_OK;
-}
-extern "C" int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes)
-{
-    if (!p || !nodes || step < -1 || step >= (int)p->num_steps) return HODOR_ERR_INVALID;
-    hodor_ctx *ctx = p->ctx;
-    NEED_DEVICE();
-    if (step < 0) HIPCHK(hipMemcpy(nodes, p->l0_nodes, p->n * 32, hipMemcpyDeviceToHost));
-    else HIPCHK(hipMemcpy(nodes, p->inter_nodes[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
-    return HODOR_OK;
-}
-
-extern "C" size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap)
-{
-    if (!p) return 0;
-    size_t need = 8 + 32 * (p->num_steps + 1) + 32 * p->num_steps + 32 + 8 + 32 * p->out_deg;
-    if (!buf || cap < need) return need;
-    size_t o = 0;
-    uint64_t ns = p->num_steps, nf = p->out_deg;
-    memcpy(buf + o, &ns, 8); o += 8;                                   // little-endian host
-    memcpy(buf + o, p->roots.data(), p->roots.size()); o += p->roots.size();
-    memcpy(buf + o, p->challenges.data(), 32 * p->num_steps); o += 32 * p->num_steps;
-    memcpy(buf + o, p->final_root, 32); o += 32;
-    memcpy(buf + o, &nf, 8); o += 8;
-    memcpy(buf + o, p->final_coeffs.data(), 32 * p->out_deg); o += 32 * p->out_deg;
-    return o;
 }

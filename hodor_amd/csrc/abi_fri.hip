@@ -1,0 +1,529 @@
+// abi_fri.hip — the FRI entry points of include/hodor_gpu.h: commit (device and slice), query phase,
+// proof bytes, the two verifiers and the prototype accessors.
+#include "ctx.hpp"
+
+// The prototype's device buffers (l0 tree, every intermediate vector and tree, the small result block)
+// are carved from ONE slab; a freed slab is parked on the context and reused by the next commit of a
+// size that fits, so a prover committing polynomial after polynomial pays hipMalloc once.
+extern "C" void hodor_fri_free(hodor_fri_proto *p)
+{
+    if (!p) return;
+    hodor_ctx *ctx = p->ctx;
+    if (ctx && ctx->device >= 0 && p->slab) {
+        (void)hipSetDevice(ctx->device);
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->fri_slab) {
+            ctx->fri_slab = p->slab;
+            ctx->fri_slab_bytes = p->slab_bytes;
+        } else if (p->slab_bytes > ctx->fri_slab_bytes) {
+            (void)hipFree(ctx->fri_slab);
+            ctx->fri_slab = p->slab;
+            ctx->fri_slab_bytes = p->slab_bytes;
+        } else {
+            (void)hipFree(p->slab);
+        }
+    }
+    delete p;
+}
+
+extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
+                                    size_t lde_factor, size_t out_deg, hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;
+    size_t initial_degree_plus_one = n / lde_factor;
+    if (initial_degree_plus_one < 2 * out_deg) {   // num_steps == 0: the reference panics at roots.pop() (:124)
+        ctx->err = "fri_commit: needs at least one folding step";
+        return HODOR_ERR_SIZE;
+    }
+    size_t num_steps = log2u(initial_degree_plus_one / out_deg);
+    if ((n >> num_steps) < 2) return HODOR_ERR_SIZE;
+    uint32_t log_n = log2u(n);
+    HFr omega, omega_inv;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = poly_domain(ctx, log_n, &omega);
+    if (rc) return rc;
+    ctx->F.inverse(omega, &omega_inv);
+    hipStream_t stream = pick_stream(ctx, stream_);
+
+    hodor_fri_proto *p = new (std::nothrow) hodor_fri_proto();
+    if (!p) return HODOR_ERR_INVALID;
+    p->ctx = ctx;
+    p->n = n;
+    p->num_steps = num_steps;
+    p->lde_factor = lde_factor;
+    p->out_deg = out_deg;
+    p->initial_degree_plus_one = initial_degree_plus_one;
+
+#define FRICHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);             \
+            fri_release(p);                                                            \
+            return HODOR_ERR_DEVICE;                                                   \
+        }                                                                              \
+    } while (0)
+
+    // slab layout: l0 tree | per step: values, tree | small block (challenges, roots, final coeffs)
+    size_t fin_n = n >> num_steps;
+    size_t small_bytes = 32 * (num_steps + 1) * 2 + 32 * fin_n * 2;
+    const uint32_t winv_lo_bits = (log_n + 1) / 2;
+    const size_t hi_cnt = (size_t)1 << (log_n - winv_lo_bits);
+    small_bytes += 48 * hi_cnt;   // per-round copy of the w^-1 `hi` table scaled by beta/2
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t need = up(n * 32) + up(small_bytes);
+    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
+    auto fri_release = [&](hodor_fri_proto *q) {   // error path: the ctx mutex is already held
+        if (q->slab) (void)hipFree(q->slab);
+        delete q;
+    };
+    if (ctx->fri_slab && ctx->fri_slab_bytes >= need) {
+        p->slab = ctx->fri_slab;
+        p->slab_bytes = ctx->fri_slab_bytes;
+        ctx->fri_slab = nullptr;
+        ctx->fri_slab_bytes = 0;
+    } else {
+        FRICHK(hipMalloc(&p->slab, need));
+        p->slab_bytes = need;
+    }
+    uint8_t *cursor = (uint8_t *)p->slab;
+    auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
+    p->l0_nodes = carve(n * 32);
+    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) {
+        p->inter_values.push_back(carve(sz * 32));
+        p->inter_nodes.push_back(carve(sz * 32));
+        p->inter_sizes.push_back(sz);
+    }
+    uint8_t *d_small = (uint8_t *)carve(small_bytes);
+    uint4 *d_chal = (uint4 *)d_small;
+    uint4 *d_roots = (uint4 *)(d_small + 32 * (num_steps + 1));
+    uint4 *d_fin = (uint4 *)(d_small + 64 * (num_steps + 1));
+    uint4 *d_hi_beta = (uint4 *)(d_small + 64 * (num_steps + 1) + 64 * fin_n);
+    const Fr9 c16 = to_dev9(ctx->F, ctx->F.from_u64(16));
+
+    TwoLevel winv;
+    if ((rc = get_pow_table(ctx, omega_inv, log_n, &winv, 1, winv_lo_bits))) { fri_release(p); return rc; }
+    uint32_t shave = 256 - ctx->F.capacity;
+    Fr r2 = to_dev(ctx->F.r2);
+
+    FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
+
+    const uint4 *values = (const uint4 *)lde_values;
+    size_t next_size = n / 2;
+    static int tail_on = -1;   // HODOR_FRI_TAIL=0: every round through the multi-launch path (A/B, debugging)
+    if (tail_on < 0) {
+        const char *e = getenv("HODOR_FRI_TAIL");
+        tail_on = e ? atoi(e) : 1;
+    }
+    // the challenge of round i (:51, :109) is derived from tree i-1 at the start of round i
+    const uint4 *prev_nodes = (const uint4 *)p->l0_nodes;
+    bool tail_done = false;
+    for (size_t i = 0; i < num_steps; i++) {                                                             // :61
+        if (tail_on && next_size <= (size_t)FRI_TAIL_THREADS && num_steps - i <= (size_t)FRI_TAIL_MAX_ROUNDS) {
+            FriTailArgs T = {};   // the remaining rounds fit one workgroup: one launch for all of them
+            FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, r2, shave, ctx->P));
+            T.src = values;
+            T.rounds = (uint32_t)(num_steps - i);
+            for (uint32_t k = 0; k < T.rounds; k++) {
+                T.values[k] = (uint4 *)p->inter_values[i + k];
+                T.nodes[k] = (uint4 *)p->inter_nodes[i + k];
+            }
+            T.chal = d_chal;
+            T.roots = d_roots;
+            T.lo = winv.lo;
+            T.hi = winv.hi;
+            T.lo_bits = winv.lo_bits;
+            T.first_round = (uint32_t)i;
+            T.half0 = (uint32_t)next_size;
+            T.shave = shave;
+            FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P));
+            values = (const uint4 *)p->inter_values[num_steps - 1];
+            tail_done = true;
+            break;
+        }
+        void *next = p->inter_values[i], *nodes = p->inter_nodes[i];
+        FRICHK(fri_round_table_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, winv.hi, d_hi_beta, hi_cnt,
+                                      c16, r2, shave, ctx->Q, ctx->P));
+        FoldArgs fold = {values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits, (uint32_t)i};
+        const bool fused = merkle_fuses_fold(next_size);   // small rounds: fold inside the tree's leaf launch
+        if (!fused) FRICHK(fri_fold_launch(stream, fold, ctx->Q));                                        // :70-104
+        FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid, 1,
+                                   fused ? &fold : nullptr, &ctx->Q));                                   // :106
+        prev_nodes = (const uint4 *)nodes;
+        values = (const uint4 *)next;
+        next_size >>= 1;
+    }
+    if (!tail_done)   // the last tree's root (and the challenge the reference computes and pops, :120)
+        FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * num_steps, d_roots + 2 * num_steps, r2, shave, ctx->P));
+    // final: values -> ifft -> truncate (:130-145)
+    rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
+    if (rc) { fri_release(p); return rc; }
+
+    // challenges | roots | final coefficients sit back to back in the slab's small block: one copy
+    std::vector<uint8_t> small(64 * (num_steps + 1) + 32 * out_deg);
+    FRICHK(hipMemcpyAsync(small.data(), d_small, small.size(), hipMemcpyDeviceToHost, stream));
+    FRICHK(hipStreamSynchronize(stream));
+    p->roots.assign(small.begin() + 32 * (num_steps + 1), small.begin() + 64 * (num_steps + 1));
+    p->challenges.resize(num_steps);
+    memcpy(p->challenges.data(), small.data(), 32 * num_steps);
+    p->final_coeffs.resize(out_deg);
+    memcpy(p->final_coeffs.data(), small.data() + 64 * (num_steps + 1), 32 * out_deg);
+    memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
+#undef FRICHK
+    *out = p;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                                size_t out_deg, hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
+    DevBuf dv;
+    HIPCHK(hipMalloc(&dv.p, n * 32));
+    HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
+    return hodor_fri_commit_dev(ctx, nullptr, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
+}
+
+// IOP::query on device-resident leaves and tree (src/iop/blake2s_trivial_iop.rs:324-338)
+extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *leafs, const uint8_t *nodes,
+                                   size_t n, size_t natural_index, hodor_fr *value, uint8_t *path,
+                                   size_t *path_len)
+{
+    NEED_DEVICE();
+    if (!leafs || !nodes || !value || !path || !path_len) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2 || natural_index >= n) return HODOR_ERR_SIZE;   // asserts at :325-326
+    hipStream_t stream = pick_stream(ctx, stream_);
+    size_t entries = log2u(n) + 1;
+    DevBuf stage;
+    HIPCHK(hipMalloc(&stage.p, entries * 32));
+    HIPCHK(iop_query_launch(stream, (const uint4 *)(leafs + (natural_index & ~(size_t)1)), (const uint4 *)nodes, n,
+                            natural_index, (uint4 *)stage.p, ctx->mid));
+    std::vector<uint8_t> host(entries * 32);
+    HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    memcpy(value, host.data(), 32);
+    memcpy(path, host.data() + 32, (entries - 1) * 32);
+    *path_len = entries - 1;
+    return HODOR_OK;
+}
+
+// FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53): for the l0 oracle and every
+// intermediate oracle, the two queries of the coset {idx, idx + size/2} (sorted), idx halving as the
+// domain does (Domain::index_and_size_for_next_domain).  Serialised FRIProof (src/fri/mod.rs:139-147):
+//   u64 num_queries | per query: u64 natural_index, value (32 B), u64 path_len, path |
+//   u64 num_roots | roots | u64 n_final | final_coefficients |
+//   u64 initial_degree_plus_one | u64 output_coeffs_at_degree_plus_one | u64 lde_factor
+extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
+                                          size_t natural_first_element_index, uint8_t *buf, size_t cap)
+{
+    if (!p || !lde_values_dev) return 0;
+    hodor_ctx *ctx = p->ctx;
+    if (!ctx || ctx->device < 0 || natural_first_element_index >= p->n) return 0;
+    const size_t rounds = p->num_steps + 1;
+    size_t need = 8, stage_bytes = 0;
+    for (size_t r = 0, sz = p->n; r < rounds; r++, sz >>= 1) {
+        size_t entries = log2u(sz) + 1;
+        need += 2 * (8 + 32 + 8 + (entries - 1) * 32);
+        stage_bytes += 2 * entries * 32;
+    }
+    need += 8 + rounds * 32 + 8 + p->out_deg * 32 + 24;
+    if (!buf || cap < need) return need;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DevBuf stage;
+    if (hipMalloc(&stage.p, stage_bytes) != hipSuccess) return 0;
+    std::vector<size_t> q_index, q_entries;
+    size_t domain_size = p->n, domain_idx = natural_first_element_index, off = 0;
+    for (size_t r = 0; r < rounds; r++) {
+        const hodor_fr *leafs = r == 0 ? lde_values_dev : (const hodor_fr *)p->inter_values[r - 1];
+        const uint4 *nodes = (const uint4 *)(r == 0 ? p->l0_nodes : p->inter_nodes[r - 1]);
+        size_t pair = (domain_idx + domain_size / 2) % domain_size;
+        size_t coset[2] = {domain_idx < pair ? domain_idx : pair, domain_idx < pair ? pair : domain_idx};
+        size_t entries = log2u(domain_size) + 1;
+        for (int k = 0; k < 2; k++) {
+            if (iop_query_launch(ctx->stream, (const uint4 *)(leafs + (coset[k] & ~(size_t)1)), nodes, domain_size,
+                                 coset[k], (uint4 *)((uint8_t *)stage.p + off), ctx->mid) != hipSuccess)
+                return 0;
+            q_index.push_back(coset[k]);
+            q_entries.push_back(entries);
+            off += entries * 32;
+        }
+        size_t next = domain_size / 2;                       // index_and_size_for_next_domain
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+    }
+    std::vector<uint8_t> host(stage_bytes);
+    if (hipMemcpyAsync(host.data(), stage.p, stage_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return 0;
+    size_t o = 0, h = 0;
+    auto put64 = [&](uint64_t v) { memcpy(buf + o, &v, 8); o += 8; };
+    put64(q_index.size());
+    for (size_t q = 0; q < q_index.size(); q++) {
+        put64(q_index[q]);
+        memcpy(buf + o, host.data() + h, 32); o += 32;
+        put64(q_entries[q] - 1);
+        memcpy(buf + o, host.data() + h + 32, (q_entries[q] - 1) * 32); o += (q_entries[q] - 1) * 32;
+        h += q_entries[q] * 32;
+    }
+    put64(rounds);
+    memcpy(buf + o, p->roots.data(), rounds * 32); o += rounds * 32;
+    put64(p->out_deg);
+    memcpy(buf + o, p->final_coeffs.data(), p->out_deg * 32); o += p->out_deg * 32;
+    put64(p->initial_degree_plus_one);
+    put64(p->out_deg);
+    put64(p->lde_factor);
+    return o;
+}
+
+// NaiveFriIop::verify_proof_queries (src/fri/verifier.rs:131-289) over the serialised FRIProof that
+// hodor_fri_produce_proof writes.  Host-only (log n hashes and a handful of field operations per
+// round): works on a ctx without a device.  *valid = Ok(true/false); the reference's Err(..) cases
+// (point outside the LDE domain, query count not a multiple of DEGREE = 2, wrong tree index) and a
+// malformed buffer return HODOR_ERR_INVALID.
+extern "C" int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len,
+                                      size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
+                                      int *valid)
+{
+    if (!ctx || !proof || !expected_value_from_oracle || !valid) return HODOR_ERR_INVALID;
+    *valid = 0;
+    size_t o = 0;
+    bool bad = false;
+    auto get64 = [&]() -> uint64_t {
+        uint64_t v = 0;
+        if (o > len || len - o < 8) { bad = true; return 0; }
+        memcpy(&v, proof + o, 8);
+        o += 8;
+        return v;
+    };
+    auto take = [&](uint64_t count) -> const uint8_t * {   // count 32-byte entries
+        if (bad || count > (len - o) / 32) { bad = true; return nullptr; }
+        const uint8_t *r = proof + o;
+        o += (size_t)count * 32;
+        return r;
+    };
+    struct Query { uint64_t index; const uint8_t *value; uint64_t path_len; const uint8_t *path; };
+    uint64_t nq = get64();
+    if (bad || nq > len / 48) return HODOR_ERR_INVALID;
+    std::vector<Query> queries((size_t)nq);
+    for (auto &q : queries) {
+        q.index = get64();
+        q.value = take(1);
+        q.path_len = get64();
+        q.path = take(q.path_len);
+        if (bad) return HODOR_ERR_INVALID;
+    }
+    uint64_t n_roots = get64();
+    const uint8_t *roots = take(n_roots);
+    uint64_t n_final = get64();
+    const uint8_t *final_coeffs = take(n_final);
+    uint64_t initial_degree_plus_one = get64();
+    (void)get64();   // output_coeffs_at_degree_plus_one: carried by the proof, unused by the verifier
+    uint64_t lde_factor = get64();
+    if (bad || o != len) return HODOR_ERR_INVALID;
+
+    const HostField &F = ctx->F;
+    HFr two_inv, omega, omega_inv;
+    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_size;
+    if (lde_factor && initial_degree_plus_one > ~0ull / lde_factor) return HODOR_ERR_SIZE;
+    if (!F.domain(initial_degree_plus_one * lde_factor, &size, &log_size, &omega)) return HODOR_ERR_SIZE;
+    HFr x = F.pow(omega, natural_element_index);
+    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) return HODOR_ERR_INVALID;
+    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
+    if (queries.size() % 2 != 0) return HODOR_ERR_INVALID;
+
+    auto value_of = [&](const Query &q) { hodor_fr v; memcpy(v.l, q.value, 32); return to_h(&v); };
+    bool have_expected = false;
+    HFr expected = F.one;
+    uint64_t domain_size = size, domain_idx = natural_element_index;
+    const HFr oracle_value = to_h(expected_value_from_oracle);
+    const size_t rounds = std::min<size_t>((size_t)n_roots, queries.size() / 2);   // zip(roots, chunks_exact)
+    for (size_t rnd = 0; rnd < rounds; rnd++) {
+        if (domain_size < 2) return HODOR_ERR_INVALID;
+        const Query *qs = &queries[2 * rnd];
+        const uint8_t *root = roots + 32 * rnd;
+        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
+        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
+        for (int k = 0; k < 2; k++)
+            if (qs[k].index != coset[0] && qs[k].index != coset[1]) return HODOR_OK;          // Ok(false)
+        if (rnd == 0)
+            for (int k = 0; k < 2; k++)
+                if (qs[k].index == natural_element_index && !(value_of(qs[k]) == oracle_value)) return HODOR_OK;
+        for (int k = 0; k < 2; k++)
+            if (qs[k].index != coset[k]) return HODOR_ERR_INVALID;                            // "invalid tree index"
+        for (int k = 0; k < 2; k++) {
+            int ok = 0;
+            hodor_fr leaf;
+            memcpy(leaf.l, qs[k].value, 32);
+            hodor_iop_verify(ctx, root, &leaf, qs[k].path, (size_t)qs[k].path_len, (size_t)qs[k].index, &ok);
+            if (!ok) return HODOR_OK;
+        }
+        hodor_fr ch;
+        if (hodor_iop_challenge(ctx, root, &ch)) return HODOR_ERR_INVALID;
+        const HFr challenge = to_h(&ch);
+        const HFr f_at_omega = value_of(qs[0]), f_at_minus_omega = value_of(qs[1]);
+        if (have_expected) {
+            int hits = 0;
+            HFr supplied = F.one;
+            for (int k = 0; k < 2; k++)
+                if (qs[k].index == domain_idx) { hits++; supplied = value_of(qs[k]); }
+            if (hits != 1 || !(supplied == expected)) return HODOR_OK;
+        }
+        HFr divisor = F.pow(omega_inv, coset[0]);
+        HFr even = F.add(f_at_omega, f_at_minus_omega);
+        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
+        expected = F.mul(F.add(F.mul(odd, challenge), even), two_inv);
+        have_expected = true;
+        uint64_t next = domain_size / 2;                      // index_and_size_for_next_domain
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+        omega = F.sqr(omega);
+        omega_inv = F.sqr(omega_inv);
+    }
+    if (!have_expected) return HODOR_ERR_INVALID;             // expect("is some")
+    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
+    for (uint64_t i = 0; i < n_final; i++) {
+        hodor_fr c;
+        memcpy(c.l, final_coeffs + 32 * i, 32);
+        acc = F.add(acc, F.mul(power, to_h(&c)));
+        power = F.mul(power, point);
+    }
+    *valid = (acc == expected) ? 1 : 0;
+    return HODOR_OK;
+}
+
+// NaiveFriIop::verify_prototype (src/fri/verifier.rs:10-129): the same folding walk against the
+// prover's own (device-resident) vectors instead of Merkle queries — two elements per round are
+// fetched from the device.  `lde_values_dev` is the codeword the prototype was committed from.
+extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
+                                          size_t natural_element_index, int *valid)
+{
+    if (!p || !lde_values_dev || !valid) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = p->ctx;
+    NEED_DEVICE();
+    *valid = 0;
+    const HostField &F = ctx->F;
+    HFr two_inv, omega, omega_inv;
+    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_size;
+    if (!F.domain((uint64_t)p->initial_degree_plus_one * p->lde_factor, &size, &log_size, &omega))
+        return HODOR_ERR_SIZE;
+    HFr x = F.pow(omega, natural_element_index);
+    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) {
+        ctx->err = "initial challenge value is not in the LDE domain";
+        return HODOR_ERR_INVALID;
+    }
+    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    bool have_expected = false;
+    HFr expected = F.one;
+    uint64_t domain_size = size, domain_idx = natural_element_index;
+    auto fetch = [&](const hodor_fr *base, uint64_t i, HFr *out) -> bool {
+        hodor_fr v;
+        if (hipMemcpy(&v, base + i, 32, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        *out = to_h(&v);
+        return true;
+    };
+    // zip(leaf_values ++ intermediate_values, challenges): num_steps rounds
+    for (size_t rnd = 0; rnd < p->num_steps; rnd++) {
+        const hodor_fr *values = rnd == 0 ? lde_values_dev : (const hodor_fr *)p->inter_values[rnd - 1];
+        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
+        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
+        HFr f_at_omega, f_at_minus_omega;
+        if (!fetch(values, coset[0], &f_at_omega) || !fetch(values, coset[1], &f_at_minus_omega)) {
+            ctx->err = "verify_prototype: device read failed";
+            return HODOR_ERR_DEVICE;
+        }
+        if (have_expected) {
+            const HFr &supplied = domain_idx == coset[0] ? f_at_omega : f_at_minus_omega;
+            if (!(supplied == expected)) return HODOR_OK;     // Ok(false)
+        }
+        hodor_fr ch = p->challenges[rnd];
+        HFr divisor = F.pow(omega_inv, coset[0]);
+        HFr even = F.add(f_at_omega, f_at_minus_omega);
+        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
+        expected = F.mul(F.add(F.mul(odd, to_h(&ch)), even), two_inv);
+        have_expected = true;
+        uint64_t next = domain_size / 2;
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+        omega = F.sqr(omega);
+        omega_inv = F.sqr(omega_inv);
+    }
+    if (!have_expected) return HODOR_ERR_INVALID;
+    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
+    for (size_t i = 0; i < p->final_coeffs.size(); i++) {
+        hodor_fr c = p->final_coeffs[i];
+        acc = F.add(acc, F.mul(power, to_h(&c)));
+        power = F.mul(power, point);
+    }
+    *valid = (acc == expected) ? 1 : 0;
+    return HODOR_OK;
+}
+
+extern "C" size_t hodor_fri_num_steps(const hodor_fri_proto *p) { return p ? p->num_steps : 0; }
+
+extern "C" int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots)
+{
+    if (!p || !roots) return HODOR_ERR_INVALID;
+    memcpy(roots, p->roots.data(), p->roots.size());
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_final_root(const hodor_fri_proto *p, uint8_t root[32])
+{
+    if (!p || !root) return HODOR_ERR_INVALID;
+    memcpy(root, p->final_root, 32);
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_challenges(const hodor_fri_proto *p, hodor_fr *c)
+{
+    if (!p || !c) return HODOR_ERR_INVALID;
+    memcpy(c, p->challenges.data(), 32 * p->num_steps);
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_final_coefficients(const hodor_fri_proto *p, hodor_fr *c)
+{
+    if (!p || !c) return HODOR_ERR_INVALID;
+    memcpy(c, p->final_coeffs.data(), 32 * p->out_deg);
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_intermediate_values(hodor_fri_proto *p, size_t step, hodor_fr *values)
+{
+    if (!p || !values || step >= p->num_steps) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = p->ctx;
+    NEED_DEVICE();
+    HIPCHK(hipMemcpy(values, p->inter_values[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
+    return HODOR_OK;
+}
+extern "C" int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes)
+{
+    if (!p || !nodes || step < -1 || step >= (int)p->num_steps) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = p->ctx;
+    NEED_DEVICE();
+    if (step < 0) HIPCHK(hipMemcpy(nodes, p->l0_nodes, p->n * 32, hipMemcpyDeviceToHost));
+    else HIPCHK(hipMemcpy(nodes, p->inter_nodes[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
+    return HODOR_OK;
+}
+
+extern "C" size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap)
+{
+    if (!p) return 0;
+    size_t need = 8 + 32 * (p->num_steps + 1) + 32 * p->num_steps + 32 + 8 + 32 * p->out_deg;
+    if (!buf || cap < need) return need;
+    size_t o = 0;
+    uint64_t ns = p->num_steps, nf = p->out_deg;
+    memcpy(buf + o, &ns, 8); o += 8;                                   // little-endian host
+    memcpy(buf + o, p->roots.data(), p->roots.size()); o += p->roots.size();
+    memcpy(buf + o, p->challenges.data(), 32 * p->num_steps); o += 32 * p->num_steps;
+    memcpy(buf + o, p->final_root, 32); o += 32;
+    memcpy(buf + o, &nf, 8); o += 8;
+    memcpy(buf + o, p->final_coeffs.data(), 32 * p->out_deg); o += 32 * p->out_deg;
+    return o;
+}

@@ -1,0 +1,202 @@
+// abi_host.hip — entry points that never touch the device: field helpers, single BLAKE2s hashes, path
+// and root helpers of the IOP, the transcript.  They work on a context created with device = -1.
+#include "ctx.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// host scalar helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int hodor_fr_mul(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
+{
+    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.mul(to_h(a), to_h(b)), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_add(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
+{
+    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.add(to_h(a), to_h(b)), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_sub(const hodor_ctx *ctx, const hodor_fr *a, const hodor_fr *b, hodor_fr *out)
+{
+    if (!ctx || !a || !b || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.sub(to_h(a), to_h(b)), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_pow(const hodor_ctx *ctx, const hodor_fr *a, uint64_t e, hodor_fr *out)
+{
+    if (!ctx || !a || !out) return HODOR_ERR_INVALID;
+    from_h(ctx->F.pow(to_h(a), e), out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_inverse(const hodor_ctx *ctx, const hodor_fr *a, hodor_fr *out)
+{
+    if (!ctx || !a || !out) return HODOR_ERR_INVALID;
+    HFr r;
+    if (!ctx->F.inverse(to_h(a), &r)) return HODOR_ERR_INVALID;
+    from_h(r, out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_from_repr(const hodor_ctx *ctx, const uint64_t c[4], hodor_fr *out)
+{
+    if (!ctx || !c || !out) return HODOR_ERR_INVALID;
+    HFr r;
+    if (!ctx->F.from_repr(c, &r)) return HODOR_ERR_INVALID;
+    from_h(r, out);
+    return HODOR_OK;
+}
+extern "C" int hodor_fr_into_repr(const hodor_ctx *ctx, const hodor_fr *a, uint64_t c[4])
+{
+    if (!ctx || !a || !c) return HODOR_ERR_INVALID;
+    ctx->F.into_repr(to_h(a), c);
+    return HODOR_OK;
+}
+
+extern "C" int hodor_domain_new_for_size(const hodor_ctx *ctx, uint64_t size, uint64_t *out_size,
+                                         uint32_t *out_log_n, hodor_fr *out_generator)
+{
+    if (!ctx || !out_size || !out_log_n || !out_generator) return HODOR_ERR_INVALID;
+    HFr g;
+    if (!ctx->F.domain(size, out_size, out_log_n, &g)) return HODOR_ERR_SIZE;
+    from_h(g, out_generator);
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_challenge(const hodor_ctx *ctx, const uint8_t root[32], hodor_fr *out)
+{
+    if (!ctx || !root || !out) return HODOR_ERR_INVALID;
+    uint64_t repr[4];
+    for (int i = 0; i < 4; i++) {   // read_be
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) w = (w << 8) | root[8 * i + b];
+        repr[3 - i] = w;
+    }
+    uint32_t shave = 256 - ctx->F.capacity;
+    repr[3] &= 0xffffffffffffffffull >> (shave % 64);
+    HFr r;
+    if (!ctx->F.from_repr(repr, &r)) return HODOR_ERR_INVALID;   // "in a field" expect
+    from_h(r, out);
+    return HODOR_OK;
+}
+
+static void host_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32])
+{
+    HostBlake2s::finish(ctx->mid.h, (const uint8_t *)leaf->l, 32, out);   // LE limbs == memory image
+}
+static void host_hash_node(const hodor_ctx *ctx, const uint8_t *l, const uint8_t *r, uint8_t out[32])
+{
+    uint8_t buf[64];
+    memcpy(buf, l, 32);
+    memcpy(buf + 32, r, 32);
+    HostBlake2s::finish(ctx->mid.h, buf, 64, out);
+}
+
+// IopTreeHasher::{hash_leaf, hash_node} (src/iop/blake2s_trivial_iop.rs:81-104) for single digests on
+// the host: the top log2(P) levels of a tree whose subtrees live on P GPUs, path checks, ...
+extern "C" int hodor_hash_leaf(const hodor_ctx *ctx, const hodor_fr *leaf, uint8_t out[32])
+{
+    if (!ctx || !leaf || !out) return HODOR_ERR_INVALID;
+    host_hash_leaf(ctx, leaf, out);
+    return HODOR_OK;
+}
+extern "C" int hodor_hash_node(const hodor_ctx *ctx, const uint8_t left[32], const uint8_t right[32], uint8_t out[32])
+{
+    if (!ctx || !left || !right || !out) return HODOR_ERR_INVALID;
+    host_hash_node(ctx, left, right, out);
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
+                              size_t tree_index, uint8_t *path, size_t *path_len)
+{
+    if (!ctx || !nodes || !leafs || !path || !path_len) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2 || tree_index >= n) return HODOR_ERR_SIZE;
+    size_t cnt = 0;
+    host_hash_leaf(ctx, &leafs[tree_index ^ 1], path);
+    cnt++;
+    size_t idx = tree_index >> 1;
+    for (size_t w = n / 2; w >= 2; w /= 2) {
+        memcpy(path + 32 * cnt, nodes + 32 * (w + (idx ^ 1)), 32);
+        cnt++;
+        idx >>= 1;
+    }
+    *path_len = cnt;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *leaf,
+                                const uint8_t *path, size_t path_len, size_t tree_index, int *ok)
+{
+    if (!ctx || !root || !leaf || (!path && path_len) || !ok) return HODOR_ERR_INVALID;
+    uint8_t h[32], t[32];
+    host_hash_leaf(ctx, leaf, h);
+    size_t idx = tree_index;
+    for (size_t i = 0; i < path_len; i++) {
+        if ((idx & 1) == 0) host_hash_node(ctx, h, path + 32 * i, t);
+        else host_hash_node(ctx, path + 32 * i, h, t);
+        memcpy(h, t, 32);
+        idx >>= 1;
+    }
+    *ok = memcmp(h, root, 32) == 0;
+    return HODOR_OK;
+}
+
+// ---- Blake2sTranscript (src/transcript/mod.rs:10-80): host-side, sequential, O(#roots) ----
+struct hodor_transcript {
+    const hodor_ctx *ctx;
+    HostBlake2sStream state;
+    hodor_transcript(const hodor_ctx *c)
+        : ctx(c), state((const uint8_t *)"Squeamish Ossifrage", 19, (const uint8_t *)"Shaftoe", 7) {}
+};
+
+extern "C" int hodor_transcript_new(const hodor_ctx *ctx, hodor_transcript **out)
+{
+    if (!ctx || !out) return HODOR_ERR_INVALID;
+    if (ctx->F.num_bits >= 256) return HODOR_ERR_INVALID;   // assert!(F::NUM_BITS < 256), :41
+    *out = new (std::nothrow) hodor_transcript(ctx);
+    return *out ? HODOR_OK : HODOR_ERR_INVALID;
+}
+extern "C" void hodor_transcript_free(hodor_transcript *t) { delete t; }
+extern "C" int hodor_transcript_commit_bytes(hodor_transcript *t, const uint8_t *bytes, size_t len)
+{
+    if (!t || (!bytes && len)) return HODOR_ERR_INVALID;
+    t->state.update(bytes, len);
+    return HODOR_OK;
+}
+extern "C" int hodor_transcript_commit_field_element(hodor_transcript *t, const hodor_fr *e)
+{
+    if (!t || !e) return HODOR_ERR_INVALID;
+    uint64_t repr[4];
+    t->ctx->F.into_repr(to_h(e), repr);                    // into_repr(): canonical, then write_be (:52-57)
+    uint8_t be[32];
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) be[8 * i + b] = (uint8_t)(repr[3 - i] >> (56 - 8 * b));
+    t->state.update(be, 32);
+    return HODOR_OK;
+}
+extern "C" int hodor_transcript_get_challenge_bytes(hodor_transcript *t, uint8_t out[32])
+{
+    if (!t || !out) return HODOR_ERR_INVALID;
+    t->state.finalize(out);
+    t->state.update(out, 32);                               // the digest is re-absorbed (:61-62)
+    return HODOR_OK;
+}
+extern "C" int hodor_transcript_get_challenge(hodor_transcript *t, hodor_fr *out)
+{
+    if (!t || !out) return HODOR_ERR_INVALID;
+    uint8_t v[32];
+    t->state.finalize(v);
+    t->state.update(v, 32);
+    return hodor_iop_challenge(t->ctx, v, out);             // same read_be + shave + from_repr as interpret_hash
+}
+// Verifier::bytes_to_challenge_index (src/verifier/mod.rs:246-263)
+extern "C" size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t lde_size, size_t lde_factor)
+{
+    if (!bytes || len < 8 || !lde_size || !lde_factor) return 0;
+    uint64_t x = 0;
+    for (size_t i = len - 8; i < len; i++) x = (x << 8) | bytes[i];   // BigEndian::read_u64 of the last 8 bytes
+    size_t idx = (size_t)x % lde_size;
+    if (idx % lde_factor == 0) idx = (idx + 1) % lde_size;
+    if (idx % 2 == 0) idx = (idx + 1) % lde_size;
+    return idx;
+}

@@ -1,0 +1,205 @@
+// ctx.hpp — internal to csrc/: the context and prototype behind the opaque handles of
+// include/hodor_gpu.h, the kernels' host launchers, and the helpers the abi_*.hip files share.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hodor_gpu.h"
+#include "host_blake2s.hpp"
+#include "host_field.hpp"
+#include "ntt.cuh"
+
+namespace hodor {
+
+// kernels' host launchers (ntt.hip, pointwise.hip, merkle.hip, fri.hip)
+hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr9 *scale, const Fr9Params &);
+hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
+                            uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
+hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &);
+hipError_t distribute_powers_small_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
+hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
+hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
+hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
+hipError_t unary_launch(hipStream_t, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &);
+hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod,
+                                   uint32_t *zero_flag, const FrParams &);
+hipError_t batchinv_backward_launch(hipStream_t, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,
+                                    const uint4 *prod_inv, const FrParams &);
+unsigned evaluate_at_table_blocks(uint32_t log_n);
+hipError_t evaluate_at_table_launch(hipStream_t, const uint4 *a, uint64_t n, uint32_t log_n, const TwoLevel &t,
+                                    uint4 *partials, uint32_t *ticket, uint4 *out, const Fr9Params &, const FrParams &);
+hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr &g, uint4 *partials,
+                              uint32_t *ticket, uint4 *out, const FrParams &);
+hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
+                              const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
+hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &,
+                               uint32_t batch = 1, const FoldArgs *fold = nullptr, const Fr9Params *Q = nullptr);
+bool merkle_fuses_fold(uint64_t n);
+hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
+                            uint64_t index, uint4 *out, const B2Mid &);
+hipError_t challenge_launch(hipStream_t, const uint4 *nodes, uint4 *out, uint4 *root_out, const Fr &r2,
+                            uint32_t shave_bits, const FrParams &);
+hipError_t fri_round_table_launch(hipStream_t, const uint4 *nodes, uint4 *chal_out, uint4 *root_out,
+                                  const uint4 *hi, uint4 *hi_out, uint64_t count, const Fr9 &c16, const Fr &r2,
+                                  uint32_t shave, const Fr9Params &, const FrParams &);
+hipError_t fri_tail_launch(hipStream_t, const FriTailArgs &, const Fr9 &c16, const Fr &r2, const B2Mid &,
+                           const Fr9Params &, const FrParams &);
+hipError_t fri_fold_launch(hipStream_t, const FoldArgs &, const Fr9Params &);
+
+static inline Fr to_dev(const HFr &a)
+{
+    Fr r;
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)a.l[i];
+        r.v[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
+    }
+    return r;
+}
+
+// split a 256-bit integer (4 x u64) into 9 limbs of 29 bits
+static inline void split29(const uint64_t l[4], uint32_t out[9])
+{
+    for (int i = 0; i < 9; i++) {
+        int bit = 29 * i, w = bit >> 6, s = bit & 63;
+        uint64_t v = l[w] >> s;
+        if (s > 35 && w < 3) v |= l[w + 1] << (64 - s);
+        out[i] = (uint32_t)(v & 0x1fffffffu);
+    }
+}
+
+// R-form host element (x * 2^256) -> R'-form 9 x 29-bit multiplier operand (x * 2^261 mod p)
+static inline Fr9 to_dev9(const HostField &F, const HFr &a)
+{
+    HFr t = a;
+    for (int i = 0; i < 5; i++) t = F.add(t, t);
+    Fr9 r;
+    split29(t.l, r.v);
+    return r;
+}
+
+struct PowTable {
+    HFr base;
+    uint32_t log_n;
+    uint32_t lo_bits;
+    uint32_t fmt;          // 0: 32-byte R-form entries, 1: 48-byte 9 x 29-bit R'-form entries
+    HFr hi_mult;           // every `hi` entry is multiplied by this (one, or n^-1 for the last iNTT pass)
+    uint4 *lo, *hi;
+};
+
+struct RadixTable {
+    HFr omega;
+    uint32_t log_n, log_r;
+    uint4 *rtw;
+};
+
+}  // namespace hodor
+
+using namespace hodor;
+
+struct hodor_ctx {
+    int device = -1;
+    HostField F;
+    FrParams P;
+    Fr9Params Q;
+    B2Mid mid;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::vector<PowTable> pow_tables;
+    std::vector<RadixTable> radix_tables;
+    void *scratch[2] = {nullptr, nullptr};
+    size_t scratch_bytes[2] = {0, 0};
+    // slice API staging: IO_LANES independent (copy stream, in/out device buffers) sets, so that
+    // concurrent callers (src/arp/per_register/mod.rs:43-49 calls best_fft from several scoped threads)
+    // overlap one caller's upload with another's kernels and a third's download; see with_device_copy
+    struct IoLane {
+        hipStream_t stream = nullptr;
+        hipEvent_t uploaded = nullptr, computed = nullptr;
+        void *buf[2] = {nullptr, nullptr};   // grow-only (in / out)
+        size_t bytes[2] = {0, 0};
+        bool busy = false;
+    };
+    static constexpr int IO_LANES = 3;
+    IoLane lanes[IO_LANES];
+    std::mutex lane_mu;
+    std::condition_variable lane_cv;
+    void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
+    size_t fri_slab_bytes = 0;
+    uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
+    uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
+    std::string err;
+};
+
+struct hodor_fri_proto {
+    hodor_ctx *ctx;
+    size_t n, num_steps, lde_factor, out_deg, initial_degree_plus_one;
+    void *slab = nullptr;                     // one device allocation holding everything below
+    size_t slab_bytes = 0;
+    void *l0_nodes = nullptr;                 // device, n*32
+    std::vector<void *> inter_values;         // device
+    std::vector<void *> inter_nodes;          // device
+    std::vector<size_t> inter_sizes;
+    std::vector<uint8_t> roots;               // host: (num_steps+1)*32
+    std::vector<hodor_fr> challenges;         // host: num_steps
+    std::vector<hodor_fr> final_coeffs;       // host
+    uint8_t final_root[32];
+};
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);            \
+            return HODOR_ERR_DEVICE;                                                  \
+        }                                                                             \
+    } while (0)
+
+#define NEED_DEVICE()                                                                 \
+    do {                                                                              \
+        if (!ctx) return HODOR_ERR_INVALID;                                           \
+        if (ctx->device < 0) { ctx->err = "context has no HIP device"; return HODOR_ERR_DEVICE; } \
+        HIPCHK(hipSetDevice(ctx->device));                                            \
+    } while (0)
+
+static inline HFr to_h(const hodor_fr *a)
+{
+    HFr r;
+    memcpy(r.l, a->l, 32);
+    return r;
+}
+static inline void from_h(const HFr &a, hodor_fr *out) { memcpy(out->l, a.l, 32); }
+static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static inline uint32_t log2u(size_t n)
+{
+    uint32_t r = 0;
+    while (n > 1) { n >>= 1; r++; }
+    return r;
+}
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
+{
+    (void)ctx;
+    return (hipStream_t)stream;   // NULL selects the HIP default (null) stream, as for any HIP API
+}
+
+// defined in abi.hip (caller holds ctx->mu)
+int trim_table_cache(hodor_ctx *ctx);
+int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
+                  uint32_t lo_bits = 0xffffffffu, const HFr *hi_mult_p = nullptr);
+int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes);
+int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega);
+enum PolyOp { OP_FFT, OP_COSET_FFT, OP_IFFT, OP_ICOSET_FFT };
+int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op);

@@ -346,7 +346,7 @@ struct FRIProof {
     std::vector<Fr> final_coefficients;
     size_t initial_degree_plus_one, output_coeffs_at_degree_plus_one, lde_factor;
 
-    // the wire format of hodor_fri_produce_proof / hodor_fri_verify_proof (documented in csrc/abi.hip)
+    // the wire format of hodor_fri_produce_proof / hodor_fri_verify_proof (documented in csrc/abi_fri.hip)
     std::vector<uint8_t> to_bytes() const
     {
         std::vector<uint8_t> out;

@@ -213,7 +213,7 @@ int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, si
 int hodor_iop_query_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, const uint8_t *nodes, size_t n,
                         size_t natural_index, hodor_fr *value, uint8_t *path, size_t *path_len);
 /* FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53) against the device-resident
- * prototype: the serialised FRIProof (src/fri/mod.rs:139-147; layout documented in csrc/abi.hip).
+ * prototype: the serialised FRIProof (src/fri/mod.rs:139-147; layout documented in csrc/abi_fri.hip).
  * `lde_values_dev` is the codeword the prototype was committed from (device pointer).  Returns the
  * byte count; writes only when buf != NULL and cap is large enough; 0 on error. */
 size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,

@@ -321,7 +321,7 @@ def fri_produce_proof(F, proto, lde_values, natural_first_element_index, lde_fac
 
 
 def fri_proof_to_bytes(proof):
-    """The FRIProof wire format this build defines (hodor_amd/csrc/abi.hip, hodor_fri_produce_proof)."""
+    """The FRIProof wire format this build defines (hodor_amd/csrc/abi_fri.hip, hodor_fri_produce_proof)."""
     u64 = lambda v: int(v).to_bytes(8, "little")
     out = u64(len(proof["queries"]))
     for idx, value, path in proof["queries"]:
