@@ -1,4 +1,4 @@
-// fri.hip — K7: one FRI folding round on device.
+// fri.hip — K7: the FRI folding rounds on device (round table + fold, and the fused tail of small rounds).
 //
 // Replaces the per-round loop body of NaiveFriIop::proof_from_lde_by_values
 // (/root/reference/src/fri/fri_on_values.rs:70-104):

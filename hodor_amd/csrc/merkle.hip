@@ -14,8 +14,8 @@
 // Tree layout = the reference's heap array: nodes[1] root, level l at nodes[2^l .. 2^(l+1)),
 // nodes[0] unused (zeroed), leaf hashes are not stored.
 //
-// 32-bit ARX integer work: no MFMA.  One hash per lane, all 16 state words + 16 message words in
-// VGPRs, sigma schedule resolved at compile time.
+// 32-bit ARX integer work: no MFMA.  The compression functions (one hash per lane, and the quad-lane
+// variant for narrow levels) live in blake2s.cuh; this file holds the two tree schedules.
 #include <cstdlib>
 
 #include "blake2s.cuh"
