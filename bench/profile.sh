@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra"   # the default steps/warmup: clocks need a few steps to ramp under the profiler
+CMD="python $REPO/bench.py --no-cpu-baseline --no-extra"   # the default steps/warmup: clocks need ~100 ms to ramp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ntt -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o ntt -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o ntt -- $CMD > $OUT/pmc_write.log 2>&1
