@@ -167,11 +167,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32x8 (256-bit Montgomery, integer)",
+        "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": "2^%d-point NTT + iNTT over the src/bn256.rs Fr field, device-resident, "
                                "bit-exact vs CPU oracle (BASELINE config[1])" % log_n,
                    "log_n": log_n, "field": "bn256.rs Fr (255-bit, R=2^256)",
+                   "arithmetic": "exact integer: 256-bit Montgomery elements as 9 x 29-bit limbs in u32, "
+                                 "32x32->64 multiply-accumulate (v_mad_u64_u32)",
                    "parallelism": ("6-step, 2^%d points over %d GPUs, RCCL all-to-all transposes"
                                    % (log_n + world.bit_length() - 1, world)) if args.mode == "sixstep"
                    else ("1 polynomial per GPU" if world > 1 else "1 GPU")},
