@@ -275,7 +275,8 @@ def test_iop_tree_benchmark_sizes_are_made_of_their_subtrees(gpu_ctxs, oracles, 
 
 
 # ---------------------------------------------------------------- FRI commit phase
-@pytest.mark.parametrize("log_deg,lde_factor,out_deg", [(2, 4, 2), (3, 4, 1), (6, 8, 1), (8, 16, 2), (11, 8, 1), (13, 8, 4)])
+@pytest.mark.parametrize("log_deg,lde_factor,out_deg", [(2, 4, 2), (3, 4, 1), (4, 2, 1), (5, 32, 2), (6, 8, 1), (8, 16, 2),
+                                                        (9, 4, 8), (10, 2, 1), (11, 8, 1), (13, 8, 4), (15, 4, 1)])
 def test_fri_commit_matches_oracle(gpu_ctxs, oracles, field_name, log_deg, lde_factor, out_deg):
     """proof_from_lde_by_values (src/fri/fri_on_values.rs:11-159): prototype equality field by field,
     as test_one_fri_step asserts between its two CPU paths (src/fri/mod.rs:338-343)."""
