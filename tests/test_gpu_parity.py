@@ -600,32 +600,37 @@ def test_fri_produce_proof(gpu_ctxs, oracles, log_deg, lde_factor, out_deg, inde
 # ---------------------------------------------------------------- re-entrancy
 def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     """The reference calls best_fft concurrently from scoped threads (src/arp/per_register/mod.rs:43-49,
-    src/polynomials/mod.rs:446-460); the ABI must be re-entrant on one context (ctypes drops the GIL)."""
+    src/polynomials/mod.rs:446-460); the ABI must be re-entrant on one context (ctypes drops the GIL).
+    Eight threads on three copy lanes, different sizes per thread (the lanes' staging buffers grow while
+    other lanes are in flight), in-place transforms, LDE (separate in/out buffers) and tree builds."""
     import threading
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
-    log_n = 13
-    n = 1 << log_n
-    _, _, w = O.domain(n)
-    inputs = [O.random_elements(n, 500 + t) for t in range(8)]
-    expected = []
-    for a in inputs:
+    sizes = [10, 13, 11, 14, 12, 13, 15, 10]
+    inputs = [O.random_elements(1 << lg, 500 + t) for t, lg in enumerate(sizes)]
+    expected, expected_lde = [], []
+    for a, lg in zip(inputs, sizes):
         e = a.copy()
-        O.serial_fft(e, w, log_n)
+        O.serial_fft(e, O.domain(1 << lg)[2], lg)
         expected.append(e)
+        expected_lde.append(O.poly_lde(a, 4))
     results = [None] * len(inputs)
+    results_lde = [None] * len(inputs)
     errors = []
 
     def work(t):
         try:
+            lg = sizes[t]
+            w = O.domain(1 << lg)[2]
             for _ in range(3):
                 b = inputs[t].copy()
                 if t % 2:
-                    ctx.fft(b, w, log_n)
+                    ctx.fft(b, w, lg)
                 else:
                     ctx.poly_fft(b)
                 results[t] = b
+                results_lde[t] = ctx.poly_lde(inputs[t], 4)
                 nodes = ctx.iop_create(b)
-                assert nodes.shape == (n, 32)
+                assert nodes.shape == (1 << lg, 32)
         except Exception as exc:   # noqa: BLE001
             errors.append(exc)
 
@@ -637,6 +642,7 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     assert not errors, errors
     for t in range(len(inputs)):
         assert np.array_equal(results[t], expected[t]), t
+        assert np.array_equal(results_lde[t], expected_lde[t]), t
 
 
 # ---------------------------------------------------------------- value-form polynomial ops (§8 f.1)
