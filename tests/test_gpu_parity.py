@@ -846,6 +846,77 @@ def test_lde_by_cosets_single_rank_on_device(gpu_ctxs, oracles, coset):
     assert root == bytes(O.iop_create(exp)[1])
 
 
+# ---------------------------------------------------------------- the pieces composed the way the prover composes them
+@pytest.mark.parametrize("log_n,cols,factor", [(6, 3, 8), (10, 5, 8)])
+def test_prover_shaped_pipeline_matches_restatement(gpu_ctxs, oracles, log_n, cols, factor):
+    """The order of operations of Prover::prove (src/prover/mod.rs:66-174), on device end to end and against
+    the oracle / Python restatement: batched LDE of the register columns and their commitments, roots into
+    the transcript, a transcript challenge that combines the columns (add_assign_scaled), FRI commit of the
+    combination, its roots into the transcript, query indices from transcript bytes
+    (bytes_to_challenge_index), query proofs, verification."""
+    import torch
+    from hodor_amd import _lib
+    ctx, O, F = gpu_ctxs["bn256"], oracles["bn256"], P.BN256
+    n, big = 1 << log_n, (1 << log_n) * factor
+    coeffs = [O.random_elements(n, 4000 + c) for c in range(cols)]
+    # ---- device
+    d_src = torch.from_numpy(np.concatenate(coeffs).view(np.int64)).cuda()
+    d_lde = torch.empty((cols * big, 4), dtype=torch.int64, device="cuda")
+    d_nodes = torch.empty((cols * big, 32), dtype=torch.uint8, device="cuda")
+    ctx.poly_lde_batch_dev(d_src, d_lde, log_n, factor, cols)
+    ctx.iop_create_batch_dev(d_lde, big, cols, d_nodes)
+    ctx.synchronize()
+    t_dev = _lib.Transcript(ctx)
+    roots_dev = [bytes(d_nodes[c * big + 1].cpu().numpy()) for c in range(cols)]
+    for r in roots_dev:
+        t_dev.commit_bytes(r)
+    alpha_dev = t_dev.get_challenge()
+    comb = d_lde[:big].clone()
+    power = alpha_dev
+    for c in range(1, cols):                                   # f_0 + alpha f_1 + alpha^2 f_2 + ...
+        ctx.poly_add_scaled_dev(comb, d_lde[c * big:(c + 1) * big], big, power)
+        power = ctx.mul(power, alpha_dev)
+    proto = ctx.fri_commit_dev(comb, big, factor, 1)
+    for r in proto.roots:
+        t_dev.commit_bytes(r)
+    for c in proto.final_coeffs:
+        t_dev.commit_field_element(array_to_ints(c.reshape(1, 4))[0])
+    idx_dev = [ctx.bytes_to_challenge_index(t_dev.get_challenge_bytes(), big, factor) for _ in range(4)]
+    proofs_dev = [proto.produce_proof(comb, i) for i in idx_dev]
+    comb_host = comb.cpu().numpy().view(np.uint64)
+
+    # ---- restatement (C oracle for the bulk, Python for transcript / queries / verifier)
+    ldes = [O.poly_lde(c, factor) for c in coeffs]
+    t_ref = P.Transcript(F)
+    roots_ref = [bytes(O.iop_create(l)[1]) for l in ldes]
+    for r in roots_ref:
+        t_ref.commit_bytes(r)
+    alpha_ref = t_ref.get_challenge()                          # canonical
+    exp_comb = ldes[0].copy()
+    power = F.to_mont(alpha_ref)
+    for c in range(1, cols):
+        O.poly_add_scaled(exp_comb, ldes[c], power)
+        power = O.mul(power, F.to_mont(alpha_ref))
+    ref = O.fri_commit(exp_comb, factor, 1)
+    for r in ref["roots"]:
+        t_ref.commit_bytes(r)
+    for c in array_to_ints(ref["final_coeffs"]):
+        t_ref.commit_field_element(F.from_mont(c))
+    idx_ref = [P.bytes_to_challenge_index(t_ref.get_challenge_bytes(), big, factor) for _ in range(4)]
+
+    assert roots_dev == roots_ref
+    assert F.from_mont(alpha_dev) == alpha_ref
+    assert np.array_equal(comb_host, exp_comb)
+    assert proto.roots == ref["roots"] and proto.serialized == ref["serialized"]
+    assert idx_dev == idx_ref
+    ints = array_to_ints(exp_comb)
+    for i, proof in zip(idx_dev, proofs_dev):
+        assert i % 2 == 1 and i % factor != 0          # bytes_to_challenge_index steps off the sub-domains (:251-260)
+        assert ctx.fri_verify_proof(proof["raw"], i, ints[i]) is True
+        assert P.fri_verify_proof_queries(F, proof, i, ints[i])
+    proto.free()
+
+
 # ---------------------------------------------------------------- batched multi-column LDE + commit (§8 f.4)
 @pytest.mark.parametrize("log_n,factor,batch", [(4, 4, 3), (10, 8, 5), (13, 16, 4)])
 def test_batched_lde_and_commit(gpu_ctxs, oracles, log_n, factor, batch):
