@@ -43,7 +43,7 @@ EXPORTS = [
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
-    "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev",
+    "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_prototype",
 ]
 
@@ -500,6 +500,11 @@ class Context:
         cc = _fr(c) if c is not None else None
         self._chk(self.L.hodor_poly_unary_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.c_int(code),
                                               C.byref(cc) if cc is not None else None, C.c_uint64(e)))
+
+    def gen_elements_dev(self, dst, first_index, count, seed, stream=None):
+        """dst[r] = element first_index + r of the SplitMix64 input stream `seed`."""
+        self._chk(self.L.hodor_gen_elements_dev(self.h, C.c_void_p(stream), _dptr(dst), C.c_uint64(first_index),
+                                                C.c_size_t(count), C.c_uint64(seed)))
 
     def poly_batch_inversion_dev(self, a, n, stream=None):
         self._chk(self.L.hodor_poly_batch_inversion_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n)))

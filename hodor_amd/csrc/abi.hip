@@ -31,6 +31,16 @@ static void make_params9(const HostField &F, Fr9Params *Q)
         if (i > 0) c -= 1;
         Q->c4p[i] = c;
     }
+    // 5p = 4p + p, spread the same way
+    uint32_t carry = 0;
+    for (int i = 0; i < 9; i++) {
+        uint32_t v = q[i] + Q->p[i] + carry;
+        carry = i < 8 ? v >> 29 : 0;
+        if (i < 8) v &= 0x1fffffffu;
+        if (i < 8) v += 1u << 29;
+        if (i > 0) v -= 1;
+        Q->c5p[i] = v;
+    }
     // mu = floor(2^(red_bit + 16) / p), red_bit = NUM_BITS - 5, by binary long division (~12-bit quotient)
     const int red_bit = (int)F.num_bits - 5;
     Q->red_shift = (uint32_t)(red_bit - 232);
@@ -132,9 +142,9 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     t.log_n = log_n;
     t.log_r = log_r;
     uint64_t cnt = log_r ? (1ull << (log_r - 1)) : 1;
-    HIPCHK(hipMalloc((void **)&t.rtw, cnt * 48));
-    HIPCHK(pow_table_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt, 1,
-                            ctx->P));
+    HIPCHK(hipMalloc((void **)&t.rtw, cnt * 112));
+    HIPCHK(pow_table_w3_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt,
+                               ctx->K3, ctx->P));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->radix_tables.push_back(t);
     *out = t.rtw;
@@ -365,6 +375,14 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
     Fr one = to_dev(ctx->F.one);
     for (int i = 0; i < 8; i++) ctx->P.one[i] = one.v[i];
     make_params9(ctx->F, &ctx->Q);
+    {   // plain-integer 2^(87 c), c = 1..3: into_repr strips the R of the Montgomery power
+        HFr two = ctx->F.from_u64(2);
+        for (int c = 0; c < 3; c++) {
+            HFr plain;
+            ctx->F.into_repr(ctx->F.pow(two, 87 * (uint64_t)(c + 1)), plain.l);
+            ctx->K3.k[c] = to_dev(plain);
+        }
+    }
     // BASE_BLAKE2S_PARAMS, src/iop/blake2s_trivial_iop.rs:8-16
     HostBlake2s::keyed_midstate(ctx->mid.h, (const uint8_t *)"Squeamish Ossifrage", 19,
                                 (const uint8_t *)"Shaftoe", 7);
@@ -631,6 +649,17 @@ extern "C" int hodor_poly_unary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, s
     if (c) cd = to_dev(to_h(c));
     if (op == 2 && e == 2) op = 1;   // pow(2) is square (src/polynomials/mod.rs:746-748)
     HIPCHK(unary_launch(pick_stream(ctx, stream), (uint4 *)a, n, op, cd, e, ctx->P));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_gen_elements_dev(hodor_ctx *ctx, void *stream, hodor_fr *dst, uint64_t first_index,
+                                      size_t count, uint64_t seed)
+{
+    NEED_DEVICE();
+    if (!dst && count) return HODOR_ERR_INVALID;
+    const uint64_t top_mask = ctx->F.num_bits >= 256 ? ~0ull : ((1ull << (ctx->F.num_bits - 192)) - 1);
+    HIPCHK(gen_elements_launch(pick_stream(ctx, stream), (uint4 *)dst, first_index, count, seed, top_mask,
+                               to_dev(ctx->F.r2), ctx->P));
     return HODOR_OK;
 }
 

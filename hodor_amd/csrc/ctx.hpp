@@ -22,8 +22,12 @@ namespace hodor {
 hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr9 *scale, const Fr9Params &);
 hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
                             uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
+hipError_t pow_table_w3_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
+                               uint32_t log_stride, uint64_t count, const W3Consts &, const FrParams &);
 hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &);
 hipError_t distribute_powers_small_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
+hipError_t gen_elements_launch(hipStream_t, uint4 *out, uint64_t first, uint64_t count, uint64_t seed,
+                               uint64_t top_mask, const Fr &r2, const FrParams &);
 hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
 hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
 hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
@@ -108,6 +112,7 @@ struct hodor_ctx {
     HostField F;
     FrParams P;
     Fr9Params Q;
+    W3Consts K3;               // 2^87, 2^174, 2^261 mod p (plain integers) for the W3 table generator
     B2Mid mid;
     hipStream_t stream = nullptr;
     std::mutex mu;

@@ -1,0 +1,94 @@
+// fr9w3.cuh — K1'': data x table-constant products with a 3-limb Montgomery step ("W3 constants").
+//
+// Every multiplication of the transforms is (lazily reduced data) x (a constant that comes out of a
+// table): butterfly twiddles (src/fft/radix4_fft/mod.rs:72-113), inter-pass twiddles, coset powers
+// (src/fft/mod.rs:110-123), the n^-1 scale (src/polynomials/mod.rs:777-787).  A table can therefore
+// hold the constant pre-shifted three ways,
+//
+//     W_c = w * 2^(87 (c + 1)) mod p,   c = 0, 1, 2        (w the plain integer value, 87 = 3 x 29)
+//
+// and with x split into its three 87-bit limb groups  x = X_0 + X_1 2^87 + X_2 2^174:
+//
+//     T = X_0 W_0 + X_1 W_1 + X_2 W_2  ==  x w 2^87  (mod p),      11 columns of 29 bits
+//     r = (T + m p) / 2^87             ==  x w       (mod p),      m = -T p^-1 mod 2^87
+//
+// i.e. only THREE Montgomery steps instead of nine: 81 + 27 v_mad_u64_u32 and 3 v_mul_lo against the
+// 162 + 9 of fr9_mul, for a table entry of 27 limbs instead of 9.  Data keeps whatever form it is in
+// (the reference's R = 2^256 Montgomery image stays that image: the constant is a plain integer).
+//
+// Bounds (p < 2^255): with x normalized (limbs 0..7 < 2^29, value < 2^261) every X_c < 2^87, so
+// T < 3 * 2^87 p and r < 4p, normalized.  Column sums: at most 9 data terms (< 2^29 * 2^29 when x is
+// normalized, < 2^31.5 * 2^29 tolerated) + 3 reduction terms < 2^64.
+#pragma once
+#ifndef HODOR_HOST_TEST
+#include "fr9.cuh"
+#endif
+
+namespace hodor {
+
+struct Fr9W3 {
+    uint32_t w[3][9];
+};
+
+#ifndef FR9_MAD
+#define FR9_MAD(acc, x, y) do { acc += (uint64_t)(x) * (y); } while (0)
+#endif
+
+__device__ __forceinline__ Fr9 fr9_mul3(const Fr9 &a, const Fr9W3 &W, const Fr9Params &P)
+{
+    uint32_t m[3];
+    Fr9 t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (k - j >= 0 && k - j < 9) FR9_MAD(acc, a.v[3 * c + j], W.w[c][k - j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j < k && k - j < 9) FR9_MAD(acc, m[j], P.p[k - j]);
+        }
+        if (k < 3) {
+            m[k] = ((uint32_t)acc * P.pinv) & HODOR_M29;
+            FR9_MAD(acc, m[k], P.p[0]);
+        } else {
+            t.v[k - 3] = (uint32_t)acc & HODOR_M29;
+        }
+        acc >>= 29;
+    }
+    t.v[8] = (uint32_t)acc;
+    return t;
+}
+
+// 27 limbs stored as 7 x 16 bytes (28 words, the last one unused)
+__device__ __forceinline__ Fr9W3 fr9w3_load(const void *ptr)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(ptr);
+    uint32_t f[28];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        uint4 v = q[i];
+        f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+    }
+    Fr9W3 r;
+#pragma unroll
+    for (int i = 0; i < 27; i++) r.w[i / 9][i % 9] = f[i];
+    return r;
+}
+
+__device__ __forceinline__ void fr9w3_store(void *ptr, const Fr9W3 &a)
+{
+    uint4 *q = reinterpret_cast<uint4 *>(ptr);
+    uint32_t f[28];
+#pragma unroll
+    for (int i = 0; i < 27; i++) f[i] = a.w[i / 9][i % 9];
+    f[27] = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) q[i] = make_uint4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+}
+
+}  // namespace hodor

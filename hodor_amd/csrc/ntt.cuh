@@ -18,10 +18,15 @@ struct TwoLevel {
     uint32_t lo_bits;
 };
 
+// 2^87, 2^174, 2^261 mod p as plain integers: turn an R-form power into its W3 entry (fr9w3.cuh)
+struct W3Consts {
+    Fr k[3];
+};
+
 struct PassArgs {
     const uint4 *src;        // n elements (only the first nnz are read; the rest are implicit zeros)
     uint4 *dst;              // n elements
-    const uint4 *rtw;        // omega_R^e, e < R/2  (R = radix of this pass)
+    const uint4 *rtw;        // omega_R^e, e < R/2  (R = radix of this pass), W3 entries of 7 x 16 B
     TwoLevel tw;             // inter-pass twiddles (powers of the size-n omega; hi possibly scaled)
     TwoLevel pre;            // optional input scaling x[i] *= g^i  (coset shift), lo == nullptr if unused
     TwoLevel post;           // optional output scaling X[k] *= h^k, lo == nullptr if unused
@@ -35,7 +40,7 @@ struct PassArgs {
     uint32_t batch;          // number of independent size-n transforms (grid.y); dst arrays are n elements apart
     uint64_t src_batch_stride;   // distance between the batch's source arrays, in elements
     uint32_t log_skip;       // first pass of a zero-padded transform: nnz == n >> log_skip (see k_ntt_pass)
-    uint32_t dbg;            // profiling only (HODOR_DBG): 1 skip butterflies, 2 skip twiddles, 4 skip loads, 8 skip stores
+    uint32_t dbg;            // read only by -DHODOR_ABLATE builds (bench/ablate.sh): 1 skip butterflies, 2 twiddles, 4 loads, 8 stores
 };
 
 // One FRI folding step (src/fri/fri_on_values.rs:77-100), shared by k_fri_fold (fri.hip) and the fused

@@ -14,20 +14,25 @@
 //     global read and write is a run of C*32 contiguous bytes.
 //   * Inside the workgroup the R-point transform runs out of LDS (in-place DIT, two radix-2 stages
 //     fused per barrier = one radix-4 step), twiddles of the sub-transform staged in LDS.
-//   * Inside the kernel elements live in the carry-free 9 x 29-bit form of fr9.cuh (162 mads per
-//     product, add/sub = 9 plain adds, lazily reduced); HBM always holds the reference's 8 x 32-bit
-//     Montgomery image.  LDS keeps limbs 0-3 / 4-7 as two 16-byte arrays plus a 4-byte array for
-//     limb 8, columns XOR-swizzled by the row index.
+//   * Inside the kernel elements live in the carry-free 9 x 29-bit form of fr9.cuh (add/sub = 9
+//     plain adds, lazily reduced); HBM always holds the reference's 8 x 32-bit Montgomery image.
+//     LDS keeps limbs 0-3 / 4-7 as two 16-byte arrays plus a 4-byte array for limb 8, columns
+//     XOR-swizzled by the row index.
+//   * Butterfly twiddles sit in LDS as W3 constants (fr9w3.cuh: the twiddle pre-shifted three ways,
+//     112 B per entry), so a butterfly product is 108 v_mad_u64_u32 + 3 v_mul_lo instead of 162 + 9.
 //   * Inter-pass twiddles come from a two-level power table (L2-resident) instead of an n-entry
-//     table streamed from HBM.
+//     table streamed from HBM (48-byte entries, full-width fr9_mul: a W3 `hi` table would not fit L2).
 //
-// Value bounds inside a pass (p < 2^255, R' = 2^261 > 64 p): loaded values are < 2.1 p (a packed
-// intermediate) or < 1.5 p (fresh product); each radix-4 step adds at most 8 p (two subtractions
-// with the 4 p offset), so after the <= 5 steps of a pass values stay < 45 p < 2^261, and every
-// subtrahend is a fresh product (< 2 p) except in the twiddle-free first step, handled explicitly.
+// Value bounds inside a pass (p < 2^255, 2^261 > 64 p): loaded values are < 2^256 < 4 p (a packed
+// value) or < 3 p (fresh fr9_mul product); a W3 product of a normalized value is < 4 p; subtraction
+// adds the 5 p offset, so a radix-4 step raises the bound by at most 10 p (two subtractions):
+// 14 p after the twiddle-free first step (9 p after a leading radix-2 stage), <= 59 p after the
+// <= 6 steps of a pass of radix <= 2^11.  Every subtrahend is a fresh product (< 4 p) except in the
+// twiddle-free first step, handled explicitly; every product takes a normalized operand.
 #include <cstdlib>
 
 #include "ntt.cuh"
+#include "fr9w3.cuh"
 
 namespace hodor {
 
@@ -51,6 +56,26 @@ k_pow_table(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, u
         for (int i = 0; i < 5; i++) w = fr_add(w, w, P);   // * 2^5: R-form -> R'-form
         fr9_store48(out + 3 * j, fr9_unpack(w));
     }
+}
+
+// W3 entries (fr9w3.cuh): out[j] = { v 2^87, v 2^174, v 2^261 } mod p for the plain integer
+// v = mult * base^(j << log_stride).  K.k[c] holds 2^(87 (c + 1)) mod p as a plain integer, so the
+// Montgomery product with the R-form power strips the R and leaves the plain, canonical W_c.
+__global__ void __launch_bounds__(256)
+k_pow_table_w3(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, W3Consts K, FrParams P)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fr w = fr_pow(base, j << log_stride, P);
+    w = fr_mul(w, mult, P);
+    Fr9W3 e;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        Fr9 t = fr9_unpack(fr_mul(w, K.k[c], P));
+#pragma unroll
+        for (int i = 0; i < 9; i++) e.w[c][i] = t.v[i];
+    }
+    fr9w3_store(out + 7 * j, e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -79,6 +104,16 @@ __device__ __forceinline__ void lds_put(const LdsView &L, uint32_t s, const Fr9 
     L.c1[s] = a.v[8];
 }
 
+// a - b + 5p, limb-wise non-negative when b is normalized and < 4p (c5p: 5p with limbs 0..7 raised
+// by 2^29 borrowed from the limb above, so its top limb still exceeds that of any value < 4p)
+__device__ __forceinline__ Fr9 fr9_sub5(const Fr9 &a, const Fr9 &b, const Fr9Params &P)
+{
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (P.c5p[i] - b.v[i]);
+    return r;
+}
+
 // base^e from the two-level table (R'-form, normalized, < 2p)
 __device__ __forceinline__ Fr9 two_level_pow9(const TwoLevel &t, uint64_t e, const Fr9Params &Q)
 {
@@ -98,6 +133,14 @@ __device__ __forceinline__ Fr9 two_level_pow9(const TwoLevel &t, uint64_t e, con
 // ---------------------------------------------------------------------------------------------
 constexpr int NTT_MAX_THREADS = 512;
 
+// HODOR_ABLATE builds (csrc/Makefile target `ablate`, bench/ablate.sh) carry the phase-skipping
+// switches used to apportion the kernel's time; the shipped library is compiled without them.
+#ifdef HODOR_ABLATE
+#define ABL(bit) (A.dbg & (bit))
+#else
+#define ABL(bit) false
+#endif
+
 __global__ void __launch_bounds__(NTT_MAX_THREADS)
 k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 {
@@ -106,22 +149,20 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     const uint32_t log_r = A.log_r, log_c = A.log_c;
     const uint32_t R = 1u << log_r, C = 1u << log_c;
     // element (row, c) sits at slot row*C + (c ^ (row & (C-1))): the XOR swizzle spreads a column over
-    // all C 16-byte bank groups without the 1/C padding (two workgroups must fit the 160 KiB of a CU)
+    // all C 16-byte bank groups without the 1/C padding (three workgroups must fit the 160 KiB of a CU)
     const uint32_t Cm = C - 1;
 #define SLOT(row, c) ((((uint32_t)(row)) << log_c) + (((uint32_t)(c)) ^ (((uint32_t)(row)) & Cm)))
     const uint32_t slots = R << log_c;
     const uint32_t half_r = (R >> 1) ? (R >> 1) : 1;
-    // carve: data a4 | data b4 | tw a4 | tw b4 | data c1 | tw c1   (16-byte arrays first)
-    LdsView D, T;
+    // carve: data a4 | data b4 | twiddles (7 x 16 B per W3 entry) | data c1
+    LdsView D;
     D.a4 = smem;
     D.b4 = smem + slots;
-    T.a4 = smem + 2 * slots;
-    T.b4 = smem + 2 * slots + half_r;
-    D.c1 = reinterpret_cast<uint32_t *>(smem + 2 * slots + 2 * half_r);
-    T.c1 = D.c1 + slots;
+    uint4 *const T = smem + 2 * slots;
+    D.c1 = reinterpret_cast<uint32_t *>(T + 7 * half_r);
 
     // stage omega_R^e (e < R/2) into LDS
-    for (uint32_t e = tid; e < (R >> 1); e += nthreads) lds_put(T, e, fr9_load48(A.rtw + 3 * e));
+    for (uint32_t e = tid; e < 7 * (R >> 1); e += nthreads) T[e] = A.rtw[e];
 
     // batched transforms: blockIdx.y selects one of `batch` independent size-n arrays
     const uint4 *src_b = A.src + 2ull * blockIdx.y * A.src_batch_stride;   // first LDE pass: n/f apart
@@ -144,14 +185,14 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         uint64_t g = j + (uint64_t)i * n_over_r;
         Fr9 x;
         if (g < A.nnz) {
-            if (A.dbg & 4) {
+            if (ABL(4)) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) x.v[k] = (uint32_t)g + k;
+                for (int k = 0; k < 9; k++) x.v[k] = ((uint32_t)g + k) & HODOR_M29;
             } else {
                 x = fr9_unpack(fr_load(src_b + 2 * g));
             }
             if (A.pre.lo != nullptr && g != 0) x = fr9_mul(x, two_level_pow9(A.pre, g, Q), Q);
-            if (A.apply_tw && !(A.dbg & 2)) {
+            if (A.apply_tw && !ABL(2)) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
                 if (ex != 0 || A.tw_always) x = fr9_mul(x, two_level_pow9(A.tw, ex, Q), Q);
             }
@@ -175,9 +216,9 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             uint32_t r0 = ((q >> log_m) << (log_m + 1)) + jp;
             uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c);
             Fr9 x0 = lds_get(D, s0), x1 = lds_get(D, s1);
-            // m == 1: twiddle 1 and x1 is a stored value (normalized, < 2.1p), a valid subtrahend
-            if (m > 1) x1 = fr9_mul(x1, lds_get(T, jp << (log_r - log_m - 1)), Q);
-            Fr9 y0 = fr9_add(x0, x1), y1 = fr9_sub(x0, x1, Q);
+            // m == 1: twiddle 1 and x1 is a stored value (normalized, < 4p), a valid subtrahend
+            if (m > 1) x1 = fr9_mul3(x1, fr9w3_load(T + 7 * (jp << (log_r - log_m - 1))), Q);
+            Fr9 y0 = fr9_add(x0, x1), y1 = fr9_sub5(x0, x1, Q);
             fr9_normalize(y0);
             fr9_normalize(y1);
             lds_put(D, s0, y0);
@@ -186,7 +227,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         log_m += 1;
         __syncthreads();
     }
-    if (A.dbg & 1) log_m = log_r;
+    if (ABL(1)) log_m = log_r;
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
@@ -203,26 +244,29 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             Fr9 x3 = lds_get(D, s3);
             Fr9 t;
             if (m > 1) {
-                Fr9 wa = lds_get(T, jp << (log_r - log_m - 1));
-                t = fr9_mul(x1, wa, Q);
-                x1 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
-                t = fr9_mul(x3, wa, Q);
-                x3 = fr9_sub(x2, t, Q); x2 = fr9_add(x2, t);
-                Fr9 wb0 = lds_get(T, jp << (log_r - log_m - 2));
-                t = fr9_mul(x2, wb0, Q);
-                x2 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
+                const Fr9W3 wa = fr9w3_load(T + 7 * (jp << (log_r - log_m - 1)));
+                t = fr9_mul3(x1, wa, Q);
+                x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                t = fr9_mul3(x3, wa, Q);
+                x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
+                // the second stage multiplies the lazy sums: carry-propagate them first so that the
+                // W3 product sees 87-bit limb groups (its < 4p bound)
+                fr9_normalize(x2);
+                fr9_normalize(x3);
+                t = fr9_mul3(x2, fr9w3_load(T + 7 * (jp << (log_r - log_m - 2))), Q);
+                x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
             } else {
-                // twiddles are 1: subtrahends are stored values (normalized, < 2.1p), except the
-                // stage-B one, a lazy sum that is first brought back under 2.1p
-                t = x1; x1 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
-                t = x3; x3 = fr9_sub(x2, t, Q); x2 = fr9_add(x2, t);
+                // twiddles are 1: subtrahends are stored values (normalized, < 4p), except the
+                // stage-B one, a lazy sum that is first brought back under 2p
+                t = x1; x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                t = x3; x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
                 t = x2;
                 fr9_reduce_partial(t, Q);
-                x2 = fr9_sub(x0, t, Q); x0 = fr9_add(x0, t);
+                x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                fr9_normalize(x3);
             }
-            Fr9 wb1 = lds_get(T, (jp + m) << (log_r - log_m - 2));
-            t = fr9_mul(x3, wb1, Q);
-            x3 = fr9_sub(x1, t, Q); x1 = fr9_add(x1, t);
+            t = fr9_mul3(x3, fr9w3_load(T + 7 * ((jp + m) << (log_r - log_m - 2))), Q);
+            x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
             fr9_normalize(x0);
             fr9_normalize(x1);
             fr9_normalize(x2);
@@ -250,7 +294,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         if (A.post.lo != nullptr && o != 0) x = fr9_mul(x, two_level_pow9(A.post, o, Q), Q);
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
-        if ((A.dbg & 8) && y.v[0] != 0x12345u) continue;
+        if (ABL(8) && y.v[0] != 0x12345u) continue;
         fr_store(dst_b + 2 * o, y);
     }
 }
@@ -262,7 +306,7 @@ size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c)
 {
     size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c;
     size_t half_r = (R / 2) ? R / 2 : 1;
-    return (R * C + half_r) * 36;
+    return R * C * 36 + half_r * 112;
 }
 
 hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *scale, const Fr9Params &Q)
@@ -285,13 +329,15 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
         const char *e = getenv("HODOR_NTT_THREADS");
         threads_override = e ? atoi(e) : 0;
     }
+    PassArgs B = A;
+#ifdef HODOR_ABLATE
     static int dbg = -1;
     if (dbg < 0) {
         const char *e = getenv("HODOR_DBG");
         dbg = e ? atoi(e) : 0;
     }
-    PassArgs B = A;
     B.dbg = (uint32_t)dbg;
+#endif
     uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
     unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
@@ -305,6 +351,15 @@ hipError_t pow_table_launch(hipStream_t stream, uint4 *out, const Fr &base, cons
 {
     unsigned grid = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(k_pow_table, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride, count, fmt,
+                       P);
+    return hipGetLastError();
+}
+
+hipError_t pow_table_w3_launch(hipStream_t stream, uint4 *out, const Fr &base, const Fr &mult,
+                               uint32_t log_stride, uint64_t count, const W3Consts &K, const FrParams &P)
+{
+    unsigned grid = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(k_pow_table_w3, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride, count, K,
                        P);
     return hipGetLastError();
 }

@@ -45,6 +45,44 @@ k_distribute_powers(uint4 *a, uint64_t n, TwoLevel t, Fr9Params Q)
     }
 }
 
+// Synthetic input, index-addressable: element i is the first of 16 candidates
+// (four SplitMix64 outputs each, top limb masked to the field's bit length) below p, converted to
+// Montgomery form.  Bit-identical to oracle/hodor_oracle.c:o_gen_elements, which documents the stream.
+__device__ __forceinline__ uint64_t splitmix64_out(uint64_t seed, uint64_t m)
+{
+    uint64_t z = seed + (m + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+k_gen_elements(uint4 *out, uint64_t first, uint64_t count, uint64_t seed, uint64_t top_mask, Fr r2, FrParams P)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < count; r += stride) {
+        const uint64_t i = first + r;
+        Fr x;
+        bool ok = false;
+        for (uint64_t t = 0; t < 16 && !ok; t++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint64_t w = splitmix64_out(seed, 4 * (16 * i + t) + k);
+                if (k == 3) w &= top_mask;
+                x.v[2 * k] = (uint32_t)w;
+                x.v[2 * k + 1] = (uint32_t)(w >> 32);
+            }
+            ok = false;   // x < p ?
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                if (x.v[k] != P.p[k]) { ok = x.v[k] < P.p[k]; break; }
+            }
+        }
+        if (!ok) { x.v[6] = 0; x.v[7] = 0; }
+        fr_store(out + 2 * r, fr_mul(x, r2, P));
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_scale(uint4 *a, uint64_t n, Fr s, FrParams P)
 {
@@ -344,6 +382,17 @@ hipError_t binary_launch(hipStream_t s, uint4 *a, const uint4 *b, uint64_t n, in
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_binary, dim3(stream_grid(n)), dim3(256), 0, s, a, b, n, op, P);
+    return hipGetLastError();
+}
+
+hipError_t gen_elements_launch(hipStream_t stream, uint4 *out, uint64_t first, uint64_t count, uint64_t seed,
+                               uint64_t top_mask, const Fr &r2, const FrParams &P)
+{
+    if (count == 0) return hipSuccess;
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_gen_elements, dim3((unsigned)blocks), dim3(256), 0, stream, out, first, count, seed,
+                       top_mask, r2, P);
     return hipGetLastError();
 }
 

@@ -206,6 +206,12 @@ int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, si
 /* evaluate_at: *out (host) = sum coeffs[i] g^i.  Synchronises the stream. */
 int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream, const hodor_fr *coeffs, size_t n, const hodor_fr *g,
                                hodor_fr *out);
+/* Synthetic input for tests and benchmarks: dst[r] = element first_index + r of the
+ * index-addressable SplitMix64 stream `seed` — uniform canonical residues (rejection-sampled < p)
+ * in Montgomery form, i.e. what the reference's tests draw with Fr::rand (src/fft/mod.rs:71-77), but
+ * reproducible on the CPU (oracle/hodor_oracle.c:o_gen_elements) and shardable across GPUs. */
+int hodor_gen_elements_dev(hodor_ctx *ctx, void *stream, hodor_fr *dst, uint64_t first_index, size_t count,
+                           uint64_t seed);
 /* Merkle tree over n device-resident leaves into n*32 device bytes */
 int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, uint8_t *nodes);
 /* IOP::query (src/iop/blake2s_trivial_iop.rs:324-338) on device-resident leaves and tree: the leaf

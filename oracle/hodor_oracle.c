@@ -1034,3 +1034,51 @@ size_t o_fri_serialize(const ofri_proto *p, uint8_t *buf, size_t cap)
     }
     return o;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic input: index-addressable, so the GPU (hodor_gen_elements_dev) and
+ * this oracle produce the same buffer from (seed, index) with no host staging.
+ *   w(m)      = output number m of the SplitMix64 stream seeded `seed`
+ *             = mix(seed + (m + 1) * 0x9E3779B97F4A7C15)
+ *   cand(i,t) = limbs w(4*(16 i + t) + k), k = 0..3, top limb masked to NUM_BITS - 192 bits
+ *   a[i]      = the first cand(i, t), t = 0..15, that is < p (canonical residue; after 16
+ *               rejections — probability < 2^-16 per element even at the worst mask — the top limb is cleared),
+ *               converted to Montgomery form as Fr::from_repr does.
+ * The reference draws test inputs from rand 0.4's XorShiftRng (src/fft/mod.rs:71-77), which is
+ * sequential; any uniform canonical residues exercise the same code.
+ * ------------------------------------------------------------------------------------------ */
+static uint64_t splitmix64_out(uint64_t seed, uint64_t m)
+{
+    uint64_t z = seed + (m + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+typedef struct { const ofield *f; ofr *out; uint64_t first, seed; } gen_ctx;
+static void gen_chunk(void *vctx, size_t ci, size_t start, size_t len)
+{
+    (void)ci;
+    gen_ctx *c = (gen_ctx *)vctx;
+    const ofield *f = c->f;
+    const uint64_t mask = f->num_bits >= 256 ? ~0ULL : ((1ULL << (f->num_bits - 192)) - 1);
+    for (size_t r = start; r < start + len; r++) {
+        uint64_t i = c->first + r, cand[4];
+        int ok = 0;
+        for (uint64_t t = 0; t < 16 && !ok; t++) {
+            for (uint64_t k = 0; k < 4; k++) cand[k] = splitmix64_out(c->seed, 4 * (16 * i + t) + k);
+            cand[3] &= mask;
+            ok = !geq4(cand, f->p);
+        }
+        if (!ok) cand[3] = 0;
+        ofr_from_repr(f, &c->out[r], cand);
+    }
+}
+
+void o_gen_elements(const ofield *f, ofr *out, uint64_t first_index, size_t count, uint64_t seed,
+                    uint32_t cpus)
+{
+    gen_ctx c = {f, out, first_index, seed};
+    worker_scope(cpus, count, gen_chunk, &c);
+}
+

@@ -125,6 +125,10 @@ void o_fri_free(ofri_proto *p);
  * (32 B Montgomery LE) | final_root (32 B) | u64le n_final | final_coeffs (32 B each). */
 size_t o_fri_serialize(const ofri_proto *p, uint8_t *buf, size_t cap);
 
+/* ---- synthetic input, index-addressable; twin of hodor_gen_elements_dev ---- */
+void o_gen_elements(const ofield *f, ofr *out, uint64_t first_index, size_t count, uint64_t seed,
+                    uint32_t cpus);
+
 /* threads helper */
 uint32_t o_num_cpus(void);
 

@@ -172,6 +172,13 @@ class Oracle:
             need = need[~lt]
         return out   # a uniform residue is also a uniform Montgomery representation
 
+    def gen_elements(self, first_index, count, seed, cpus=None):
+        """SplitMix64 index-addressable input; same buffer as Context.gen_elements_dev."""
+        out = np.zeros((count, 4), dtype=np.uint64)
+        self.L.o_gen_elements(C.byref(self.f), _ptr(out), C.c_uint64(first_index), C.c_size_t(count),
+                              C.c_uint64(seed), C.c_uint32(cpus or self.cpus))
+        return out
+
     # ---- transforms (in place on (n,4) uint64 arrays)
     def serial_fft(self, a, omega, log_n):
         w = self.fr(omega)
