@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../hodor_amd/csrc/fr9.cuh"
+#include "../hodor_amd/csrc/fr9w3.cuh"
 
 using namespace hodor;
 #define ITERS 2048
@@ -575,6 +576,94 @@ __global__ void k_fraddsub(uint64_t *out, FrParams P, uint32_t seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// data x W3-constant product (fr9w3.cuh): 108 mads + 3 mul_lo, constant in registers
+__global__ void k_fr9mul3(uint64_t *out, Fr9Params Q, uint32_t seed)
+{
+    Fr9 x[2];
+    Fr9W3 w;
+    for (int i = 0; i < 9; i++) {
+        x[0].v[i] = (seed + i + threadIdx.x) & HODOR_M29; x[1].v[i] = (seed * 3 + i + blockIdx.x) & HODOR_M29;
+        for (int c = 0; c < 3; c++) w.w[c][i] = (seed * (7 + c) + i) & HODOR_M29;
+    }
+    x[0].v[8] &= 0xfffff; x[1].v[8] &= 0xfffff;
+    for (int c = 0; c < 3; c++) w.w[c][8] &= 0xfffff;
+    for (int it = 0; it < MUL_ITERS; it++) {
+        x[0] = fr9_mul3(x[0], w, Q);
+        x[1] = fr9_mul3(x[1], w, Q);
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 9; i++) s += x[0].v[i] + x[1].v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Instruction-mix proxy of a 5 x 52-bit double-precision-FMA Montgomery product (the scheme of Emmart,
+// Zheng, Weems: hi = fma(a, b, 2^104), lo = fma(a, b, (2^104 + 2^52) - hi), bit patterns summed as
+// 64-bit integers): per limb product 2 v_fma_f64 + 1 v_add_f64 + 2 64-bit integer adds, 50 limb products
+// (a x b and m x p), plus 10 int->double conversions of the carried columns.  The values are not a
+// real product (no rounding-mode switch, no final carry pass): only the issue cost is measured.
+__global__ void k_dpfma_proxy(uint64_t *out, uint32_t a0, uint32_t b0)
+{
+    double a[5], b[5], p[5];
+    for (int i = 0; i < 5; i++) { a[i] = (double)(a0 + i + threadIdx.x); b[i] = (double)(b0 + 3 * i + 1); p[i] = (double)(7 * i + 5); }
+    const double C1 = 0x1p104, C2 = 0x1p104 + 0x1p52;
+    uint64_t col[10];
+    for (int it = 0; it < MUL_ITERS; it++) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) col[k] = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    double y = half ? p[j] : b[j];
+                    double hi = __builtin_fma(a[i], y, C1);
+                    double lo = __builtin_fma(a[i], y, C2 - hi);
+                    col[i + j + 1] += (uint64_t)__double_as_longlong(hi);
+                    col[i + j] += (uint64_t)__double_as_longlong(lo);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) a[i] = (double)(uint32_t)(col[i] ^ col[i + 5]) * 0x1p-8 + 1.0;
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 10; i++) s += col[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Memory pattern of a two-pass 2^12 x 2^12 plan for the 2^24-point transform (one 4096-point
+// sub-transform per workgroup, C = 1): a workgroup gathers 4096 elements that lie 4096 elements apart
+// (32-byte pieces), parks them in LDS, and writes them back either contiguously (first pass) or with the
+// same stride (second pass).  xcd_aware: the four workgroups that share each 128-byte line are mapped
+// to the same XCD (block b runs on XCD b % 8) and dispatched back to back.
+__global__ void __launch_bounds__(1024)
+k_stride_probe(const uint4 *src, uint4 *dst, int strided_store, int xcd_aware)
+{
+    extern __shared__ uint4 lds[];
+    uint32_t b = blockIdx.x, j;
+    if (xcd_aware) {
+        uint32_t x = b & 7, q = b >> 3;
+        j = ((q >> 2) << 5) + (x << 2) + (q & 3);
+    } else {
+        j = b;
+    }
+    for (uint32_t i = threadIdx.x; i < 4096; i += 1024) {
+        const uint4 *s = src + 2 * ((uint64_t)j + ((uint64_t)i << 12));
+        lds[i] = s[0];
+        lds[4096 + i] = s[1];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 4096; i += 1024) {
+        uint32_t r = (i * 2654435761u) >> 20;   // some permutation-ish shuffle so LDS is really used
+        r = (r & ~4095u) | i;
+        uint4 *d = strided_store ? dst + 2 * ((uint64_t)j + ((uint64_t)i << 12)) : dst + 2 * (((uint64_t)j << 12) + i);
+        d[0] = lds[r & 4095];
+        d[1] = lds[4096 + (r & 4095)];
+    }
+}
+
 __global__ void k_copy(const uint4 *in, uint4 *out, size_t n)
 {
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -664,6 +753,10 @@ int main()
         Q.pinv = 0x1fffffff; Q.mu = 2262; Q.red_shift = 18;
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9mul, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
         printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr9_mul (9x29)", ms, muls / ms * 1e-6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_fr9mul3, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
+        printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr9_mul3 (W3)", ms, muls / ms * 1e-6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_dpfma_proxy, dim3(blocks), dim3(threads), 0, 0, out, 3u, 5u); });
+        printf("%-16s %8.3f ms  %8.2f Gmul/s (issue-cost proxy, 5x52-bit DP-FMA Montgomery: 100 fma + 50 add_f64 + 100 add_u64)\n", "dp-fma proxy", ms, lanes * MUL_ITERS / ms * 1e-6);
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9addsub, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
         printf("%-16s %8.3f ms  %8.2f Gop/s (incl. normalize)\n", "fr9_add+sub", ms, muls / ms * 1e-6);
     }
@@ -674,6 +767,14 @@ int main()
         hipMemset(a, 1, n * 16);
         float ms = time_it([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(threads), 0, 0, a, b, n); });
         printf("%-16s %8.3f ms  %8.2f GB/s (read+write)\n", "copy 1GiB", ms, 2.0 * n * 16 / ms * 1e-6);
+        // 2^24 elements of 32 B = 512 MiB: the two-pass plan's memory patterns
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_stride_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int strided = 0; strided < 2; strided++)
+            for (int xcd = 0; xcd < 2; xcd++) {
+                ms = time_it([&] { hipLaunchKernelGGL(k_stride_probe, dim3(4096), dim3(1024), 128 * 1024, 0, a, b, strided, xcd); });
+                printf("stride probe (%s store, %s)  %8.3f ms  %8.2f GB/s\n", strided ? "strided" : "contiguous",
+                       xcd ? "xcd-aware" : "plain order", ms, 2.0 * 512 * 1048576 / ms * 1e-6);
+            }
     }
     return 0;
 }

@@ -26,7 +26,7 @@ OK, ERR_SIZE, ERR_INVALID, ERR_DEVICE = 0, 1, 2, 3
 # every symbol include/hodor_gpu.h declares
 EXPORTS = [
     "hodor_ctx_create", "hodor_ctx_destroy", "hodor_ctx_field_info", "hodor_last_error",
-    "hodor_ctx_synchronize",
+    "hodor_ctx_synchronize", "hodor_knobs_set",
     "hodor_fr_mul", "hodor_fr_add", "hodor_fr_sub", "hodor_fr_pow", "hodor_fr_inverse",
     "hodor_fr_from_repr", "hodor_fr_into_repr", "hodor_domain_new_for_size",
     "hodor_fft", "hodor_lde", "hodor_distribute_powers",
@@ -98,6 +98,7 @@ def lib():
             pass
         _lib = C.CDLL(_LIB)
         _lib.hodor_last_error.restype = C.c_char_p
+        _lib.hodor_knobs_set.restype = C.c_char_p
         _lib.hodor_fri_num_steps.restype = C.c_size_t
         _lib.hodor_fri_serialize.restype = C.c_size_t
         _lib.hodor_fri_produce_proof.restype = C.c_size_t
@@ -106,6 +107,11 @@ def lib():
         _lib.hodor_ctx_destroy.restype = None
         _lib.hodor_fri_free.restype = None
     return _lib
+
+
+def knobs_set():
+    """Tuning variables the library found in the environment ("NAME=value ...", "" when none)."""
+    return lib().hodor_knobs_set().decode()
 
 
 def _limbs(x):

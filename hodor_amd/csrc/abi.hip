@@ -98,7 +98,8 @@ int trim_table_cache(hodor_ctx *ctx)
 }
 
 // base^e = lo[e & mask] * hi[e >> lo_bits] for e < 2^log_n
-// fmt 1 = 9 x 29-bit R'-form entries for k_ntt_pass, fmt 0 = 32-byte R-form entries (fold, twiddle_mul)
+// fmt 2 = 112-byte W3 entries for k_ntt_pass (fr9w3.cuh), fmt 1 = 48-byte 9 x 29-bit R'-form entries
+// (fr9_mul operand: fold, distribute_powers, evaluate_at), fmt 0 = 32-byte R-form entries (twiddle_mul)
 int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt, uint32_t lo_bits,
                   const HFr *hi_mult_p)
 {
@@ -115,13 +116,18 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
     t.lo_bits = lo_bits;
     t.fmt = fmt;
     t.hi_mult = hi_mult;
-    const size_t esz = fmt ? 48 : 32;
+    const size_t esz = fmt == 2 ? 112 : (fmt ? 48 : 32);
     uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
     HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * esz));
     HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * esz));
     Fr b = to_dev(base), one = to_dev(ctx->F.one);
-    HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, fmt, ctx->P));
-    HIPCHK(pow_table_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, fmt, ctx->P));
+    if (fmt == 2) {
+        HIPCHK(pow_table_w3_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, ctx->K3, ctx->P));
+        HIPCHK(pow_table_w3_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, ctx->K3, ctx->P));
+    } else {
+        HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, fmt, ctx->P));
+        HIPCHK(pow_table_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, fmt, ctx->P));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));   // tables are shared across streams afterwards
     ctx->pow_tables.push_back(t);
     *out = TwoLevel{t.lo, t.hi, t.lo_bits};
@@ -234,17 +240,17 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
     uint32_t tw_lo_bits = 0xffffffffu;
     if (passes > 1) {
         uint32_t shift2 = log_n - radices[0] - radices[1];
-        if (log_n - shift2 <= 17 && shift2 <= 16) tw_lo_bits = shift2;
+        if (log_n - shift2 <= ctx->tw_hi_max_log && shift2 <= 16) tw_lo_bits = shift2;
     }
-    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw, 1, tw_lo_bits))) return rc;
+    if (passes > 1 && (rc = get_pow_table(ctx, omega, log_n, &tw, 2, tw_lo_bits))) return rc;
     // iNTT: fold the n^-1 scale into the `hi` half of the LAST pass's twiddle table — every element of
     // that pass is multiplied by a twiddle anyway (tw_always covers the exponent-0 ones), so the scale
     // costs no product of its own (it is a separate streaming pass on the CPU, src/polynomials/mod.rs:777-787)
     TwoLevel tw_last = tw;
     const bool fold_scale = scale && passes > 1;
-    if (fold_scale && (rc = get_pow_table(ctx, omega, log_n, &tw_last, 1, tw_lo_bits, scale))) return rc;
-    if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t, 1))) return rc;
-    if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t, 1))) return rc;
+    if (fold_scale && (rc = get_pow_table(ctx, omega, log_n, &tw_last, 2, tw_lo_bits, scale))) return rc;
+    if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t, 2))) return rc;
+    if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t, 2))) return rc;
 
     // ping-pong buffers: the last pass writes dst; a pass never runs in place unless it is the only
     // one (a single tile is fully staged in LDS before anything is written back).
@@ -310,7 +316,7 @@ int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega)
     uint64_t sz;
     uint32_t k;
     if (log_n > 63 || !ctx->F.domain(1ull << log_n, &sz, &k, omega)) {
-        ctx->err = "domain too large for the field's 2-adicity";
+        set_err(ctx, "domain too large for the field's 2-adicity");
         return HODOR_ERR_SIZE;
     }
     return HODOR_OK;
@@ -345,7 +351,7 @@ int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *
 static int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
                          uint32_t log_n, size_t factor, int coset, uint32_t batch = 1)
 {
-    if (!is_pow2(factor)) { ctx->err = "lde factor must be a power of two"; return HODOR_ERR_SIZE; }
+    if (!is_pow2(factor)) { set_err(ctx, "lde factor must be a power of two"); return HODOR_ERR_SIZE; }
     uint32_t log_big = log_n + log2u(factor);
     HFr Omega;
     int rc = poly_domain(ctx, log_big, &Omega);
@@ -395,10 +401,10 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
             delete ctx;
             return HODOR_ERR_DEVICE;
         }
-        const char *e = getenv("HODOR_MAX_LOG_R");
-        if (e && atoi(e) >= 2 && atoi(e) <= 11) ctx->max_log_r = (uint32_t)atoi(e);
-        e = getenv("HODOR_TILE_LOG");
-        if (e && atoi(e) >= 6 && atoi(e) <= 12) ctx->tile_log = (uint32_t)atoi(e);
+        const Knobs &k = knobs();
+        ctx->max_log_r = (uint32_t)k.max_log_r;
+        ctx->tw_hi_max_log = (uint32_t)k.tw_hi_max_log;
+        ctx->tile_log = (uint32_t)k.tile_log;
         if (ctx->max_log_r > ctx->tile_log) ctx->max_log_r = ctx->tile_log;
     }
     *out = ctx;
@@ -577,7 +583,7 @@ extern "C" int hodor_precomputed_omegas_dev(hodor_ctx *ctx, void *stream, uint32
     uint32_t lg;
     HFr w, winv;
     if (log_n > 40 || !ctx->F.domain(1ull << log_n, &size, &lg, &w)) {
-        ctx->err = "domain larger than the field's two-adicity";
+        set_err(ctx, "domain larger than the field's two-adicity");
         return HODOR_ERR_SIZE;
     }
     if (!ctx->F.inverse(w, &winv)) return HODOR_ERR_INVALID;
@@ -679,12 +685,7 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     std::vector<Level> levels;
     size_t off = 0;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    static int seq = -1;   // elements per thread and level
-    if (seq < 0) {
-        const char *e = getenv("HODOR_BATCHINV_SEQ");
-        seq = e ? atoi(e) : 8;
-        if (seq < 2) seq = 2;
-    }
+    const int seq = knobs().batchinv_seq;   // elements per thread and level
     for (uint64_t m = n; m > TOP || levels.empty();) {
         uint64_t T = (m + seq - 1) / seq;
         Level L = {m, T, off, 0};
@@ -713,12 +714,12 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (host_flag) {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
-        ctx->err = "batch_inversion: zero element";
+        set_err(ctx, "batch_inversion: zero element");
         return HODOR_ERR_INVALID;
     }
     for (uint64_t i = 0; i < top.T; i++) {
         HFr inv;
-        if (!ctx->F.inverse(to_h(&top_prod[i]), &inv)) { ctx->err = "batch_inversion: zero product"; return HODOR_ERR_INVALID; }
+        if (!ctx->F.inverse(to_h(&top_prod[i]), &inv)) { set_err(ctx, "batch_inversion: zero product"); return HODOR_ERR_INVALID; }
         from_h(inv, &top_prod[i]);
     }
     HIPCHK(hipMemcpyAsync(base + top.prod_off, top_prod, top.T * 32, hipMemcpyHostToDevice, stream));
@@ -766,7 +767,7 @@ extern "C" int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr
 {
     NEED_DEVICE();
     if (!leafs || !nodes) return HODOR_ERR_INVALID;
-    if (!is_pow2(n) || n < 2) { ctx->err = "iop_create: n must be a power of two >= 2"; return HODOR_ERR_SIZE; }
+    if (!is_pow2(n) || n < 2) { set_err(ctx, "iop_create: n must be a power of two >= 2"); return HODOR_ERR_SIZE; }
     HIPCHK(merkle_build_launch(pick_stream(ctx, stream), (const uint4 *)leafs, (uint4 *)nodes, n, ctx->mid));
     return HODOR_OK;
 }
@@ -790,7 +791,7 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         (void)hipStreamSynchronize(L->stream);
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
-            ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+            set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
         }
         lane_release(ctx, L);
         return HODOR_ERR_DEVICE;
@@ -827,7 +828,7 @@ extern "C" int hodor_fft(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *
 {
     NEED_DEVICE();
     if (!a || !omega) return HODOR_ERR_INVALID;
-    if (log_n > 40 || n != ((size_t)1 << log_n)) { ctx->err = "fft: n != 1 << log_n"; return HODOR_ERR_SIZE; }   // assert_eq at src/fft/fft.rs:34
+    if (log_n > 40 || n != ((size_t)1 << log_n)) { set_err(ctx, "fft: n != 1 << log_n"); return HODOR_ERR_SIZE; }   // assert_eq at src/fft/fft.rs:34
     HFr w = to_h(omega);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
         return ntt_exec(ctx, ctx->stream, s, d, log_n, w, n, nullptr, nullptr, nullptr);
@@ -861,7 +862,7 @@ static int poly_slice(hodor_ctx *ctx, hodor_fr *a, size_t n, PolyOp op)
 {
     NEED_DEVICE();
     if (!a) return HODOR_ERR_INVALID;
-    if (!is_pow2(n)) { ctx->err = "polynomial size must be a power of two"; return HODOR_ERR_SIZE; }
+    if (!is_pow2(n)) { set_err(ctx, "polynomial size must be a power of two"); return HODOR_ERR_SIZE; }
     uint32_t log_n = log2u(n);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
         return poly_transform(ctx, ctx->stream, s, d, log_n, op);
@@ -892,7 +893,7 @@ extern "C" int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n,
 {
     NEED_DEVICE();
     if (!leafs || !nodes) return HODOR_ERR_INVALID;
-    if (!is_pow2(n) || n < 2) { ctx->err = "iop_create: n must be a power of two >= 2"; return HODOR_ERR_SIZE; }
+    if (!is_pow2(n) || n < 2) { set_err(ctx, "iop_create: n must be a power of two >= 2"); return HODOR_ERR_SIZE; }
     return with_device_copy(ctx, leafs, n, nodes, n, [&](const uint4 *s, uint4 *d) -> int {
         HIPCHK(merkle_build_launch(ctx->stream, s, d, n, ctx->mid));
         return HODOR_OK;

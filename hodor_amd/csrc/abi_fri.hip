@@ -34,7 +34,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;
     size_t initial_degree_plus_one = n / lde_factor;
     if (initial_degree_plus_one < 2 * out_deg) {   // num_steps == 0: the reference panics at roots.pop() (:124)
-        ctx->err = "fri_commit: needs at least one folding step";
+        set_err(ctx, "fri_commit: needs at least one folding step");
         return HODOR_ERR_SIZE;
     }
     size_t num_steps = log2u(initial_degree_plus_one / out_deg);
@@ -60,7 +60,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     do {                                                                               \
         hipError_t e__ = (expr);                                                       \
         if (e__ != hipSuccess) {                                                       \
-            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);             \
+            set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));             \
             fri_release(p);                                                            \
             return HODOR_ERR_DEVICE;                                                   \
         }                                                                              \
@@ -112,11 +112,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
 
     const uint4 *values = (const uint4 *)lde_values;
     size_t next_size = n / 2;
-    static int tail_on = -1;   // HODOR_FRI_TAIL=0: every round through the multi-launch path (A/B, debugging)
-    if (tail_on < 0) {
-        const char *e = getenv("HODOR_FRI_TAIL");
-        tail_on = e ? atoi(e) : 1;
-    }
+    const int tail_on = knobs().fri_tail;   // HODOR_FRI_TAIL=0: every round through the multi-launch path (A/B, debugging)
     // the challenge of round i (:51, :109) is derived from tree i-1 at the start of round i
     const uint4 *prev_nodes = (const uint4 *)p->l0_nodes;
     bool tail_done = false;
@@ -185,7 +181,10 @@ extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size
     DevBuf dv;
     HIPCHK(hipMalloc(&dv.p, n * 32));
     HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
-    return hodor_fri_commit_dev(ctx, nullptr, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
+    // the context's own compute stream, like every other slice entry point: in-order with the other
+    // callers' transforms that share ctx->scratch (hodor_fri_commit_dev holds ctx->mu until it has
+    // synchronised), never the legacy NULL stream, which has no ordering with a non-blocking stream
+    return hodor_fri_commit_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
 }
 
 // IOP::query on device-resident leaves and tree (src/iop/blake2s_trivial_iop.rs:324-338)
@@ -417,7 +416,7 @@ extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *ld
         return HODOR_ERR_SIZE;
     HFr x = F.pow(omega, natural_element_index);
     if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) {
-        ctx->err = "initial challenge value is not in the LDE domain";
+        set_err(ctx, "initial challenge value is not in the LDE domain");
         return HODOR_ERR_INVALID;
     }
     if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
@@ -438,7 +437,7 @@ extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *ld
         uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
         HFr f_at_omega, f_at_minus_omega;
         if (!fetch(values, coset[0], &f_at_omega) || !fetch(values, coset[1], &f_at_minus_omega)) {
-            ctx->err = "verify_prototype: device read failed";
+            set_err(ctx, "verify_prototype: device read failed");
             return HODOR_ERR_DEVICE;
         }
         if (have_expected) {

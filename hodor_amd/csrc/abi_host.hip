@@ -200,3 +200,41 @@ extern "C" size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t le
     if (idx % 2 == 0) idx = (idx + 1) % lde_size;
     return idx;
 }
+
+// ------------------------------------------------------------------------------------------------
+// tuning knobs: one thread-safe read per process (C++11 static initialisation)
+// ------------------------------------------------------------------------------------------------
+namespace hodor {
+static Knobs read_knobs()
+{
+    Knobs k;
+    k.set[0] = 0;
+    size_t used = 0;
+    auto get = [&](const char *name, int dflt, int lo, int hi) {
+        const char *e = getenv(name);
+        if (!e) return dflt;
+        int n = snprintf(k.set + used, sizeof(k.set) - used, "%s%s=%s", used ? " " : "", name, e);
+        if (n > 0 && used + (size_t)n < sizeof(k.set)) used += (size_t)n;
+        int v = atoi(e);
+        return (v < lo || v > hi) ? dflt : v;
+    };
+    k.max_log_r = get("HODOR_MAX_LOG_R", 9, 2, 11);
+    k.tile_log = get("HODOR_TILE_LOG", 10, 6, 12);
+    k.tw_hi_max_log = get("HODOR_TW_HI_MAX_LOG", 17, 0, 20);
+    k.ntt_threads = get("HODOR_NTT_THREADS", 0, 0, 1024);
+    k.merkle_tail_log = get("HODOR_MERKLE_TAIL_LOG", 6, 0, 30);
+    k.merkle_lat_log = get("HODOR_MERKLE_LAT_LOG", 19, 0, 40);
+    k.fri_tail = get("HODOR_FRI_TAIL", 1, 0, 1);
+    k.fri_fuse_fold = get("HODOR_FRI_FUSE_FOLD", 1, 0, 1);
+    k.batchinv_seq = get("HODOR_BATCHINV_SEQ", 8, 2, 64);
+    return k;
+}
+const Knobs &knobs()
+{
+    static const Knobs k = read_knobs();
+    return k;
+}
+}  // namespace hodor
+
+extern "C" const char *hodor_knobs_set(void) { return hodor::knobs().set; }
+

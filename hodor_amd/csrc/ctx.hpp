@@ -14,6 +14,7 @@
 #include "../../include/hodor_gpu.h"
 #include "host_blake2s.hpp"
 #include "host_field.hpp"
+#include "knobs.hpp"
 #include "ntt.cuh"
 
 namespace hodor {
@@ -92,7 +93,7 @@ struct PowTable {
     HFr base;
     uint32_t log_n;
     uint32_t lo_bits;
-    uint32_t fmt;          // 0: 32-byte R-form entries, 1: 48-byte 9 x 29-bit R'-form entries
+    uint32_t fmt;          // 0: 32-byte R-form entries, 1: 48-byte 9 x 29-bit R'-form entries, 2: 112-byte W3 entries
     HFr hi_mult;           // every `hi` entry is multiplied by this (one, or n^-1 for the last iNTT pass)
     uint4 *lo, *hi;
 };
@@ -138,8 +139,17 @@ struct hodor_ctx {
     size_t fri_slab_bytes = 0;
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
     uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
-    std::string err;
+    uint32_t tw_hi_max_log = 17;   // largest `hi` half (log2 entries) for which the second pass gets a hi-only
+                                   // twiddle split (one product instead of two, for a table that outgrows L2)
+    std::string err;           // written through set_err() only (entry points run concurrently)
+    std::mutex err_mu;
 };
+
+static inline void set_err(hodor_ctx *ctx, const std::string &msg)
+{
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    ctx->err = msg;
+}
 
 struct hodor_fri_proto {
     hodor_ctx *ctx;
@@ -160,7 +170,7 @@ struct hodor_fri_proto {
     do {                                                                              \
         hipError_t e__ = (expr);                                                      \
         if (e__ != hipSuccess) {                                                      \
-            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e__);            \
+            set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));         \
             return HODOR_ERR_DEVICE;                                                  \
         }                                                                             \
     } while (0)
@@ -168,7 +178,7 @@ struct hodor_fri_proto {
 #define NEED_DEVICE()                                                                 \
     do {                                                                              \
         if (!ctx) return HODOR_ERR_INVALID;                                           \
-        if (ctx->device < 0) { ctx->err = "context has no HIP device"; return HODOR_ERR_DEVICE; } \
+        if (ctx->device < 0) { set_err(ctx, "context has no HIP device"); return HODOR_ERR_DEVICE; } \
         HIPCHK(hipSetDevice(ctx->device));                                            \
     } while (0)
 

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "blake2s.cuh"
+#include "knobs.hpp"
 #include "ntt.cuh"
 
 namespace hodor {
@@ -212,24 +213,12 @@ hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *
 // `fold` (optional, batch == 1): the leaves are fold->dst, still to be computed from fold->src; when the
 // tree is small enough for the latency schedule the first launch folds and hashes in one go, otherwise
 // the caller must have run the fold already (merkle_fuses_fold tells which).
-static int g_tail_log = -1, g_lat_log = -1;
-static void merkle_knobs()
-{
-    if (g_tail_log >= 0) return;
-    const char *e = getenv("HODOR_MERKLE_TAIL_LOG");
-    g_tail_log = e ? atoi(e) : 6;
-    e = getenv("HODOR_MERKLE_LAT_LOG");
-    g_lat_log = e ? atoi(e) : 19;
-}
+#define g_tail_log (knobs().merkle_tail_log)
+#define g_lat_log (knobs().merkle_lat_log)
+static void merkle_knobs() {}
 bool merkle_fuses_fold(uint64_t n)
 {
-    merkle_knobs();
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("HODOR_FRI_FUSE_FOLD");
-        on = e ? atoi(e) : 1;
-    }
-    return on && n <= (1ull << g_lat_log);
+    return knobs().fri_fuse_fold && n <= (1ull << g_lat_log);
 }
 
 hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,

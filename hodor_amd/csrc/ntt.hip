@@ -20,17 +20,19 @@
 //     XOR-swizzled by the row index.
 //   * Butterfly twiddles sit in LDS as W3 constants (fr9w3.cuh: the twiddle pre-shifted three ways,
 //     112 B per entry), so a butterfly product is 108 v_mad_u64_u32 + 3 v_mul_lo instead of 162 + 9.
-//   * Inter-pass twiddles come from a two-level power table (L2-resident) instead of an n-entry
-//     table streamed from HBM (48-byte entries, full-width fr9_mul: a W3 `hi` table would not fit L2).
+//   * Inter-pass twiddles and coset powers come from two-level power tables of W3 constants
+//     (base^e = hi[e >> b] * lo[e & mask], applied as two successive products) instead of an n-entry
+//     table streamed from HBM.
 //
 // Value bounds inside a pass (p < 2^255, 2^261 > 64 p): loaded values are < 2^256 < 4 p (a packed
-// value) or < 3 p (fresh fr9_mul product); a W3 product of a normalized value is < 4 p; subtraction
+// value) or < 4 p (after a twiddle product); a W3 product of a normalized value is < 4 p; subtraction
 // adds the 5 p offset, so a radix-4 step raises the bound by at most 10 p (two subtractions):
 // 14 p after the twiddle-free first step (9 p after a leading radix-2 stage), <= 59 p after the
 // <= 6 steps of a pass of radix <= 2^11.  Every subtrahend is a fresh product (< 4 p) except in the
 // twiddle-free first step, handled explicitly; every product takes a normalized operand.
 #include <cstdlib>
 
+#include "knobs.hpp"
 #include "ntt.cuh"
 #include "fr9w3.cuh"
 
@@ -114,14 +116,15 @@ __device__ __forceinline__ Fr9 fr9_sub5(const Fr9 &a, const Fr9 &b, const Fr9Par
     return r;
 }
 
-// base^e from the two-level table (R'-form, normalized, < 2p)
-__device__ __forceinline__ Fr9 two_level_pow9(const TwoLevel &t, uint64_t e, const Fr9Params &Q)
+// x * base^e through the two-level W3 table: base^e = hi[e >> lo_bits] * lo[e & mask], applied as two
+// successive data x constant products (x normalized on entry, result normalized and < 4p).
+// `always`: hi[0] is not 1 (it carries the folded n^-1 scale), so it is applied even for exponent 0.
+__device__ __forceinline__ Fr9 mul_two_level(Fr9 x, const TwoLevel &t, uint64_t e, bool always, const Fr9Params &Q)
 {
-    uint64_t lo_i = e & ((1ull << t.lo_bits) - 1), hi_i = e >> t.lo_bits;
-    Fr9 h = fr9_load48(t.hi + 3 * hi_i);
-    if (lo_i == 0) return h;
-    Fr9 l = fr9_load48(t.lo + 3 * lo_i);
-    return fr9_mul(h, l, Q);
+    const uint64_t lo_i = e & ((1ull << t.lo_bits) - 1), hi_i = e >> t.lo_bits;
+    if (hi_i != 0 || always) x = fr9_mul3(x, fr9w3_load(t.hi + 7 * hi_i), Q);
+    if (lo_i != 0) x = fr9_mul3(x, fr9w3_load(t.lo + 7 * lo_i), Q);
+    return x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -191,10 +194,10 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             } else {
                 x = fr9_unpack(fr_load(src_b + 2 * g));
             }
-            if (A.pre.lo != nullptr && g != 0) x = fr9_mul(x, two_level_pow9(A.pre, g, Q), Q);
+            if (A.pre.lo != nullptr) x = mul_two_level(x, A.pre, g, false, Q);
             if (A.apply_tw && !ABL(2)) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
-                if (ex != 0 || A.tw_always) x = fr9_mul(x, two_level_pow9(A.tw, ex, Q), Q);
+                x = mul_two_level(x, A.tw, ex, A.tw_always != 0, Q);
             }
         } else {
 #pragma unroll
@@ -291,7 +294,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << A.log_l);
         Fr9 x = lds_get(D, SLOT(cc, c));
         if (has_scale) x = fr9_mul(x, scale, Q);
-        if (A.post.lo != nullptr && o != 0) x = fr9_mul(x, two_level_pow9(A.post, o, Q), Q);
+        if (A.post.lo != nullptr) x = mul_two_level(x, A.post, o, false, Q);
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
         if (ABL(8) && y.v[0] != 0x12345u) continue;
@@ -311,24 +314,16 @@ size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c)
 
 hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *scale, const Fr9Params &Q)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc != hipSuccess) return attr_rc;
     uint64_t n = 1ull << A.log_n;
     uint64_t grid = n >> (A.log_r + A.log_c);
     Fr9 s = {};
     if (scale) s = *scale;
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c);
     // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
-    static int threads_override = -1;
-    if (threads_override < 0) {
-        const char *e = getenv("HODOR_NTT_THREADS");
-        threads_override = e ? atoi(e) : 0;
-    }
+    const int threads_override = knobs().ntt_threads;
     PassArgs B = A;
 #ifdef HODOR_ABLATE
     static int dbg = -1;

@@ -60,6 +60,12 @@ void hodor_ctx_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
+/* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
+ * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS,
+ * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ.
+ * They are read once per process, change schedules only (never results), and a benchmark must echo
+ * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
+const char *hodor_knobs_set(void);
 
 /* ---- scalar field helpers on the host (ff_ce Field/PrimeField methods the callers use to derive
  * omegainv / minv / geninv, src/polynomials/mod.rs:146-166) */
@@ -147,9 +153,15 @@ int  hodor_transcript_get_challenge(hodor_transcript *t, hodor_fr *out);
 size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t lde_size, size_t lde_factor);
 
 /* ================================ device API (device memory) ============================== */
-/* `stream` is a hipStream_t (NULL = the HIP default stream, which is also PyTorch-ROCm's default).  All work is enqueued in stream
- * order; nothing synchronises with the host unless stated.  A context owns one scratch pool, so use
- * one context per concurrently active stream. */
+/* `stream` is a hipStream_t (NULL = the HIP legacy default stream, which is also PyTorch-ROCm's default).
+ * All work is enqueued in stream order; nothing synchronises with the host unless stated.
+ * Ordering rules of one context:
+ *   - it owns ONE scratch pool (the ping-pong buffers of multi-pass transforms; batch_inversion,
+ *     evaluate_at and fri_commit use it too), one twiddle-table cache and one parked FRI slab;
+ *   - the slice API runs on streams the context creates itself (one non-blocking compute stream + three
+ *     copy lanes, invisible to the caller) and is internally serialised on them;
+ *   - therefore `_dev` calls of one context must all use the SAME stream, and must not overlap slice-API
+ *     calls of that context from other threads.  Use one context per concurrently active stream. */
 int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr);
 int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr);
 int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
@@ -226,7 +238,14 @@ size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_de
                                size_t natural_first_element_index, uint8_t *buf, size_t cap);
 /* NaiveFriIop::verify_proof_queries — src/fri/verifier.rs:131-289 (FriIop::verify_proof,
  * src/fri/mod.rs:96-102) over the bytes hodor_fri_produce_proof wrote.  Host-only.  *valid = 1/0 for
- * Ok(true)/Ok(false); the reference's Err(..) cases and a malformed buffer give HODOR_ERR_INVALID. */
+ * Ok(true)/Ok(false); the reference's Err(..) cases and a malformed buffer give HODOR_ERR_INVALID.
+ * CAVEATS inherited from the reference, which this function mirrors step for step: it walks
+ * zip(roots, queries.chunks_exact(2)) and binds neither the number of rounds, nor n_final, nor the path
+ * lengths, nor output_coeffs_at_degree_plus_one to the claimed domain — a CALLER that accepts proofs from
+ * an untrusted prover must itself check  n_roots == log2(initial_degree_plus_one / out_deg) + 1,
+ * n_queries == 2 * n_roots, n_final == out_deg and path_len == log2(domain size of that round)
+ * before calling; and, like the reference (it folds num_steps + 1 times), only proofs with
+ * output_coeffs_at_degree_plus_one == 1 round-trip through produce_proof -> verify_proof. */
 int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t natural_element_index,
                            const hodor_fr *expected_value_from_oracle, int *valid);
 /* NaiveFriIop::verify_prototype — src/fri/verifier.rs:10-129: the folding walk against the prover's own

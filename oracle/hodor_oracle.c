@@ -430,6 +430,93 @@ void o_best_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t lo
     else o_parallel_fft(f, a, n, omega, log_n, log_cpus);
 }
 
+/* serial_DIT_fft — src/fft/dit_fft/mod.rs:4-53.  (A decimation-in-frequency schedule despite its
+ * name: butterflies on natural order, bit reversal at the end.)  `non_zero_entries_count` prunes every
+ * block to its first min(block_len/2, count) butterflies (:29), which is exact when only the first
+ * `count` inputs are non-zero — the reference's own zero-aware transform beside lde.rs. */
+void o_serial_dit_fft(const ofield *f, ofr *a, size_t n_, const ofr *omega, uint32_t log_n,
+                      size_t non_zero_entries_count)
+{
+    uint64_t n = (uint64_t)n_, m = 1;
+    for (uint32_t s = 0; s < log_n; s++) {
+        ofr w_m;
+        ofr_pow(f, &w_m, omega, m);                                   /* :23 */
+        uint64_t block_len = n / m;
+        for (uint64_t block = 0; block < m; block++) {
+            ofr w = f->r;
+            uint64_t lim = block_len / 2 < (uint64_t)non_zero_entries_count ? block_len / 2
+                                                                             : (uint64_t)non_zero_entries_count;
+            for (uint64_t k = block * block_len; k < block * block_len + lim; k++) {   /* :29 */
+                ofr t = a[k + block_len / 2];
+                ofr tmp = a[k];
+                ofr_sub(f, &tmp, &t);
+                a[k + block_len / 2] = tmp;
+                ofr_mul(f, &a[k + block_len / 2], &w);
+                ofr_add(f, &a[k], &t);
+                ofr_mul(f, &w, &w_m);
+            }
+        }
+        m *= 2;
+    }
+    for (uint64_t k = 0; k < n; k++) {                                /* :44-51 */
+        uint64_t rk = 0, x = k;
+        for (uint32_t i = 0; i < log_n; i++) { rk = (rk << 1) | (x & 1); x >>= 1; }
+        if (k < rk) { ofr t = a[rk]; a[rk] = a[k]; a[k] = t; }
+    }
+}
+
+/* parallel_DIT_fft — src/fft/dit_fft/mod.rs:55-113: the shuffle of parallel_fft, pruned sub-FFTs */
+typedef struct { pfft_ctx base; size_t nz; } pdit_ctx;
+static void pdit_shuffle(void *vctx, size_t j, size_t start, size_t len)
+{
+    (void)start; (void)len;
+    pdit_ctx *d = (pdit_ctx *)vctx;
+    pfft_ctx *c = &d->base;
+    const ofield *f = c->f;
+    size_t num_cpus = (size_t)1 << c->log_cpus, new_n = (size_t)1 << c->log_new_n;
+    ofr *tmp = c->tmp[j];
+    ofr omega_j, omega_step;
+    ofr_pow(f, &omega_j, c->omega, j);
+    ofr_pow(f, &omega_step, c->omega, (uint64_t)j << c->log_new_n);
+    ofr elt = f->r;
+    for (size_t i = 0; i < new_n; i++) {
+        for (size_t s = 0; s < num_cpus; s++) {
+            size_t idx = i + (s << c->log_new_n);                      /* :82 */
+            ofr t = c->a[idx];
+            ofr_mul(f, &t, &elt);
+            ofr_add(f, &tmp[i], &t);
+            ofr_mul(f, &elt, &omega_step);
+        }
+        ofr_mul(f, &elt, &omega_j);
+    }
+    o_serial_dit_fft(f, tmp, new_n, &c->new_omega, c->log_new_n, d->nz < new_n ? d->nz : new_n);   /* :92 */
+}
+
+void o_parallel_dit_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                        uint32_t log_cpus, size_t non_zero_entries_count)
+{
+    size_t num_cpus = (size_t)1 << log_cpus;
+    uint32_t log_new_n = log_n - log_cpus;
+    ofr **tmp = (ofr **)malloc(num_cpus * sizeof(ofr *));
+    for (size_t j = 0; j < num_cpus; j++) tmp[j] = (ofr *)calloc((size_t)1 << log_new_n, sizeof(ofr));
+    pdit_ctx d = {{f, a, tmp, omega, {{0}}, log_n, log_cpus, log_new_n}, non_zero_entries_count};
+    ofr_pow(f, &d.base.new_omega, omega, num_cpus);
+    worker_scope((uint32_t)num_cpus, num_cpus, pdit_shuffle, &d);
+    punshuf_ctx u = {a, tmp, log_cpus};
+    worker_scope((uint32_t)num_cpus, n, pfft_unshuffle, &u);
+    for (size_t j = 0; j < num_cpus; j++) free(tmp[j]);
+    free(tmp);
+}
+
+/* best_DIT_fft — src/fft/dit_fft/mod.rs:114-123 */
+void o_best_dit_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, uint32_t cpus,
+                    size_t non_zero_entries_count)
+{
+    uint32_t log_cpus = log2_floor(cpus < 1 ? 1 : cpus);
+    if (log_n <= log_cpus) o_serial_dit_fft(f, a, n, omega, log_n, non_zero_entries_count);
+    else o_parallel_dit_fft(f, a, n, omega, log_n, log_cpus, non_zero_entries_count);
+}
+
 /* serial_lde — src/fft/lde.rs:15-126 (zero-aware FFT of a vector whose only non-zeros are the
  * first n/lde_factor coefficients) */
 void o_serial_lde(const ofield *f, ofr *a, size_t n_, const ofr *omega, uint32_t log_n,
@@ -688,6 +775,39 @@ void o_poly_evaluate_at(const ofield *f, const ofr *coeffs, size_t n, const ofr 
         ofr_add(f, &acc, &v);
         ofr_mul(f, &x, g);
     }
+    *out = acc;
+}
+
+/* The same sum as the reference schedules it (src/polynomials/mod.rs:685-711): one partial sum per
+ * Worker chunk, each starting from g^(i*chunk), added up in chunk order.  Field addition is exact,
+ * so the result equals o_poly_evaluate_at's for every `cpus`. */
+typedef struct { const ofield *f; const ofr *coeffs; const ofr *g; ofr *sub; size_t chunk; } eval_ctx;
+static void eval_chunk(void *vctx, size_t ci, size_t start, size_t len)
+{
+    eval_ctx *c = (eval_ctx *)vctx;
+    const ofield *f = c->f;
+    ofr x, acc = {{0, 0, 0, 0}};
+    ofr_pow(f, &x, c->g, (uint64_t)start);      /* g.pow([(i*chunk) as u64]) */
+    for (size_t i = start; i < start + len; i++) {
+        ofr v = x;
+        ofr_mul(f, &v, &c->coeffs[i]);
+        ofr_add(f, &acc, &v);
+        ofr_mul(f, &x, c->g);
+    }
+    c->sub[ci] = acc;
+}
+
+void o_poly_evaluate_at_mt(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out, uint32_t cpus)
+{
+    if (cpus < 1) cpus = 1;
+    size_t chunk = n < cpus ? 1 : n / cpus;
+    size_t nchunks = n ? (n + chunk - 1) / chunk : 0;
+    ofr *sub = (ofr *)calloc(nchunks ? nchunks : 1, sizeof(ofr));
+    eval_ctx c = {f, coeffs, g, sub, chunk};
+    worker_scope(cpus, n, eval_chunk, &c);
+    ofr acc = {{0, 0, 0, 0}};
+    for (size_t i = 0; i < nchunks; i++) ofr_add(f, &acc, &sub[i]);
+    free(sub);
     *out = acc;
 }
 

@@ -71,6 +71,12 @@ void o_parallel_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_
                     uint32_t log_cpus);                                                          /* src/fft/fft.rs:68-124 */
 void o_best_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
                 uint32_t cpus);                                                                  /* src/fft/fft.rs:5-19 */
+void o_serial_dit_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                      size_t non_zero_entries_count);                                            /* src/fft/dit_fft/mod.rs:4-53 */
+void o_parallel_dit_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                        uint32_t log_cpus, size_t non_zero_entries_count);                       /* :55-113 */
+void o_best_dit_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                    uint32_t cpus, size_t non_zero_entries_count);                               /* :114-123 */
 void o_serial_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
                   size_t lde_factor);                                                            /* src/fft/lde.rs:15-126 */
 void o_distribute_powers(const ofield *f, ofr *a, size_t n, const ofr *g, uint32_t cpus);       /* src/fft/mod.rs:110-123 */
@@ -91,7 +97,9 @@ void o_poly_binary(const ofield *f, ofr *a, const ofr *b, size_t n, int op);
 void o_poly_add_scaled(const ofield *f, ofr *a, const ofr *b, size_t n, const ofr *scaling);
 void o_poly_unary(const ofield *f, ofr *a, size_t n, int op, const ofr *c, uint64_t e);
 int  o_poly_batch_inversion(const ofield *f, ofr *a, size_t n);   /* -1 (a untouched) if any zero, :909 */
-void o_poly_evaluate_at(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out);  /* :685-711 */
+void o_poly_evaluate_at(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out);  /* :685-711, one chunk */
+void o_poly_evaluate_at_mt(const ofield *f, const ofr *coeffs, size_t n, const ofr *g, ofr *out,
+                           uint32_t cpus);                       /* :685-711 with its Worker chunks */
 
 /* ---- BLAKE2s IOP (src/iop/blake2s_trivial_iop.rs) ---- */
 void o_blake2s(uint8_t out[32], const uint8_t *key, size_t keylen, const uint8_t *personal,

@@ -198,6 +198,21 @@ class Oracle:
         self.L.o_best_fft(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w),
                           C.c_uint32(log_n), C.c_uint32(cpus or self.cpus))
 
+    def serial_dit_fft(self, a, omega, log_n, non_zero_entries_count):
+        w = self.fr(omega)
+        self.L.o_serial_dit_fft(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                                C.c_size_t(non_zero_entries_count))
+
+    def parallel_dit_fft(self, a, omega, log_n, log_cpus, non_zero_entries_count):
+        w = self.fr(omega)
+        self.L.o_parallel_dit_fft(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                                  C.c_uint32(log_cpus), C.c_size_t(non_zero_entries_count))
+
+    def best_dit_fft(self, a, omega, log_n, non_zero_entries_count, cpus=None):
+        w = self.fr(omega)
+        self.L.o_best_dit_fft(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                              C.c_uint32(cpus or self.cpus), C.c_size_t(non_zero_entries_count))
+
     def serial_lde(self, a, omega, log_n, lde_factor):
         w = self.fr(omega)
         self.L.o_serial_lde(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w),
@@ -258,10 +273,15 @@ class Oracle:
         if self.L.o_poly_batch_inversion(C.byref(self.f), _ptr(a), C.c_size_t(len(a))) != 0:
             raise ValueError("SynthesisError::Error")
 
-    def evaluate_at(self, coeffs, g):
+    def evaluate_at(self, coeffs, g, cpus=1):
+        """sum coeffs[i] g^i; cpus > 1 follows the reference's Worker chunking (same value)."""
         gg, out = self.fr(g), OFr()
-        self.L.o_poly_evaluate_at(C.byref(self.f), _ptr(coeffs), C.c_size_t(len(coeffs)),
-                                  C.byref(gg), C.byref(out))
+        if cpus == 1:
+            self.L.o_poly_evaluate_at(C.byref(self.f), _ptr(coeffs), C.c_size_t(len(coeffs)),
+                                      C.byref(gg), C.byref(out))
+        else:
+            self.L.o_poly_evaluate_at_mt(C.byref(self.f), _ptr(coeffs), C.c_size_t(len(coeffs)),
+                                         C.byref(gg), C.byref(out), C.c_uint32(cpus or self.cpus))
         return _limbs_to_int(out.l)
 
     # ---- IOP

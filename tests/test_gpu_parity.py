@@ -54,6 +54,30 @@ def test_fft_large_matches_parallel_oracle(gpu_ctxs, oracles, log_n):
     assert _digest(got) == _digest(exp)
 
 
+@pytest.mark.parametrize("log_n,log_nz", [(4, 0), (10, 3), (12, 12), (16, 12), (18, 14), (20, 17)])
+def test_pruned_transform_matches_dit_fft(gpu_ctxs, oracles, field_name, log_n, log_nz):
+    """Row a7: serial/parallel/best_DIT_fft with non_zero_entries_count (src/fft/dit_fft/mod.rs:4-123,
+    test_fft_prunning src/fft/mod.rs:187-230).  hodor_lde(lde_factor = n / nz) — the zero-aware transform
+    of the ABI — against the restated pruned schedule, and hodor_fft against the unpruned one."""
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    n, nz = 1 << log_n, 1 << log_nz
+    _, k, w = O.domain(n)
+    a = O.random_elements(n, 800 + log_n)
+    a[nz:] = 0
+    exp = a.copy()
+    O.best_dit_fft(exp, w, k, nz, cpus=8)
+    got = a.copy()
+    ctx.lde(got, w, log_n, n // nz)
+    assert np.array_equal(got, exp)
+    full = a.copy()
+    ctx.fft(full, w, log_n)
+    assert np.array_equal(full, exp)
+    if log_n <= 16:
+        un = a.copy()
+        O.serial_dit_fft(un, w, k, n)
+        assert np.array_equal(un, exp)
+
+
 def test_fft_arbitrary_omega_and_inverse_roundtrip(gpu_ctxs, oracles, field_name):
     """test_worker_size (src/fft/mod.rs:281-328): forward then inverse * n^-1 == identity."""
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
@@ -602,7 +626,10 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     """The reference calls best_fft concurrently from scoped threads (src/arp/per_register/mod.rs:43-49,
     src/polynomials/mod.rs:446-460); the ABI must be re-entrant on one context (ctypes drops the GIL).
     Eight threads on three copy lanes, different sizes per thread (the lanes' staging buffers grow while
-    other lanes are in flight), in-place transforms, LDE (separate in/out buffers) and tree builds."""
+    other lanes are in flight), in-place transforms, LDE (separate in/out buffers), tree builds, and the
+    slice-API FRI commit with a final inverse transform larger than one tile (lde 16 x out_deg 128 = 2048
+    points: a multi-pass iFFT through the context's shared ping-pong scratch, the case that used to run on
+    the legacy NULL stream, unordered with the other threads' transforms)."""
     import threading
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     sizes = [10, 13, 11, 14, 12, 13, 15, 10]
@@ -613,8 +640,11 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
         O.serial_fft(e, O.domain(1 << lg)[2], lg)
         expected.append(e)
         expected_lde.append(O.poly_lde(a, 4))
+    fri_code = O.poly_lde(O.random_elements(1 << 10, 4321), 16)     # 2^14 codeword, degree < 2^10
+    fri_expected = O.fri_commit(fri_code, 16, 128)["serialized"]
     results = [None] * len(inputs)
     results_lde = [None] * len(inputs)
+    results_fri = [None] * len(inputs)
     errors = []
 
     def work(t):
@@ -631,6 +661,10 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
                 results_lde[t] = ctx.poly_lde(inputs[t], 4)
                 nodes = ctx.iop_create(b)
                 assert nodes.shape == (1 << lg, 32)
+                if t % 3 == 0:
+                    proto = ctx.fri_commit(fri_code, 16, 128)
+                    results_fri[t] = proto.serialized
+                    proto.free()
         except Exception as exc:   # noqa: BLE001
             errors.append(exc)
 
@@ -643,6 +677,8 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     for t in range(len(inputs)):
         assert np.array_equal(results[t], expected[t]), t
         assert np.array_equal(results_lde[t], expected_lde[t]), t
+        assert results_fri[t] in (None, fri_expected), t
+    assert sum(r is not None for r in results_fri) == 3
 
 
 # ---------------------------------------------------------------- value-form polynomial ops (§8 f.1)
@@ -692,11 +728,27 @@ def test_value_form_ops_dev(gpu_ctxs, oracles, field_name, n):
 
 
 # ---------------------------------------------------------------- full BASELINE sizes
+# (every element of configs 1-3 is compared in tests/test_gpu_fullsize.py through whole-buffer digests;
+# the tests below add sizes for which no CPU transform was run: output points by direct evaluation)
+def cpu_point(O, dev_coeffs, point, chunk_log=25):
+    """sum_i a[i] point^i by the CPU ORACLE (o_poly_evaluate_at_mt, the reference's own chunked schedule,
+    src/polynomials/mod.rs:685-711) over a device-resident coefficient vector, downloaded 1 GiB at a time.
+    Shares no arithmetic, table or kernel with the library under test."""
+    n = dev_coeffs.shape[0]
+    step = min(n, 1 << chunk_log)
+    acc = 0
+    for start in range(0, n, step):
+        host = dev_coeffs[start:start + step].cpu().numpy().view(np.uint64)
+        part = O.evaluate_at(host, point, cpus=None)
+        acc = O.add(acc, O.mul(part, O.pow(point, start)))
+    return acc
+
+
 def test_ntt_2_24_output_points_against_cpu_oracle(gpu_ctxs, oracles):
-    """BASELINE config[1] size.  A CPU transform of 2^24 points is out of reach for the test budget, but
-    single output points are not: X[k] = sum_i x[i] w^(ik) (evaluate_at, src/polynomials/mod.rs:685-711)
-    by the CPU oracle for a few k, plus the device-side evaluate_at (32-bit-limb arithmetic, a code path
-    independent of the 9x29-limb NTT kernels) for many more."""
+    """BASELINE config[1] size on torch-random inputs: X[k] = sum_i x[i] w^(ik) (evaluate_at,
+    src/polynomials/mod.rs:685-711) by the CPU oracle for every checked k.  The device-side evaluate_at is
+    exercised on the same points too, but it is NOT an independent witness (above 2^16 coefficients it
+    runs on fr9_mul and the k_pow_table tables, like the NTT)."""
     import torch
     from bench import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
@@ -707,14 +759,11 @@ def test_ntt_2_24_output_points_against_cpu_oracle(gpu_ctxs, oracles):
     ctx.poly_fft_dev(a, b, log_n)
     ctx.synchronize()
     _, _, w = O.domain(n)
-    host_in = a.cpu().numpy().view(np.uint64)
-    ks_cpu = [1, n - 1]
-    ks_dev = [0, 2, 12345, n // 2, n // 3, (1 << 23) + 77, n - 2]
     out = b.cpu().numpy().view(np.uint64)
-    for k in ks_cpu:
-        assert array_to_ints(out[k:k + 1])[0] == O.evaluate_at(host_in, O.pow(w, k)), k
-    for k in ks_dev + ks_cpu:
-        assert array_to_ints(out[k:k + 1])[0] == ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)), k
+    for k in [0, 1, 2, 12345, n // 2, n // 3, (1 << 23) + 77, n - 2, n - 1]:
+        exp = cpu_point(O, a, O.pow(w, k))
+        assert array_to_ints(out[k:k + 1])[0] == exp, k
+        assert ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)) == exp, k
     # inverse brings the input back, bit for bit
     c = torch.empty_like(a)
     ctx.poly_ifft_dev(b, c, log_n)
@@ -735,7 +784,7 @@ def test_large_transforms_roundtrip_and_points(gpu_ctxs, oracles, log_n):
     _, _, w = O.domain(n)
     for k in (0, 1, n - 1, (n // 7) * 3):
         got = array_to_ints(b[k:k + 1].cpu().numpy().view(np.uint64))[0]
-        assert got == ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)), k
+        assert got == cpu_point(O, a, O.pow(w, k)), k             # CPU oracle: independent of the library
     ctx.poly_ifft_dev(b, b, log_n)            # in place
     ctx.synchronize()
     assert torch.equal(a, b)
@@ -743,9 +792,10 @@ def test_large_transforms_roundtrip_and_points(gpu_ctxs, oracles, log_n):
 
 @pytest.mark.parametrize("coset", [False, True])
 def test_lde_benchmark_size_points_and_subgrid(gpu_ctxs, oracles, coset):
-    """BASELINE config[2]: lde(8) of 2^22 coefficients.  out[idx] = P(W^idx) (resp. P(g W^idx)) checked by
-    direct evaluation (evaluate_at: a different kernel and a Horner-free sum), and the sub-grid idx = 8k is
-    the plain (coset) transform of the coefficients (src/polynomials/mod.rs:466-479 interleave)."""
+    """BASELINE config[2] on torch-random coefficients (the SplitMix64 instance is compared element for
+    element in test_gpu_fullsize.py).  out[idx] = P(W^idx) (resp. P(g W^idx)) checked by direct evaluation
+    on the CPU oracle, and the sub-grid idx = 8k is the plain (coset) transform of the coefficients
+    (src/polynomials/mod.rs:466-479 interleave)."""
     import torch
     from bench import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
@@ -761,7 +811,7 @@ def test_lde_benchmark_size_points_and_subgrid(gpu_ctxs, oracles, coset):
         if coset:
             point = O.mul(point, g)
         got = array_to_ints(d_out[idx:idx + 1].cpu().numpy().view(np.uint64))[0]
-        assert got == ctx.poly_evaluate_at_dev(d_c, n, point), idx
+        assert got == cpu_point(O, d_c, point), idx
     plain = torch.empty_like(d_c)
     (ctx.poly_coset_fft_dev if coset else ctx.poly_fft_dev)(d_c, plain, log_n)
     ctx.synchronize()
@@ -774,8 +824,8 @@ def test_lde_benchmark_size_points_and_subgrid(gpu_ctxs, oracles, coset):
 def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
     """2^30 is BASELINE config[4]'s size and two doublings short of the field's 2-adicity (S = 32);
     at 32 B per element it is 32 GiB per buffer — it fits one MI355X (288 GB) with its ping-pong
-    scratch.  Checks a 4-pass plan with > 2^31-byte offsets: output points by direct evaluation
-    (device evaluate_at, independent arithmetic) and the inverse round trip."""
+    scratch.  Checks a 4-pass plan with > 2^31-byte offsets: output points by direct evaluation on the
+    CPU oracle (coefficients downloaded 1 GiB at a time) and the inverse round trip."""
     import torch
     from bench import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
@@ -787,9 +837,9 @@ def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
     b = torch.empty_like(a)
     ctx.poly_fft_dev(a, b, log_n)
     _, _, w = O.domain(n)
-    for k in (1, n - 1, (n // 5) * 2 + 1):
+    for k in (1, (n // 5) * 2 + 1):
         got = array_to_ints(b[k:k + 1].cpu().numpy().view(np.uint64))[0]
-        assert got == ctx.poly_evaluate_at_dev(a, n, O.pow(w, k)), k
+        assert got == cpu_point(O, a, O.pow(w, k)), k
     ctx.poly_ifft_dev(b, b, log_n)
     ctx.synchronize()
     assert torch.equal(a, b)

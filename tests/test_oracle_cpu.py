@@ -142,6 +142,38 @@ def test_reference_differential_identities(oracles, field_name, log_n):
             assert array_to_ints(clde[idx:idx + 1])[0] == O.evaluate_at(a, pt)
 
 
+@pytest.mark.parametrize("log_n", [1, 3, 6, 9, 12])
+def test_dit_fft_three_way_and_pruning(oracles, field_name, log_n):
+    """serial_DIT_fft / parallel_DIT_fft / best_DIT_fft (src/fft/dit_fft/mod.rs:4-123) == serial_fft, and
+    test_fft_prunning (src/fft/mod.rs:187-230): with only the first n / 2^k inputs non-zero, the transform
+    pruned by non_zero_entries_count equals the unpruned one — the schedule hodor_lde(nnz) replaces."""
+    O = oracles[field_name]
+    n = 1 << log_n
+    _, k, w = O.domain(n)
+    a = O.random_elements(n, 40 + log_n)
+    ref = a.copy(); O.serial_fft(ref, w, k)
+    d = a.copy(); O.serial_dit_fft(d, w, k, n)
+    assert np.array_equal(d, ref)
+    for log_cpus in (1, 2):
+        if log_n >= log_cpus:
+            pd = a.copy(); O.parallel_dit_fft(pd, w, k, log_cpus, n)
+            assert np.array_equal(pd, ref)
+    for cpus in (1, 4, 64):
+        bd = a.copy(); O.best_dit_fft(bd, w, k, n, cpus=cpus)
+        assert np.array_equal(bd, ref)
+    for log_nz in range(0, log_n + 1):
+        nz = 1 << log_nz
+        z = a.copy(); z[nz:] = 0
+        full = z.copy(); O.serial_fft(full, w, k)
+        pr = z.copy(); O.serial_dit_fft(pr, w, k, nz)
+        assert np.array_equal(pr, full), log_nz
+        pp = z.copy(); O.best_dit_fft(pp, w, k, nz, cpus=4)
+        assert np.array_equal(pp, full), log_nz
+        if log_nz < log_n:                      # serial_lde (lde.rs) is the same zero-aware transform
+            sl = z.copy(); O.serial_lde(sl, w, k, n // nz)
+            assert np.array_equal(sl, full), log_nz
+
+
 def test_fri_by_values_equals_through_coefficients(oracles, field_name):
     """test_one_fri_step / test_fri_on_values_vs_on_coefficients (src/fri/mod.rs:252-361, :510-692):
     every intermediate vector equals the LDE of the folded coefficients a_2i + beta*a_2i+1."""
