@@ -44,7 +44,7 @@ WARM_MS = 150.0           # clocks settle after ~100 ms of load: warm up by time
 # regenerates the same SplitMix64 inputs on the device and refuses to print a number unless its
 # outputs hash to them.
 FIXTURES = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
-KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS",
+KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TILES",
              "HODOR_MERKLE_TAIL_LOG", "HODOR_MERKLE_LAT_LOG", "HODOR_FRI_TAIL", "HODOR_FRI_FUSE_FOLD",
              "HODOR_BATCHINV_SEQ", "HODOR_DBG", "HODOR_LIB")
 
@@ -91,7 +91,12 @@ def main():
                          "'replicas' = one independent 2^log_n polynomial per GPU, no data-path collective")
     ap.add_argument("--allow-knobs", action="store_true",
                     help="run although HODOR_* tuning variables are set (they are echoed in the JSON line)")
+    ap.add_argument("--skip-checks", action="store_true",
+                    help="ablation builds only (bench/ablate.sh): results are wrong by construction; needs "
+                         "--allow-knobs and marks the line \"checks\": {\"skipped\": true}")
     args = ap.parse_args()
+    if args.skip_checks and not args.allow_knobs:
+        raise SystemExit("--skip-checks is for ablation runs and needs --allow-knobs")
     if args.mode is None:
         args.mode = "sixstep" if args.gpus > 1 else "replicas"
     knobs = {k: os.environ[k] for k in KNOB_VARS if k in os.environ}
@@ -150,7 +155,11 @@ def main():
     stream = side.cuda_stream
 
     if args.mode == "sixstep":
-        from hodor_amd.sixstep import HipBackend, sixstep_intt, sixstep_ntt
+        # ONE transform of world * 2^log_n points: rank q holds column block q of the N1 x N2 input matrix
+        # (layout A), the forward transform leaves row block q of the output matrix (layout B), the inverse
+        # brings A back — one RCCL all-to-all each way (hodor_amd/sixstep.py; all local work, transposes
+        # included, inside the C ABI).
+        from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse
         log_total = log_n + (world.bit_length() - 1)
         assert 1 << (world.bit_length() - 1) == world, "sixstep needs a power-of-two world size"
         omega = ctx.domain(1 << log_total)[2]
@@ -158,8 +167,8 @@ def main():
         holder = {}
 
         def step():
-            y = sixstep_ntt(be, a, log_total, omega, rank, world)
-            holder["c"] = sixstep_intt(be, y, log_total, omega, rank, world)
+            holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world)
+            holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world)
     else:
         def step():
             ctx.poly_fft_dev(a, b, log_n, stream=stream)
@@ -176,11 +185,16 @@ def main():
         c = holder["c"]
     # correctness gates (outside the timed region): the round trip, and — where the CPU oracle's answer
     # for this exact input is committed — every element of the forward transform through its digest
-    checks = {"roundtrip": bool(torch.equal(a, c))}
-    if not checks["roundtrip"]:
+    checks = {"skipped": True} if args.skip_checks else {"roundtrip": bool(torch.equal(a, c))}
+    if not args.skip_checks and not checks["roundtrip"]:
         raise SystemExit("iNTT(NTT(x)) != x — refusing to report a number")
     fx = FIXTURES["ntt"].get(str(log_n))
-    if fx and rank == 0 and args.mode == "replicas":
+    if fx and rank == 0 and world == 1 and not args.skip_checks:
+        if args.mode == "sixstep":      # layout B = the N1 x N2 matrix X[k1 + N1*k2]: transpose to natural order
+            from hodor_amd.sixstep import split_logs
+            l1, l2 = split_logs(log_n)
+            b = be.transpose(holder["b"], 1 << l1, 1 << l2)
+            torch.cuda.synchronize()
         if digest(a) != fx["input"] or digest(b) != fx["fft"]:
             raise SystemExit("forward NTT differs from the CPU oracle's committed digest — refusing to report")
         checks["fft_digest_vs_cpu_oracle"] = True
@@ -206,6 +220,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    exchange = None
+    if args.mode == "sixstep":
+        # the exchange alone, timed apart from the step: bytes each rank puts on xGMI per transform and the
+        # time one all-to-all of that size takes with nothing else running
+        from hodor_amd.sixstep import all_to_all_slabs
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        all_to_all_slabs(holder["b"], world)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            all_to_all_slabs(holder["b"], world)
+        e1.record()
+        torch.cuda.synchronize()
+        sent = n * 32 * (world - 1) / world
+        ms = e0.elapsed_time(e1) / reps
+        exchange = {"all_to_alls_per_transform": 1, "bytes_sent_per_rank_per_transform": sent,
+                    "all_to_all_ms": ms, "gb_per_s_per_rank": (sent / (ms * 1e-3) / 1e9) if world > 1 else None,
+                    "share_of_step": 2 * ms / (dt / args.steps * 1e3) if world > 1 else 0.0}
+
     elems = 2.0 * n * args.steps * world       # forward + inverse
     result = {
         "metric": "ntt_field_elems_per_sec",
@@ -227,17 +261,26 @@ def main():
                    "log_n": log_n, "field": "bn256.rs Fr (255-bit, R=2^256)",
                    "arithmetic": "exact integer: 256-bit Montgomery elements as 9 x 29-bit limbs in u32, "
                                  "32x32->64 multiply-accumulate (v_mad_u64_u32)",
-                   "parallelism": ("6-step, 2^%d points over %d GPUs, RCCL all-to-all transposes"
+                   "parallelism": ("4-step (Bailey), ONE transform of 2^%d points over %d GPU(s), column blocks in / "
+                                   "row blocks out, one RCCL all-to-all per transform"
                                    % (log_n + world.bit_length() - 1, world)) if args.mode == "sixstep"
                    else ("1 polynomial per GPU" if world > 1 else "1 GPU")},
         "checks": checks,
         "knobs": knobs,
     }
+    if exchange:
+        result["exchange"] = exchange
 
     if rank == 0:
         # roofline of the dominant kernel (k_ntt_pass): one transform = `passes` launches and must
         # move 2 x n x 32 B at least once; each launch is charged 1/passes of that.
-        passes = max(1, -(-log_n // 9)) if log_n > 10 else 1     # plan_radices() in csrc/abi.hip
+        def plan_passes(lg):                                     # plan_radices() in csrc/abi.hip
+            return max(1, -(-lg // 9)) if lg > 10 else 1
+        if args.mode == "sixstep":
+            from hodor_amd.sixstep import split_logs
+            passes = sum(plan_passes(x) for x in split_logs(log_n + world.bit_length() - 1))
+        else:
+            passes = plan_passes(log_n)
         launches = 2 * passes * args.steps
         avg_launch_ms = kernel_ms / launches
         alg_bytes_per_launch = 2.0 * n * 32 / passes
@@ -276,7 +319,8 @@ def main():
                                       "addition, carry or memory instruction"
                                       % (hbm_target_ms, log_n, products, MAD_PEAK_TOPS, mad_floor_ms,
                                          mad_floor_ms / hbm_target_ms)}
-        result["roofline"]["valu"] = {
+        if args.mode == "replicas":
+          result["roofline"]["valu"] = {
             "bound": "v_mad_u64_u32 issue", "products_per_element": products, "mads_per_product": 108,
             "achieved": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
             "frac": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12 / MAD_PEAK_TOPS,

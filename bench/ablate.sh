@@ -1,6 +1,9 @@
-# Phase ablation of k_ntt_pass (profiling only; results are wrong by construction):
+# Phase ablation of k_ntt_pass (profiling only; results are wrong by construction).  Uses the
+# -DHODOR_ABLATE build (make -C hodor_amd/csrc ablate -> hodor_amd/libhodor_gpu_ablate.so); the shipped
+# library contains none of these switches.
 # HODOR_DBG bits: 1 skip butterflies, 2 skip inter-pass twiddles, 4 skip global loads, 8 skip global stores
-run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', round(d['ms_per_step'],3))"; }
+export HODOR_LIB=$PWD/hodor_amd/libhodor_gpu_ablate.so
+run() { echo "== $*"; env "$@" python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --allow-knobs --skip-checks 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', round(d['ms_per_step'],3))"; }
 run HODOR_DBG=0
 run HODOR_DBG=1
 run HODOR_DBG=2

@@ -1,29 +1,45 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for bench.py's dominant kernel.  Run on the GPU box from the repo
-# root:  bash bench/profile.sh <tag>      (outputs under gpurun_out/prof_<tag>/)
-TAG=${1:-r01}
+# Collects the rocprofv3 evidence for bench.py's kernels.  Run on the GPU box from the repo root:
+#   bash bench/profile.sh <tag>      (outputs under gpurun_out/prof_<tag>/, summary in summary.txt)
+# Counters are collected in their own passes (--kernel-trace + --pmc only), one --pmc group per run.
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --no-cpu-baseline --no-extra"   # the default steps/warmup: clocks need ~100 ms to ramp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ntt -- $CMD > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o ntt -- $CMD > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o ntt -- $CMD > $OUT/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o ntt -- $CMD > $OUT/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_lds -o ntt -- $CMD > $OUT/pmc_lds.log 2>&1
-# full bench with LDE+commit for the kernel mix
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_full -o full -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace_full.log 2>&1
-find $OUT -name "*.csv" | head -40
-python - <<PY
+NTT="python $REPO/bench.py --no-cpu-baseline --no-extra"   # default steps/warmup: clocks need ~100 ms to ramp
+FULL="python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ntt -- $NTT > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_full -o full -- $FULL > $OUT/trace_full.log 2>&1
+pmc() {  # name, command, counters...
+    local name=$1; shift; local cmd=$1; shift
+    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $cmd > $OUT/$name.log 2>&1
+}
+pmc pmc_fetch "$NTT" FETCH_SIZE
+pmc pmc_write "$NTT" WRITE_SIZE
+pmc pmc_sq "$NTT" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+pmc pmc_lds "$NTT" SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+pmc pmc_l2 "$NTT" TCC_HIT_sum TCC_MISS_sum
+# Merkle / FRI kernels (full bench: LDE x8 + commit, FRI commit 2^26)
+pmc full_fetch "$FULL" FETCH_SIZE
+pmc full_write "$FULL" WRITE_SIZE
+pmc full_sq "$FULL" SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+python - > $OUT/summary.txt <<PY
 import csv, glob, collections
-for sub in ("pmc_fetch","pmc_write","pmc_sq","pmc_lds"):
+def stats(sub):
+    for f in glob.glob("$OUT/%s/**/*kernel_stats.csv" % sub, recursive=True):
+        print("==", sub, f.split("/")[-1])
+        for r in list(csv.DictReader(open(f)))[:14]:
+            print("  %-60s calls %6s avg_ns %12s total_ns %14s pct %s" % (r["Name"][:60], r["Calls"], r["AverageNs"], r["TotalDurationNs"], r["Percentage"]))
+stats("trace"); stats("trace_full")
+for sub in ("pmc_fetch","pmc_write","pmc_sq","pmc_lds","pmc_l2","full_fetch","full_write","full_sq"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
-            k = (r["Kernel_Name"][:40], r["Counter_Name"])
+            k = (r["Kernel_Name"].split("(")[0][-44:], r["Counter_Name"])
             agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
         for k, v in sorted(agg.items()):
-            if "ntt_pass" in k[0] or "leaf" in k[0]:
-                print(sub, k, "dispatches", v[0], "avg", v[1] / v[0])
+            if any(t in k[0] for t in ("ntt_pass", "merkle", "fri_fold", "fri_tail", "fri_round")):
+                print(sub, k[0], k[1], "dispatches", v[0], "avg", v[1] / v[0])
 PY
+cat $OUT/summary.txt

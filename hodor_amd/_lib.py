@@ -44,6 +44,7 @@ EXPORTS = [
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
+    "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_prototype",
 ]
 
@@ -506,6 +507,26 @@ class Context:
         cc = _fr(c) if c is not None else None
         self._chk(self.L.hodor_poly_unary_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.c_int(code),
                                               C.byref(cc) if cc is not None else None, C.c_uint64(e)))
+
+    def sixstep_columns_dev(self, src, dst, log_n1, log_n2, log_p, rank, omega, inverse=False, stream=None):
+        w = _fr(omega)
+        self._chk(self.L.hodor_sixstep_columns_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                   C.c_uint32(log_n1), C.c_uint32(log_n2), C.c_uint32(log_p),
+                                                   C.c_uint32(rank), C.byref(w), C.c_int(1 if inverse else 0)))
+
+    def sixstep_rows_dev(self, src, dst, log_n1, log_n2, log_p, rank, omega, inverse=False, stream=None):
+        w = _fr(omega)
+        self._chk(self.L.hodor_sixstep_rows_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                C.c_uint32(log_n1), C.c_uint32(log_n2), C.c_uint32(log_p),
+                                                C.c_uint32(rank), C.byref(w), C.c_int(1 if inverse else 0)))
+
+    def sixstep_pack_dev(self, src, dst, log_rows, log_cols, log_p, stream=None):
+        self._chk(self.L.hodor_sixstep_pack_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                C.c_uint32(log_rows), C.c_uint32(log_cols), C.c_uint32(log_p)))
+
+    def transpose_dev(self, src, dst, rows, cols, stream=None):
+        self._chk(self.L.hodor_transpose_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                             C.c_size_t(rows), C.c_size_t(cols)))
 
     def gen_elements_dev(self, dst, first_index, count, seed, stream=None):
         """dst[r] = element first_index + r of the SplitMix64 input stream `seed`."""

@@ -223,9 +223,12 @@ static void plan_radices(const hodor_ctx *ctx, uint32_t log_n, std::vector<uint3
 
 // dst[k] = post^k * scale * sum_i (pre^i * src[i]) omega^(ik),  src[i] = 0 for i >= nnz.
 // src may equal dst.  Caller holds ctx->mu.
-static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n,
-                    const HFr &omega, uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post,
-                    uint32_t batch = 1)
+// `lay` (6-step building blocks): column mode over a [2^log_n][width] array (batch must then be the
+// width: it sizes the scratch), the 2D twiddle, split addressing of the first pass's input / the last
+// pass's output.
+int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n,
+             const HFr &omega, uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post,
+             uint32_t batch, const NttLayout *lay)
 {
     std::vector<uint32_t> radices;
     plan_radices(ctx, log_n, &radices);
@@ -251,6 +254,8 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
     if (fold_scale && (rc = get_pow_table(ctx, omega, log_n, &tw_last, 2, tw_lo_bits, scale))) return rc;
     if (pre && (rc = get_pow_table(ctx, *pre, log_n, &pre_t, 2))) return rc;
     if (post && (rc = get_pow_table(ctx, *post, log_n, &post_t, 2))) return rc;
+    TwoLevel tw2d_t = {nullptr, nullptr, 0};
+    if (lay && lay->tw2d_root && (rc = get_pow_table(ctx, *lay->tw2d_root, lay->tw2d_log_order, &tw2d_t, 2))) return rc;
 
     // ping-pong buffers: the last pass writes dst; a pass never runs in place unless it is the only
     // one (a single tile is fully staged in LDS before anything is written back).
@@ -280,7 +285,7 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
     if (scale) scale_d = to_dev9(ctx->F, *scale);
     for (size_t i = 0; i < passes; i++) {
         uint32_t log_r = radices[i];
-        PassArgs A;
+        PassArgs A = {};
         A.src = cur;
         A.dst = outs[i];
         if ((rc = get_radix_table(ctx, omega, log_n, log_r, &A.rtw))) return rc;
@@ -292,7 +297,20 @@ static int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 
         A.log_n = log_n;
         A.log_r = log_r;
         uint32_t log_c = ctx->tile_log > log_r ? ctx->tile_log - log_r : 0;
-        if (log_c > log_n - log_r) log_c = log_n - log_r;
+        if (lay && lay->col_mode) {
+            if (log_c > lay->log_width) log_c = lay->log_width;     // the tile's columns are array columns
+            A.col_mode = 1;
+            A.log_width = lay->log_width;
+            A.col0 = lay->col0;
+            if (tw2d_t.lo && ((lay->tw2d_on_load && i == 0) || (!lay->tw2d_on_load && i + 1 == passes))) {
+                A.tw2d = tw2d_t;
+                A.tw2d_on_load = lay->tw2d_on_load ? 1 : 0;
+            }
+        } else if (log_c > log_n - log_r) {
+            log_c = log_n - log_r;
+        }
+        if (lay && i == 0) A.src_split = lay->src_split;
+        if (lay && i + 1 == passes) A.dst_split = lay->dst_split;
         A.log_c = log_c;
         A.log_l = log_l;
         A.apply_tw = (i == 0) ? 0 : 1;
@@ -330,7 +348,7 @@ int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *
     uint64_t n = 1ull << log_n;
     switch (op) {
     case OP_FFT:
-        return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, nullptr, nullptr);
+        return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, nullptr, nullptr, 1, nullptr);
     case OP_COSET_FFT:   // distribute_powers(g) then fft — src/polynomials/mod.rs:626-631
         return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, &ctx->F.generator, nullptr);
     case OP_IFFT:

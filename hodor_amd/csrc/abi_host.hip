@@ -222,6 +222,7 @@ static Knobs read_knobs()
     k.tile_log = get("HODOR_TILE_LOG", 10, 6, 12);
     k.tw_hi_max_log = get("HODOR_TW_HI_MAX_LOG", 17, 0, 20);
     k.ntt_threads = get("HODOR_NTT_THREADS", 0, 0, 1024);
+    k.ntt_tiles = get("HODOR_NTT_TILES", 4, 0, 64);
     k.merkle_tail_log = get("HODOR_MERKLE_TAIL_LOG", 6, 0, 30);
     k.merkle_lat_log = get("HODOR_MERKLE_LAT_LOG", 19, 0, 40);
     k.fri_tail = get("HODOR_FRI_TAIL", 1, 0, 1);

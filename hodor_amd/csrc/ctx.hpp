@@ -215,6 +215,18 @@ int trim_table_cache(hodor_ctx *ctx);
 int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
                   uint32_t lo_bits = 0xffffffffu, const HFr *hi_mult_p = nullptr);
 int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes);
+struct NttLayout {
+    bool col_mode = false;           // transform along the slow axis of a [2^log_n][2^log_width] array
+    uint32_t log_width = 0;
+    uint64_t col0 = 0;               // global index of array column 0
+    const HFr *tw2d_root = nullptr;  // 2D twiddle root^(index * (col0 + col)) ...
+    uint32_t tw2d_log_order = 0;     // ... of order 2^tw2d_log_order, on the first pass's inputs (true) or the
+    bool tw2d_on_load = false;       //     last pass's outputs (false)
+    SplitAddr src_split = {}, dst_split = {};
+};
+int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, const HFr &omega,
+             uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post, uint32_t batch = 1,
+             const NttLayout *lay = nullptr);
 int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega);
 enum PolyOp { OP_FFT, OP_COSET_FFT, OP_IFFT, OP_ICOSET_FFT };
 int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op);

@@ -10,6 +10,7 @@ struct Knobs {
     int tile_log;         // HODOR_TILE_LOG        elements per NTT workgroup tile (log2)               10
     int tw_hi_max_log;    // HODOR_TW_HI_MAX_LOG   largest hi-only twiddle split (log2 entries)         17
     int ntt_threads;      // HODOR_NTT_THREADS     workgroup size override of k_ntt_pass (0 = auto)      0
+    int ntt_tiles;        // HODOR_NTT_TILES       tiles per workgroup on the prefetching pass (0 = off)   4
     int merkle_tail_log;  // HODOR_MERKLE_TAIL_LOG level width at which a throughput chunk stops         6
     int merkle_lat_log;   // HODOR_MERKLE_LAT_LOG  largest level on the latency schedule                19
     int fri_tail;         // HODOR_FRI_TAIL        fused tail of the FRI commit                          1

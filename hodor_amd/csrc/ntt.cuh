@@ -23,6 +23,16 @@ struct W3Consts {
     Fr k[3];
 };
 
+// Split addressing of one transform axis (6-step building blocks, abi_sixstep.hip): element x of batch
+// member b lives at
+//     (x >> hi_log) * stride_hi + ((x >> lo_log) & mid_mask) * stride_mid + b * batch_stride + (x & lo_mask)
+// i.e. the axis arrives (or leaves) cut into P slabs of an all-to-all, each slab optionally cut into
+// `chunks` pieces that were exchanged separately.  on == 0: plain arrays.
+struct SplitAddr {
+    uint32_t on, lo_log, hi_log, mid_mask;
+    uint64_t stride_mid, stride_hi, batch_stride;
+};
+
 struct PassArgs {
     const uint4 *src;        // n elements (only the first nnz are read; the rest are implicit zeros)
     uint4 *dst;              // n elements
@@ -39,7 +49,18 @@ struct PassArgs {
     uint32_t tw_always;      // 1: multiply by the twiddle even when its exponent is 0 (hi carries the iNTT scale)
     uint32_t batch;          // number of independent size-n transforms (grid.y); dst arrays are n elements apart
     uint64_t src_batch_stride;   // distance between the batch's source arrays, in elements
+    uint32_t tiles_per_wg;   // k_ntt_pass<*, EPT > 0>: adjacent tiles one workgroup walks (set by the launcher)
     uint32_t log_skip;       // first pass of a zero-padded transform: nnz == n >> log_skip (see k_ntt_pass)
+    // ---- generalized layouts (k_ntt_pass<1> only; all zero for plain arrays)
+    uint32_t col_mode;       // 1: the data is a 2D array [index][width] and the transform runs along `index` for
+                             //    every column: the tile's C columns are C adjacent array columns (grid.y = width/C)
+                             //    and a workgroup owns ONE sub-transform position j
+    uint32_t log_width;      // col_mode: log2(width)
+    uint64_t col0;           // col_mode: global index of array column 0, for the 2D twiddle w^(index * (col0 + col))
+    TwoLevel tw2d;           // col_mode: that twiddle's table (lo == nullptr: none) ...
+    uint32_t tw2d_on_load;   // ... applied to the inputs of the first pass (1) or the outputs of the last pass (0)
+    SplitAddr src_split;     // first pass: where input element x of batch member b lives
+    SplitAddr dst_split;     // last pass: where output element x of batch member b goes
     uint32_t dbg;            // read only by -DHODOR_ABLATE builds (bench/ablate.sh): 1 skip butterflies, 2 twiddles, 4 loads, 8 stores
 };
 

@@ -144,7 +144,21 @@ constexpr int NTT_MAX_THREADS = 512;
 #define ABL(bit) false
 #endif
 
-__global__ void __launch_bounds__(NTT_MAX_THREADS)
+__device__ __forceinline__ uint64_t split_index(const SplitAddr &S, uint64_t x, uint32_t b)
+{
+    return (x >> S.hi_log) * S.stride_hi + ((x >> S.lo_log) & S.mid_mask) * S.stride_mid + b * S.batch_stride +
+           (x & ((1ull << S.lo_log) - 1));
+}
+
+// MODE 0: plain arrays (every transform of the single-GPU API).  MODE 1: the same pass with the
+// generalized layouts of PassArgs (column mode, 2D twiddle, split addressing) compiled in.
+// EPT > 0: every thread loads exactly EPT elements of a tile (tile == EPT * blockDim.x, no zero
+// padding), a workgroup walks A.tiles_per_wg adjacent tiles, and the raw 32-byte elements of the NEXT
+// tile are fetched into registers before the butterflies of the current one, so the HBM latency of
+// all but the first tile hides behind arithmetic (and the LDS twiddle table is staged once per
+// workgroup instead of once per tile).  EPT == 0: one tile per workgroup, any shape.
+template <int MODE, int EPT>
+__global__ void __launch_bounds__(NTT_MAX_THREADS, EPT ? 3 : 1)   // EPT: 3 workgroups of 256 threads per CU (LDS) -> <= 168 VGPRs
 k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -171,26 +185,73 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     const uint4 *src_b = A.src + 2ull * blockIdx.y * A.src_batch_stride;   // first LDE pass: n/f apart
     uint4 *dst_b = A.dst + ((2ull * blockIdx.y) << A.log_n);
     const uint64_t n_over_r = 1ull << (A.log_n - log_r);
-    const uint64_t j0 = (uint64_t)blockIdx.x << log_c;
+    const bool colm = MODE == 1 && A.col_mode;
+    const uint64_t colbase = colm ? ((uint64_t)blockIdx.y << log_c) : 0;   // first array column of this tile
     const uint64_t Lmask = (1ull << A.log_l) - 1;
     const uint32_t tw_shift = A.log_n - A.log_l - log_r;   // exponent scale N / (L*R)
     const uint32_t tile = R << log_c;
+    const uint32_t tiles = EPT ? A.tiles_per_wg : 1u;
+    const uint64_t bx0 = (uint64_t)blockIdx.x * tiles;
+
+    // EPT path: the raw elements of one tile, EPT (= 4) per thread — element k of a thread is tile element
+    // tid + k * blockDim.x.  Four named values, not an array: an indexed private array lands in scratch.
+    Fr raw0 = {}, raw1 = {}, raw2 = {}, raw3 = {};
+#define FETCH_RAW(bx_)                                                                            \
+    do {                                                                                          \
+        const uint64_t b__ = (uint64_t)(bx_) << log_c;                                            \
+        const uint32_t e0 = tid, e1 = tid + nthreads, e2 = tid + 2 * nthreads, e3 = tid + 3 * nthreads; \
+        raw0 = fr_load(src_b + 2 * (b__ + (e0 & (C - 1)) + (uint64_t)(e0 >> log_c) * n_over_r));   \
+        raw1 = fr_load(src_b + 2 * (b__ + (e1 & (C - 1)) + (uint64_t)(e1 >> log_c) * n_over_r));   \
+        raw2 = fr_load(src_b + 2 * (b__ + (e2 & (C - 1)) + (uint64_t)(e2 >> log_c) * n_over_r));   \
+        raw3 = fr_load(src_b + 2 * (b__ + (e3 & (C - 1)) + (uint64_t)(e3 >> log_c) * n_over_r));   \
+    } while (0)
+    if (EPT) FETCH_RAW(bx0);
+
+  for (uint32_t t = 0; t < tiles; t++) {
+    const uint64_t bx = bx0 + t;
+    const uint64_t j0 = colm ? bx : bx << log_c;
 
     // ---- load: global -> (pre-scale, inter-pass twiddle) -> LDS at bit-reversed row
     // Zero padding (LDE, src/fft/lde.rs:28-31 `is_non_zero`): when only the first n >> s inputs are
     // non-zero, only sub-transform inputs i < R >> s are, they land on rows that are multiples of 2^s,
     // and the first s radix-2 stages merely copy each of them to the 2^s rows of its group — so load
     // 1/2^s of the tile, replicate, and start the butterflies at stage s.
-    const uint32_t log_skip = A.log_skip;
+    const uint32_t log_skip = EPT ? 0u : A.log_skip;
+    if (EPT) {
+#define CONSUME_RAW(k_, raw_)                                                                     \
+        do {                                                                                      \
+            const uint32_t e = tid + (uint32_t)(k_) * nthreads;                                   \
+            const uint32_t c = e & (C - 1), i = e >> log_c;                                       \
+            const uint64_t j = j0 + c;                                                            \
+            const uint64_t g = j + (uint64_t)i * n_over_r;                                        \
+            Fr9 x = fr9_unpack(raw_);                                                             \
+            if (A.pre.lo != nullptr) x = mul_two_level(x, A.pre, g, false, Q);                    \
+            if (A.apply_tw) {                                                                     \
+                uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;                            \
+                x = mul_two_level(x, A.tw, ex, A.tw_always != 0, Q);                              \
+            }                                                                                     \
+            const uint32_t row = log_r ? (__brev(i) >> (32 - log_r)) : 0u;                        \
+            lds_put(D, SLOT(row, c), x);                                                          \
+        } while (0)
+        CONSUME_RAW(0, raw0);
+        CONSUME_RAW(1, raw1);
+        CONSUME_RAW(2, raw2);
+        CONSUME_RAW(3, raw3);
+    } else
     for (uint32_t e = tid; e < (tile >> log_skip); e += nthreads) {
         uint32_t c = e & (C - 1), i = e >> log_c;
-        uint64_t j = j0 + c;
+        uint64_t j = colm ? j0 : j0 + c;
         uint64_t g = j + (uint64_t)i * n_over_r;
         Fr9 x;
         if (g < A.nnz) {
             if (ABL(4)) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) x.v[k] = ((uint32_t)g + k) & HODOR_M29;
+            } else if (MODE == 1 && colm) {
+                x = fr9_unpack(fr_load(A.src + 2 * ((g << A.log_width) + colbase + c)));
+                if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
+            } else if (MODE == 1 && A.src_split.on) {
+                x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, blockIdx.y)));
             } else {
                 x = fr9_unpack(fr_load(src_b + 2 * g));
             }
@@ -207,6 +268,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, SLOT(row + d, c), x);
     }
     __syncthreads();
+    if (EPT && t + 1 < tiles) FETCH_RAW(bx + 1);   // in flight during the butterflies below
 
     // ---- R-point DIT in LDS (values lazily reduced: limbs re-normalized once per step)
     uint32_t log_m = log_skip;
@@ -283,23 +345,29 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     }
 
     // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
-    const bool transposed = (A.log_l == 0);   // first pass: outputs of one sub-transform are contiguous
+    const bool transposed = (A.log_l == 0) && !colm;   // first pass: outputs of one sub-transform are contiguous
     const bool last = (A.log_l + log_r == A.log_n);
     for (uint32_t e = tid; e < tile; e += nthreads) {
         uint32_t c, cc;
         if (transposed) { cc = e & (R - 1); c = e >> log_r; }
         else            { c = e & (C - 1);  cc = e >> log_c; }
-        uint64_t j = j0 + c;
+        uint64_t j = colm ? j0 : j0 + c;
         uint64_t p = j & Lmask;
         uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << A.log_l);
         Fr9 x = lds_get(D, SLOT(cc, c));
         if (has_scale) x = fr9_mul(x, scale, Q);
         if (A.post.lo != nullptr) x = mul_two_level(x, A.post, o, false, Q);
+        if (MODE == 1 && colm && A.tw2d.lo != nullptr && !A.tw2d_on_load)
+            x = mul_two_level(x, A.tw2d, o * (A.col0 + colbase + c), false, Q);
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
         if (ABL(8) && y.v[0] != 0x12345u) continue;
-        fr_store(dst_b + 2 * o, y);
+        if (MODE == 1 && colm) fr_store(A.dst + 2 * ((o << A.log_width) + colbase + c), y);
+        else if (MODE == 1 && A.dst_split.on) fr_store(A.dst + 2 * split_index(A.dst_split, o, blockIdx.y), y);
+        else fr_store(dst_b + 2 * o, y);
     }
+    if (t + 1 < tiles) __syncthreads();   // the next tile overwrites the LDS this one was stored from
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,11 +382,20 @@ size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c)
 
 hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *scale, const Fr9Params &Q)
 {
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc != hipSuccess) return attr_rc;
+    static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<0, 0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_rc1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<1, 0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_rc2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<0, 4>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc0 != hipSuccess) return attr_rc0;
+    if (attr_rc1 != hipSuccess) return attr_rc1;
+    if (attr_rc2 != hipSuccess) return attr_rc2;
     uint64_t n = 1ull << A.log_n;
-    uint64_t grid = n >> (A.log_r + A.log_c);
+    const bool general = A.col_mode || A.src_split.on || A.dst_split.on;
+    // column mode: one sub-transform position per workgroup, grid.y walks the array's columns C at a time
+    uint64_t grid = A.col_mode ? n >> A.log_r : n >> (A.log_r + A.log_c);
+    unsigned grid_y = A.col_mode ? (1u << (A.log_width - A.log_c)) : (A.batch ? A.batch : 1);
     Fr9 s = {};
     if (scale) s = *scale;
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c);
@@ -336,8 +413,21 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
     unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
-    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)grid, A.batch ? A.batch : 1), dim3(threads), lds, stream, B,
-                       s, scale ? 1u : 0u, Q);
+    // multi-tile workgroups with register prefetch: plain layout, full tiles of exactly 4 elements per thread
+    const uint32_t want_tiles = (uint32_t)knobs().ntt_tiles;
+    const bool ept4 = !general && want_tiles >= 1 && A.log_skip == 0 && A.nnz == n &&
+                      (1ull << (A.log_r + A.log_c)) == 4ull * threads && grid % want_tiles == 0;
+    if (general) {
+        hipLaunchKernelGGL((k_ntt_pass<1, 0>), dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
+                           scale ? 1u : 0u, Q);
+    } else if (ept4) {
+        B.tiles_per_wg = want_tiles;
+        hipLaunchKernelGGL((k_ntt_pass<0, 4>), dim3((unsigned)(grid / want_tiles), grid_y), dim3(threads), lds, stream,
+                           B, s, scale ? 1u : 0u, Q);
+    } else {
+        hipLaunchKernelGGL((k_ntt_pass<0, 0>), dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
+                           scale ? 1u : 0u, Q);
+    }
     return hipGetLastError();
 }
 

@@ -1,21 +1,27 @@
 """sixstep.py — one NTT larger than a GPU, split across the ranks of a node (BASELINE config[4]).
 
-6-step (Bailey) decomposition n = N1 * N2, the generalisation of the reference's own Cooley-Tukey
-split in `parallel_fft` (/root/reference/src/fft/fft.rs:68-124: P sub-sequences, twiddle, sub-FFTs,
-un-shuffle) to distributed memory, with every transpose realised as an all-to-all (RCCL over xGMI
-when the process group is "nccl"; "gloo" in the CPU tests):
+4-step / 6-step (Bailey) decomposition n = N1 * N2, the generalisation of the reference's own
+Cooley-Tukey split in `parallel_fft` (/root/reference/src/fft/fft.rs:68-124: P sub-sequences, twiddle,
+sub-FFTs, un-shuffle) to distributed memory.  All arithmetic AND all local data movement happen inside
+the C ABI (include/hodor_gpu.h: hodor_sixstep_columns_dev / hodor_sixstep_rows_dev, with the transposes
+fused into the transform kernels' addressing); this module only sequences the calls and performs the
+exchange between them — ONE all-to-all of P contiguous slabs per transform (RCCL over xGMI when the
+process group is "nccl"; "gloo" in the CPU tests).  A Rust caller binds the same entry points and does
+the exchange with its own communicator.
 
-    x[n], n = n1*N2 + n2                rank r owns rows n1 in [r*N1/P, (r+1)*N1/P)   (natural blocks)
-    1. all-to-all        -> rank q owns columns n2 in block q, all n1
-    2. N2/P column NTTs of length N1 (omega^N2), times omega^(n2*k1)
-    3. all-to-all        -> rank q owns k1 in block q, all n2
-    4. N1/P row NTTs of length N2 (omega^N1)            -> X[k1 + N1*k2]
-    5. all-to-all        -> natural blocks of X: rank q owns k in [q*n/P, (q+1)*n/P)
+Per-rank layouts (row-major, x[n1*N2 + n2], r1 = N1/P, c2 = N2/P, rank q):
 
-Natural order in, natural order out, bit-identical to a single-device transform (exact arithmetic).
-The local arithmetic goes through a small backend interface so the same schedule runs on the HIP
-kernels (HipBackend: hodor_fft_batch_dev / hodor_twiddle_mul_dev) and, in the CPU tests, on the
-oracle.
+    A  a[n1][j] = x[n1*N2 + q*c2 + j]      N1 x c2     column block q of the N1 x N2 input matrix
+    B  b[i][k2] = X[(q*r1 + i) + N1*k2]    r1 x N2     row block q of the N1 x N2 output matrix
+
+    sixstep_forward   A -> columns -> all-to-all -> rows -> B          (1 exchange)
+    sixstep_inverse   B -> rows^-1 -> all-to-all -> columns^-1 -> A    (1 exchange, n^-1 folded in)
+    sixstep_ntt / sixstep_intt   natural blocks in, natural blocks out: the same with one more exchange
+                      and one copy (pack / transpose) on either side — 3 exchanges.  A prover that keeps
+                      A/B between transforms (LDE -> pointwise work -> iNTT) never pays those.
+
+The local steps go through a small backend interface so the same schedule runs on the HIP kernels
+(HipBackend) and, in the CPU tests, on the oracle.
 """
 import torch
 import torch.distributed as dist
@@ -27,14 +33,38 @@ class HipBackend:
     def __init__(self, ctx, stream=None):
         self.ctx, self.stream = ctx, stream
 
+    # ---- 4-step building blocks
+    def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False):
+        dst = torch.empty_like(src)
+        self.ctx.sixstep_columns_dev(src, dst, log_n1, log_n2, log_p, rank, omega, inverse, stream=self.stream)
+        return dst
+
+    def rows(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False):
+        dst = torch.empty_like(src)
+        self.ctx.sixstep_rows_dev(src, dst, log_n1, log_n2, log_p, rank, omega, inverse, stream=self.stream)
+        return dst
+
+    def pack(self, src, log_rows, log_cols, log_p):
+        if log_p == 0:
+            return src
+        dst = torch.empty_like(src)
+        self.ctx.sixstep_pack_dev(src, dst, log_rows, log_cols, log_p, stream=self.stream)
+        return dst
+
+    def transpose(self, src, rows, cols):
+        dst = torch.empty_like(src)
+        self.ctx.transpose_dev(src, dst, rows, cols, stream=self.stream)
+        return dst
+
+    def scale(self, buf, s):
+        self.ctx.poly_unary_dev(buf, buf.shape[0], "scale", c=s, stream=self.stream)
+        return buf
+
+    # ---- used by hodor_amd/distributed.py (LDE dealt by cosets)
     def batched_ntt(self, buf, batch, log_len, omega):
         out = torch.empty_like(buf)
         self.ctx.fft_batch_dev(buf, out, log_len, batch, omega, stream=self.stream)
         return out
-
-    def twiddle(self, buf, rows, cols, row0, omega, log_order, scale=None):
-        self.ctx.twiddle_mul_dev(buf, rows, cols, row0, omega, log_order, scale=scale, stream=self.stream)
-        return buf
 
     def distribute_powers(self, buf, g):
         self.ctx.distribute_powers_dev(buf, buf.shape[0], g, stream=self.stream)
@@ -53,59 +83,74 @@ class HipBackend:
         return self.ctx.from_repr(v)
 
 
-def _all_to_all_blocks(x, parts, group):
-    """x: (parts, m, 4) — slab q goes to rank q; returns (parts, m, 4) with slab s received from rank s."""
+def split_logs(log_n):
+    """n = N1 * N2 with N1 <= N2 (the choice every function of this module makes)."""
+    log_n1 = log_n // 2
+    return log_n1, log_n - log_n1
+
+
+def all_to_all_slabs(x, world, group=None):
+    """x: (m, 4) seen as `world` equal contiguous slabs; slab t goes to rank t.  Returns (m, 4) whose slab
+    s came from rank s.  Bytes on the wire per rank: (world - 1) / world * m * 32."""
+    if world == 1:
+        return x
     out = torch.empty_like(x)
-    if parts == 1:
-        out.copy_(x)
-    else:
-        dist.all_to_all_single(out, x.contiguous(), group=group)
+    dist.all_to_all_single(out, x, group=group)
     return out
 
 
+def _log_p(world):
+    log_p = world.bit_length() - 1
+    assert 1 << log_p == world, "power-of-two world size"
+    return log_p
+
+
+def sixstep_forward(backend, a, log_n, omega, rank, world, group=None):
+    """Layout A -> layout B, one exchange.  `omega`: Montgomery integer of a primitive n-th root."""
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = _log_p(world)
+    y = backend.columns(a, log_n1, log_n2, log_p, rank, omega, inverse=False)
+    y = all_to_all_slabs(y, world, group)
+    return backend.rows(y, log_n1, log_n2, log_p, rank, omega, inverse=False)
+
+
+def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None):
+    """Layout B -> layout A, one exchange; the inverse of sixstep_forward (same `omega`; n^-1 folded in)."""
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = _log_p(world)
+    y = backend.rows(b, log_n1, log_n2, log_p, rank, omega, inverse=True)
+    y = all_to_all_slabs(y, world, group)
+    return backend.columns(y, log_n1, log_n2, log_p, rank, omega, inverse=True)
+
+
+def natural_to_a(backend, x_local, log_n, rank, world, group=None):
+    """This rank's natural block (r1 rows of the N1 x N2 matrix) -> layout A: pack + one exchange."""
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = _log_p(world)
+    return all_to_all_slabs(backend.pack(x_local, log_n1 - log_p, log_n2, log_p), world, group)
+
+
+def b_to_natural(backend, b, log_n, rank, world, group=None):
+    """Layout B -> this rank's natural block of the output: pack + one exchange + a local transpose."""
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = _log_p(world)
+    y = all_to_all_slabs(backend.pack(b, log_n1 - log_p, log_n2, log_p), world, group)
+    return backend.transpose(y, 1 << log_n1, 1 << (log_n2 - log_p))      # [k1][k2_local] -> [k2_local][k1]
+
+
 def sixstep_ntt(backend, x_local, log_n, omega, rank, world, group=None, scale=None):
-    """Distributed natural->natural NTT.  `x_local`: this rank's natural block, shape (n/world, 4).
-    `omega`: Montgomery integer of a primitive n-th root (or its inverse).  `scale`: optional
-    Montgomery scalar multiplied into every output (n^-1 for the inverse transform).
-    Returns this rank's natural block of the transform."""
-    n = 1 << log_n
-    P = world
-    log_n1 = log_n // 2
-    log_n2 = log_n - log_n1
-    N1, N2 = 1 << log_n1, 1 << log_n2
-    assert N1 % P == 0 and N2 % P == 0, "world size must divide both factors"
-    r1, c2 = N1 // P, N2 // P                      # my rows n1 / my columns n2
-
-    # 1. (r1, N2) -> split columns into P slabs -> all-to-all -> (N1, c2) -> transpose to (c2, N1)
-    a = x_local.view(r1, P, c2, 4).permute(1, 0, 2, 3).contiguous()        # (P, r1, c2)
-    a = _all_to_all_blocks(a.view(P, r1 * c2, 4), P, group)                 # slab s = rows of rank s
-    a = a.view(N1, c2, 4).permute(1, 0, 2).contiguous().view(c2 * N1, 4)   # (c2, N1): column-major
-
-    # 2. column NTTs over n1 (length N1, root omega^N2), then * omega^(n2 * k1)
-    w1 = backend.pow(omega, N2)
-    a = backend.batched_ntt(a, c2, log_n1, w1)                              # Y[n2_local][k1]
-    a = backend.twiddle(a, c2, N1, rank * c2, omega, log_n)
-
-    # 3. (c2, N1) -> split k1 into P slabs -> all-to-all -> (N2, r1) -> transpose to (r1, N2)
-    a = a.view(c2, P, r1, 4).permute(1, 0, 2, 3).contiguous()               # (P, c2, r1)
-    a = _all_to_all_blocks(a.view(P, c2 * r1, 4), P, group)                 # slab s = n2 block of rank s
-    a = a.view(N2, r1, 4).permute(1, 0, 2).contiguous().view(r1 * N2, 4)    # (r1 = my k1, N2)
-
-    # 4. row NTTs over n2 (length N2, root omega^N1): Z[k1_local][k2] = X[k1 + N1*k2]
-    w2 = backend.pow(omega, N1)
-    a = backend.batched_ntt(a, r1, log_n2, w2)
+    """Distributed natural->natural NTT (3 exchanges).  `x_local`: this rank's natural block, shape
+    (n/world, 4).  `scale`: optional Montgomery scalar multiplied into every output."""
+    a = natural_to_a(backend, x_local, log_n, rank, world, group)
+    b = sixstep_forward(backend, a, log_n, omega, rank, world, group)
     if scale is not None:
-        a = backend.twiddle(a, r1, N2, 0, backend.from_u64(1), 0, scale=scale)
-
-    # 5. natural blocks: rank q owns k2 in block q (all k1): (r1, N2) -> slabs over k2 -> all-to-all
-    a = a.view(r1, P, c2, 4).permute(1, 0, 2, 3).contiguous()               # (P, r1, c2)
-    a = _all_to_all_blocks(a.view(P, r1 * c2, 4), P, group)                 # slab s = k1 block of rank s
-    a = a.view(N1, c2, 4).permute(1, 0, 2).contiguous().view(c2 * N1, 4)    # [k2_local][k1] = natural
-    return a
+        b = backend.scale(b, scale)
+    return b_to_natural(backend, b, log_n, rank, world, group)
 
 
 def sixstep_intt(backend, x_local, log_n, omega, rank, world, group=None):
-    """Inverse transform: omega^-1 and the n^-1 scale (Polynomial::ifft, src/polynomials/mod.rs:773-798)."""
+    """Inverse natural->natural transform: omega^-1 and the n^-1 scale (Polynomial::ifft,
+    src/polynomials/mod.rs:773-798)."""
     winv = backend.inverse(omega)
     ninv = backend.inverse(backend.from_u64(1 << log_n))
     return sixstep_ntt(backend, x_local, log_n, winv, rank, world, group, scale=ninv)

@@ -61,7 +61,7 @@ int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
 /* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
- * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS,
+ * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TILES,
  * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ.
  * They are read once per process, change schedules only (never results), and a benchmark must echo
  * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
@@ -218,6 +218,35 @@ int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, si
 /* evaluate_at: *out (host) = sum coeffs[i] g^i.  Synchronises the stream. */
 int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream, const hodor_fr *coeffs, size_t n, const hodor_fr *g,
                                hodor_fr *out);
+/* ---- one transform split over the P = 2^log_p GPUs of a node: 4-step / 6-step building blocks --------
+ * n = N1 * N2 (N1 = 2^log_n1, N2 = 2^log_n2, P | N1, P | N2), x[n1*N2 + n2], r1 = N1/P, c2 = N2/P.  The
+ * library does each rank's local arithmetic with the layout changes fused into the transform kernels'
+ * addressing; the CALLER owns the communicator and runs ONE all-to-all of P equal contiguous slabs
+ * (r1*c2 elements each; slab t of the send buffer goes to rank t, slab s of the receive buffer came from
+ * rank s) between the two calls.  Generalises the reference's Cooley-Tukey split in parallel_fft
+ * (src/fft/fft.rs:68-124) to distributed memory.  Per-rank layouts (row-major), rank q:
+ *     A: a[n1][j] = x[n1*N2 + q*c2 + j]        N1 x c2   (column block q of the N1 x N2 input matrix)
+ *     B: b[i][k2] = X[(q*r1 + i) + N1*k2]      r1 x N2   (row block q of the N1 x N2 output matrix)
+ *   forward (omega = primitive n-th root):   A -> hodor_sixstep_columns_dev(inverse = 0) -> all-to-all
+ *                                              -> hodor_sixstep_rows_dev(inverse = 0) -> B
+ *   inverse (same omega; the library inverts it and folds n^-1 in):
+ *                                            B -> hodor_sixstep_rows_dev(inverse = 1) -> all-to-all
+ *                                              -> hodor_sixstep_columns_dev(inverse = 1) -> A
+ * src != dst; every buffer holds n/P elements.  With P = 1 the pair is a complete transform whose output
+ * is the N1 x N2 matrix X[k1 + N1*k2] (hodor_transpose_dev gives natural order). */
+int hodor_sixstep_columns_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n1,
+                              uint32_t log_n2, uint32_t log_p, uint32_t rank, const hodor_fr *omega, int inverse);
+int hodor_sixstep_rows_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n1,
+                           uint32_t log_n2, uint32_t log_p, uint32_t rank, const hodor_fr *omega, int inverse);
+/* Natural block order on either side costs one more all-to-all each, fed by these two copies:
+ * pack: a 2^log_rows x 2^log_cols row-major block cut into the P slabs of an all-to-all,
+ *       dst[(t*rows + i)*c + j] = src[i*cols + t*c + j], c = cols / P
+ *       (natural block [r1][N2] -> pack -> all-to-all = layout A;  layout B -> pack -> all-to-all ->
+ *        hodor_transpose_dev(rows = N1, cols = c2) = natural block of the output);
+ * transpose: dst[c*rows + r] = src[r*cols + c]. */
+int hodor_sixstep_pack_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_rows,
+                           uint32_t log_cols, uint32_t log_p);
+int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, size_t rows, size_t cols);
 /* Synthetic input for tests and benchmarks: dst[r] = element first_index + r of the
  * index-addressable SplitMix64 stream `seed` — uniform canonical residues (rejection-sampled < p)
  * in Montgomery form, i.e. what the reference's tests draw with Fr::rand (src/fft/mod.rs:71-77), but

@@ -1,0 +1,159 @@
+"""GPU parity of the 4-step / 6-step building blocks (include/hodor_gpu.h: hodor_sixstep_columns_dev,
+hodor_sixstep_rows_dev, hodor_sixstep_pack_dev, hodor_transpose_dev) — the local steps of ONE transform
+split over P ranks, with the transposes fused into the transform kernels' addressing.
+
+The box has one GPU, so the P ranks are played one after the other on it and the all-to-all is done by
+hand (slab s of rank t's receive buffer = slab t of rank s's send buffer); every intermediate buffer is
+compared with the CPU restatement (tests/sixstep_ref.py), the final result with the single-device
+transform, and at 2^24 with the CPU oracle's committed digest.  A real RCCL exchange is exercised when
+more than one device is visible."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FULL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_digests.json")))
+
+
+def _dev(arr):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).cuda()
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _exchange(bufs, world):
+    """all_to_all_single by hand over a list of per-rank send buffers."""
+    import torch
+    m = bufs[0].shape[0] // world
+    return [torch.cat([bufs[s][t * m:(t + 1) * m] for s in range(world)]) for t in range(world)]
+
+
+@pytest.mark.parametrize("world,log_n", [(1, 4), (1, 9), (1, 14), (2, 6), (2, 11), (4, 8), (4, 13), (8, 12)])
+def test_forward_and_inverse_steps_match_restatement(gpu_ctxs, oracles, field_name, world, log_n):
+    from hodor_amd.sixstep import HipBackend, split_logs
+    from sixstep_ref import OracleBackend, layout_a, layout_b
+    if field_name != "bn256" and log_n > 9:
+        pytest.skip("large cases on the bn256.rs field only")
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    ref = OracleBackend()
+    ref.O = O
+    hip = HipBackend(ctx)
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = world.bit_length() - 1
+    n = 1 << log_n
+    full = O.random_elements(n, 60 + log_n)
+    _, k, w = O.domain(n)
+    spec = full.copy()
+    O.serial_fft(spec, w, k)
+    import torch
+    # forward: A -> columns -> exchange -> rows -> B
+    a = [layout_a(full, log_n, r, world) for r in range(world)]
+    cols = [hip.columns(_dev(a[r]), log_n1, log_n2, log_p, r, w) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        exp = ref.columns(torch.from_numpy(a[r].view(np.int64)), log_n1, log_n2, log_p, r, w)
+        assert np.array_equal(_host(cols[r]), exp.numpy().view(np.uint64)), ("columns", r)
+    recv = _exchange(cols, world)
+    b = [hip.rows(recv[r], log_n1, log_n2, log_p, r, w) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        assert np.array_equal(_host(b[r]), layout_b(spec, log_n, r, world)), ("rows", r)
+    # inverse: B -> rows^-1 -> exchange -> columns^-1 -> A
+    back = [hip.rows(b[r], log_n1, log_n2, log_p, r, w, inverse=True) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        exp = ref.rows(torch.from_numpy(layout_b(spec, log_n, r, world).view(np.int64)), log_n1, log_n2, log_p, r, w,
+                       inverse=True)
+        assert np.array_equal(_host(back[r]), exp.numpy().view(np.uint64)), ("rows^-1", r)
+    recv = _exchange(back, world)
+    a2 = [hip.columns(recv[r], log_n1, log_n2, log_p, r, w, inverse=True) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        assert np.array_equal(_host(a2[r]), a[r]), ("columns^-1", r)
+
+
+@pytest.mark.parametrize("world,log_n", [(1, 10), (2, 9), (4, 12)])
+def test_natural_order_path_pack_and_transpose(gpu_ctxs, oracles, world, log_n):
+    """natural block -> pack -> exchange -> A ... B -> pack -> exchange -> transpose -> natural block."""
+    from hodor_amd.sixstep import HipBackend, split_logs
+    from sixstep_ref import layout_a, layout_b
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    hip = HipBackend(ctx)
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = world.bit_length() - 1
+    n = 1 << log_n
+    blk = n // world
+    full = O.random_elements(n, 7)
+    _, k, w = O.domain(n)
+    spec = full.copy()
+    O.serial_fft(spec, w, k)
+    packed = [hip.pack(_dev(full[r * blk:(r + 1) * blk]), log_n1 - log_p, log_n2, log_p) for r in range(world)]
+    a = _exchange(packed, world)
+    ctx.synchronize()
+    for r in range(world):
+        assert np.array_equal(_host(a[r]), layout_a(full, log_n, r, world)), r
+    packed = [hip.pack(_dev(layout_b(spec, log_n, r, world)), log_n1 - log_p, log_n2, log_p) for r in range(world)]
+    y = _exchange(packed, world)
+    out = [hip.transpose(y[r], 1 << log_n1, 1 << (log_n2 - log_p)) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        assert np.array_equal(_host(out[r]), spec[r * blk:(r + 1) * blk]), r
+
+
+def test_transpose_ragged_shapes(gpu_ctxs, oracles):
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    for rows, cols in ((1, 1), (1, 37), (16, 16), (17, 33), (250, 3), (1024, 64)):
+        a = O.random_elements(rows * cols, rows)
+        d = torch.empty((rows * cols, 4), dtype=torch.int64, device="cuda")
+        ctx.transpose_dev(_dev(a), d, rows, cols)
+        ctx.synchronize()
+        exp = np.ascontiguousarray(a.reshape(rows, cols, 4).transpose(1, 0, 2)).reshape(-1, 4)
+        assert np.array_equal(_host(d), exp), (rows, cols)
+
+
+def test_sixstep_world1_2_24_equals_cpu_oracle_digest(gpu_ctxs):
+    """BASELINE config[1]'s input through the 4-step path on one rank: the B layout transposed back is
+    the natural-order transform, every element (digest) equal to the CPU oracle's."""
+    import torch
+    from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse, split_logs
+    ctx, e = gpu_ctxs["bn256"], FULL["ntt"]["24"]
+    log_n = 24
+    n = 1 << log_n
+    a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a, 0, n, e["seed"])
+    w = ctx.domain(n)[2]
+    hip = HipBackend(ctx)
+    b = sixstep_forward(hip, a, log_n, w, 0, 1)
+    log_n1, log_n2 = split_logs(log_n)
+    nat = hip.transpose(b, 1 << log_n1, 1 << log_n2)
+    ctx.synchronize()
+    got = hashlib.blake2s(memoryview(nat.cpu().numpy()).cast("B"), digest_size=32).hexdigest()
+    assert got == e["fft"]
+    back = sixstep_inverse(hip, b, log_n, w, 0, 1)
+    ctx.synchronize()
+    assert torch.equal(back, a)
+
+
+def test_rccl_exchange_when_two_devices_are_visible():
+    """world = 2 over RCCL (one process per GPU); skipped on the single-GPU test box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "20", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["checks"]["roundtrip"] is True

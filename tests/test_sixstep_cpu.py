@@ -1,6 +1,7 @@
-"""world_size-2 (and 4) gloo test of the distributed 6-step NTT schedule (hodor_amd/sixstep.py): the
-all-to-all transposes and index maps run for real on CPU tensors; the local column/row transforms go
-through the CPU oracle instead of the HIP kernels.  Result must equal the single-device transform."""
+"""world_size-2 (and 4) gloo test of the distributed 4-step / 6-step NTT schedule (hodor_amd/sixstep.py):
+the all-to-all exchanges run for real on CPU tensors; the local steps (what the C ABI's
+hodor_sixstep_*_dev entry points compute on the GPU) are restated here with numpy index maps + the CPU
+oracle.  Results must equal the single-device transform, in natural order and in the A / B layouts."""
 import os
 import socket
 
@@ -13,58 +14,7 @@ import torch.multiprocessing as mp
 from oracle import pyref as P
 
 
-class OracleBackend:
-    def __init__(self):
-        from oracle.oracle import Oracle
-        self.O = Oracle(P.BN256.p, P.BN256.g)
-
-    def _np(self, t):
-        return t.numpy().view(np.uint64)
-
-    def batched_ntt(self, buf, batch, log_len, omega):
-        out = buf.clone()
-        arr = self._np(out)
-        L = 1 << log_len
-        for b in range(batch):
-            row = np.ascontiguousarray(arr[b * L:(b + 1) * L])
-            self.O.serial_fft(row, omega, log_len)
-            arr[b * L:(b + 1) * L] = row
-        return out
-
-    def twiddle(self, buf, rows, cols, row0, omega, log_order, scale=None):
-        from oracle.oracle import array_to_ints, ints_to_array
-        arr = self._np(buf)
-        vals = array_to_ints(arr)
-        mask = (1 << log_order) - 1
-        for r in range(rows):
-            for c in range(cols):
-                v = vals[r * cols + c]
-                e = ((row0 + r) * c) & mask
-                if e:
-                    v = self.O.mul(v, self.O.pow(omega, e))
-                if scale is not None:
-                    v = self.O.mul(v, scale)
-                vals[r * cols + c] = v
-        arr[:] = ints_to_array(vals)
-        return buf
-
-    def distribute_powers(self, buf, g):
-        arr = np.ascontiguousarray(self._np(buf))
-        self.O.distribute_powers(arr, g)
-        self._np(buf)[:] = arr
-        return buf
-
-    def pow(self, a, e):
-        return self.O.pow(a, e)
-
-    def mul(self, a, b):
-        return self.O.mul(a, b)
-
-    def inverse(self, a):
-        return self.O.inverse(a)
-
-    def from_u64(self, v):
-        return self.O.from_canonical(v)
+from sixstep_ref import OracleBackend, layout_a, layout_b  # noqa: E402,F401
 
 
 def _worker(rank, world, port, log_n, ret):
@@ -86,7 +36,14 @@ def _worker(rank, world, port, log_n, ret):
         ok_fwd = np.array_equal(out.numpy().view(np.uint64), exp[rank * blk:(rank + 1) * blk])
         back = sixstep_intt(be, out, log_n, omega, rank, world)
         ok_inv = np.array_equal(back.numpy().view(np.uint64), full[rank * blk:(rank + 1) * blk])
-        ret[rank] = (ok_fwd, ok_inv)
+        # the one-exchange forms on the A / B layouts
+        from hodor_amd.sixstep import sixstep_forward, sixstep_inverse
+        a = torch.from_numpy(layout_a(full, log_n, rank, world).view(np.int64))
+        b = sixstep_forward(be, a, log_n, omega, rank, world)
+        ok_b = np.array_equal(b.numpy().view(np.uint64), layout_b(exp, log_n, rank, world))
+        a2 = sixstep_inverse(be, b, log_n, omega, rank, world)
+        ok_a = np.array_equal(a2.numpy().view(np.uint64), a.numpy().view(np.uint64))
+        ret[rank] = (ok_fwd, ok_inv, ok_b, ok_a)
     finally:
         dist.destroy_process_group()
 
@@ -106,7 +63,7 @@ def test_sixstep_matches_single_device_transform(world, log_n):
     mp.spawn(_worker, args=(world, _free_port(), log_n, ret), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
-        assert ret[r] == (True, True), (r, ret[r])
+        assert ret[r] == (True, True, True, True), (r, ret[r])
 
 
 # ---------------------------------------------------------------- distributed LDE + Merkle commit
