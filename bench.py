@@ -44,7 +44,7 @@ WARM_MS = 150.0           # clocks settle after ~100 ms of load: warm up by time
 # regenerates the same SplitMix64 inputs on the device and refuses to print a number unless its
 # outputs hash to them.
 FIXTURES = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
-KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TILES",
+KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_MIN_LOG_C", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TW_SUB",
              "HODOR_MERKLE_TAIL_LOG", "HODOR_MERKLE_LAT_LOG", "HODOR_FRI_TAIL", "HODOR_FRI_FUSE_FOLD",
              "HODOR_BATCHINV_SEQ", "HODOR_DBG", "HODOR_LIB")
 
@@ -89,6 +89,9 @@ def main():
                     help="N > 1 (default 'sixstep'): ONE transform of 2^log_n * N points split over the ranks, "
                          "transposes as RCCL all-to-alls (hodor_amd/sixstep.py, BASELINE config[4] shape); "
                          "'replicas' = one independent 2^log_n polynomial per GPU, no data-path collective")
+    ap.add_argument("--exchange-chunks", type=int, default=None,
+                    help="sixstep: cut each all-to-all into this many pieces so that piece k is on the wire while "
+                         "piece k+1 is being computed (power of two; default 4 when N > 1, 1 otherwise)")
     ap.add_argument("--allow-knobs", action="store_true",
                     help="run although HODOR_* tuning variables are set (they are echoed in the JSON line)")
     ap.add_argument("--skip-checks", action="store_true",
@@ -165,10 +168,13 @@ def main():
         omega = ctx.domain(1 << log_total)[2]
         be = HipBackend(ctx, stream=stream)
         holder = {}
+        chunks = args.exchange_chunks or (4 if world > 1 else 1)
+        log_chunks = chunks.bit_length() - 1
+        assert 1 << log_chunks == chunks, "--exchange-chunks must be a power of two"
 
         def step():
-            holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world)
-            holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world)
+            holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
+            holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=log_chunks)
     else:
         def step():
             ctx.poly_fft_dev(a, b, log_n, stream=stream)
@@ -236,8 +242,9 @@ def main():
         torch.cuda.synchronize()
         sent = n * 32 * (world - 1) / world
         ms = e0.elapsed_time(e1) / reps
-        exchange = {"all_to_alls_per_transform": 1, "bytes_sent_per_rank_per_transform": sent,
-                    "all_to_all_ms": ms, "gb_per_s_per_rank": (sent / (ms * 1e-3) / 1e9) if world > 1 else None,
+        exchange = {"all_to_alls_per_transform": 1, "chunks_per_all_to_all": chunks,
+                    "bytes_sent_per_rank_per_transform": sent,
+                    "all_to_all_ms_unoverlapped": ms, "gb_per_s_per_rank": (sent / (ms * 1e-3) / 1e9) if world > 1 else None,
                     "share_of_step": 2 * ms / (dt / args.steps * 1e3) if world > 1 else 0.0}
 
     elems = 2.0 * n * args.steps * world       # forward + inverse

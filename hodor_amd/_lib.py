@@ -508,17 +508,21 @@ class Context:
         self._chk(self.L.hodor_poly_unary_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n), C.c_int(code),
                                               C.byref(cc) if cc is not None else None, C.c_uint64(e)))
 
-    def sixstep_columns_dev(self, src, dst, log_n1, log_n2, log_p, rank, omega, inverse=False, stream=None):
+    def sixstep_columns_dev(self, src, dst, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0,
+                            chunk=0, stream=None):
         w = _fr(omega)
         self._chk(self.L.hodor_sixstep_columns_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
                                                    C.c_uint32(log_n1), C.c_uint32(log_n2), C.c_uint32(log_p),
-                                                   C.c_uint32(rank), C.byref(w), C.c_int(1 if inverse else 0)))
+                                                   C.c_uint32(rank), C.byref(w), C.c_int(1 if inverse else 0),
+                                                   C.c_uint32(log_chunks), C.c_uint32(chunk)))
 
-    def sixstep_rows_dev(self, src, dst, log_n1, log_n2, log_p, rank, omega, inverse=False, stream=None):
+    def sixstep_rows_dev(self, src, dst, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0,
+                         chunk=0, stream=None):
         w = _fr(omega)
         self._chk(self.L.hodor_sixstep_rows_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
                                                 C.c_uint32(log_n1), C.c_uint32(log_n2), C.c_uint32(log_p),
-                                                C.c_uint32(rank), C.byref(w), C.c_int(1 if inverse else 0)))
+                                                C.c_uint32(rank), C.byref(w), C.c_int(1 if inverse else 0),
+                                                C.c_uint32(log_chunks), C.c_uint32(chunk)))
 
     def sixstep_pack_dev(self, src, dst, log_rows, log_cols, log_p, stream=None):
         self._chk(self.L.hodor_sixstep_pack_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),

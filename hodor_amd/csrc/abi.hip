@@ -296,12 +296,21 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         A.nnz = (i == 0) ? nnz : (1ull << log_n);
         A.log_n = log_n;
         A.log_r = log_r;
+        // tile = 2^tile_log elements, but never fewer than 2^min_log_c columns: a radix-512 pass gets a
+        // 2048-element tile (128-byte runs in HBM) rather than 1024 elements in 64-byte runs
         uint32_t log_c = ctx->tile_log > log_r ? ctx->tile_log - log_r : 0;
+        if (log_c < ctx->min_log_c && log_r + ctx->min_log_c <= 12) log_c = ctx->min_log_c;
         if (lay && lay->col_mode) {
             if (log_c > lay->log_width) log_c = lay->log_width;     // the tile's columns are array columns
             A.col_mode = 1;
             A.log_width = lay->log_width;
             A.col0 = lay->col0;
+            // a pass reads what the previous one wrote (compact, log_width); only the first pass's source
+            // and the last pass's destination may be the caller's wider arrays
+            A.src_log_width = (i == 0 && lay->src_log_width) ? lay->src_log_width : lay->log_width;
+            A.src_col_off = (i == 0) ? lay->src_col_off : 0;
+            A.dst_log_width = (i + 1 == passes && lay->dst_log_width) ? lay->dst_log_width : lay->log_width;
+            A.dst_col_off = (i + 1 == passes) ? lay->dst_col_off : 0;
             if (tw2d_t.lo && ((lay->tw2d_on_load && i == 0) || (!lay->tw2d_on_load && i + 1 == passes))) {
                 A.tw2d = tw2d_t;
                 A.tw2d_on_load = lay->tw2d_on_load ? 1 : 0;
@@ -423,6 +432,7 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
         ctx->max_log_r = (uint32_t)k.max_log_r;
         ctx->tw_hi_max_log = (uint32_t)k.tw_hi_max_log;
         ctx->tile_log = (uint32_t)k.tile_log;
+        ctx->min_log_c = (uint32_t)k.min_log_c;
         if (ctx->max_log_r > ctx->tile_log) ctx->max_log_r = ctx->tile_log;
     }
     *out = ctx;

@@ -220,13 +220,14 @@ static Knobs read_knobs()
     };
     k.max_log_r = get("HODOR_MAX_LOG_R", 9, 2, 11);
     k.tile_log = get("HODOR_TILE_LOG", 10, 6, 12);
+    k.min_log_c = get("HODOR_MIN_LOG_C", 2, 0, 4);
     k.tw_hi_max_log = get("HODOR_TW_HI_MAX_LOG", 17, 0, 20);
     k.ntt_threads = get("HODOR_NTT_THREADS", 0, 0, 1024);
-    k.ntt_tiles = get("HODOR_NTT_TILES", 4, 0, 64);
+    k.ntt_tw_sub = get("HODOR_NTT_TW_SUB", 1, 0, 1);
     k.merkle_tail_log = get("HODOR_MERKLE_TAIL_LOG", 6, 0, 30);
     k.merkle_lat_log = get("HODOR_MERKLE_LAT_LOG", 19, 0, 40);
     k.fri_tail = get("HODOR_FRI_TAIL", 1, 0, 1);
-    k.fri_fuse_fold = get("HODOR_FRI_FUSE_FOLD", 1, 0, 1);
+    k.fri_fuse_fold = get("HODOR_FRI_FUSE_FOLD", 1, 0, 2);
     k.batchinv_seq = get("HODOR_BATCHINV_SEQ", 8, 2, 64);
     return k;
 }

@@ -19,7 +19,9 @@
 //   inverse  B -> A:  rows^-1 (output written slab by slab: split addressing, no pack copy)
 //                     -> all-to-all -> columns^-1 (times w^-(k1*n2) on load, n^-1 folded in)
 //
-// One exchange per transform.  Natural block order on either side costs one more exchange each plus
+// One exchange per transform, optionally cut into K chunks so that chunk k's all-to-all overlaps the
+// arithmetic of chunk k+1 (forward: the columns are transformed K groups at a time; inverse: the rows).
+// Natural block order on either side costs one more exchange each plus
 // hodor_sixstep_pack_dev / hodor_transpose_dev (a caller that keeps A/B between transforms — NTT,
 // pointwise work, iNTT — never pays them).
 #include "ctx.hpp"
@@ -80,30 +82,44 @@ static int sixstep_check(hodor_ctx *ctx, uint32_t log_n1, uint32_t log_n2, uint3
     return HODOR_OK;
 }
 
-// the slabs of an all-to-all as one axis: element x = s*c2 + j of batch member i at s*(r1*c2) + i*c2 + j
-static SplitAddr slab_axis(uint32_t log_r1, uint32_t log_c2, uint32_t log_p)
+// An axis that arrives (or leaves) cut into K chunks x P slabs: element x = s*c + k*cw + j (c = K*cw per
+// slab) of batch member i lives at  k*(P*b*cw) + s*(b*cw) + i*cw + j,  b = batch members per chunk buffer.
+static SplitAddr chunked_slab_axis(uint32_t log_b, uint32_t log_c, uint32_t log_p, uint32_t log_k)
 {
     SplitAddr S = {};
-    if (log_p == 0) return S;     // one slab: plain rows
+    if (log_p == 0 && log_k == 0) return S;     // one slab, one chunk: plain rows
+    const uint32_t log_cw = log_c - log_k;
     S.on = 1;
-    S.lo_log = log_c2;
-    S.hi_log = log_c2;
-    S.mid_mask = 0;
-    S.stride_mid = 0;
-    S.stride_hi = 1ull << (log_r1 + log_c2);
-    S.batch_stride = 1ull << log_c2;
+    S.lo_log = log_cw;
+    S.mid_mask = (1u << log_k) - 1;
+    S.stride_mid = 1ull << (log_p + log_b + log_cw);
+    S.hi_log = log_c;
+    S.stride_hi = 1ull << (log_b + log_cw);
+    S.batch_stride = 1ull << log_cw;
     return S;
+}
+
+static int chunk_check(hodor_ctx *ctx, uint32_t log_avail, uint32_t log_chunks, uint32_t chunk)
+{
+    if (log_chunks > log_avail || chunk >= (1u << log_chunks)) {
+        set_err(ctx, "sixstep: chunk index / count out of range");
+        return HODOR_ERR_SIZE;
+    }
+    return HODOR_OK;
 }
 
 extern "C" int hodor_sixstep_columns_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                                          uint32_t log_n1, uint32_t log_n2, uint32_t log_p, uint32_t rank,
-                                         const hodor_fr *omega, int inverse)
+                                         const hodor_fr *omega, int inverse, uint32_t log_chunks, uint32_t chunk)
 {
     NEED_DEVICE();
     if (!src || !dst || !omega || src == dst) return HODOR_ERR_INVALID;
     int rc = sixstep_check(ctx, log_n1, log_n2, log_p, rank);
     if (rc) return rc;
-    const uint32_t log_c2 = log_n2 - log_p, log_n = log_n1 + log_n2;
+    const uint32_t log_r1 = log_n1 - log_p, log_c2 = log_n2 - log_p, log_n = log_n1 + log_n2;
+    // forward: the chunks cut the columns (this call transforms chunk `chunk`); inverse: they cut the rows
+    // of the buffers this call gathers from (all of them at once)
+    if ((rc = chunk_check(ctx, inverse ? log_r1 : log_c2, log_chunks, inverse ? 0 : chunk))) return rc;
     HFr w = to_h(omega);
     if (inverse && !ctx->F.inverse(w, &w)) return HODOR_ERR_INVALID;
     HFr w1 = ctx->F.pow(w, 1ull << log_n2);                 // primitive N1-th root
@@ -111,34 +127,61 @@ extern "C" int hodor_sixstep_columns_dev(hodor_ctx *ctx, void *stream, const hod
     if (inverse) ctx->F.inverse(ctx->F.from_u64(1ull << log_n), &ninv);
     NttLayout L;
     L.col_mode = true;
-    L.log_width = log_c2;
-    L.col0 = (uint64_t)rank << log_c2;
     L.tw2d_root = &w;
     L.tw2d_log_order = log_n;
     L.tw2d_on_load = inverse != 0;
+    if (!inverse) {
+        const uint32_t log_cw = log_c2 - log_chunks;
+        L.log_width = log_cw;                               // compact [N1][cw] out: its P slabs are contiguous
+        L.src_log_width = log_c2;
+        L.src_col_off = (uint64_t)chunk << log_cw;
+        L.col0 = ((uint64_t)rank << log_c2) + ((uint64_t)chunk << log_cw);
+    } else {
+        L.log_width = log_c2;
+        L.col0 = (uint64_t)rank << log_c2;
+        if (log_chunks) {   // row k1 = s*r1 + b*rb + i sits in chunk buffer b, slab s, row i: [K][P][rb][c2]
+            const uint32_t log_rb = log_r1 - log_chunks;
+            SplitAddr S = {};
+            S.on = 1;
+            S.lo_log = log_rb;
+            S.mid_mask = (1u << log_chunks) - 1;
+            S.stride_mid = 1ull << (log_p + log_rb);
+            S.hi_log = log_r1;
+            S.stride_hi = 1ull << log_rb;
+            S.batch_stride = 0;
+            L.src_split = S;
+        }
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n1, w1, 1ull << log_n1,
-                    inverse ? &ninv : nullptr, nullptr, nullptr, 1u << log_c2, &L);
+                    inverse ? &ninv : nullptr, nullptr, nullptr, 1u << L.log_width, &L);
 }
 
 extern "C" int hodor_sixstep_rows_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                                       uint32_t log_n1, uint32_t log_n2, uint32_t log_p, uint32_t rank,
-                                      const hodor_fr *omega, int inverse)
+                                      const hodor_fr *omega, int inverse, uint32_t log_chunks, uint32_t chunk)
 {
     NEED_DEVICE();
     if (!src || !dst || !omega || src == dst) return HODOR_ERR_INVALID;
     int rc = sixstep_check(ctx, log_n1, log_n2, log_p, rank);
     if (rc) return rc;
     const uint32_t log_r1 = log_n1 - log_p, log_c2 = log_n2 - log_p;
+    if ((rc = chunk_check(ctx, inverse ? log_r1 : log_c2, log_chunks, inverse ? chunk : 0))) return rc;
     HFr w = to_h(omega);
     if (inverse && !ctx->F.inverse(w, &w)) return HODOR_ERR_INVALID;
     HFr w2 = ctx->F.pow(w, 1ull << log_n1);                 // primitive N2-th root
     NttLayout L;
-    if (inverse) L.dst_split = slab_axis(log_r1, log_c2, log_p);
-    else L.src_split = slab_axis(log_r1, log_c2, log_p);
+    uint32_t log_rows = log_r1;
+    if (!inverse) {
+        L.src_split = chunked_slab_axis(log_r1, log_c2, log_p, log_chunks);   // gathers all K chunk buffers
+    } else {
+        log_rows = log_r1 - log_chunks;                     // this call: rows chunk*rb .. of B
+        src += ((size_t)chunk << log_rows) << log_n2;
+        L.dst_split = chunked_slab_axis(log_rows, log_c2, log_p, 0);
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n2, w2, 1ull << log_n2,
-                    nullptr, nullptr, nullptr, 1u << log_r1, &L);
+                    nullptr, nullptr, nullptr, 1u << log_rows, &L);
 }
 
 extern "C" int hodor_sixstep_pack_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,

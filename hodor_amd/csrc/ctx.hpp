@@ -139,6 +139,7 @@ struct hodor_ctx {
     size_t fri_slab_bytes = 0;
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
     uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
+    uint32_t min_log_c = 2;    // fewest tile columns per pass (2^2 x 32 B = 128-byte runs)
     uint32_t tw_hi_max_log = 17;   // largest `hi` half (log2 entries) for which the second pass gets a hi-only
                                    // twiddle split (one product instead of two, for a table that outgrows L2)
     std::string err;           // written through set_err() only (entry points run concurrently)
@@ -217,7 +218,9 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
 int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes);
 struct NttLayout {
     bool col_mode = false;           // transform along the slow axis of a [2^log_n][2^log_width] array
-    uint32_t log_width = 0;
+    uint32_t log_width = 0;          // columns transformed (and the width of the intermediate arrays)
+    uint32_t src_log_width = 0, dst_log_width = 0;   // 0: same as log_width; else the caller's wider array ...
+    uint64_t src_col_off = 0, dst_col_off = 0;       // ... and the array column of tile column 0 in it
     uint64_t col0 = 0;               // global index of array column 0
     const HFr *tw2d_root = nullptr;  // 2D twiddle root^(index * (col0 + col)) ...
     uint32_t tw2d_log_order = 0;     // ... of order 2^tw2d_log_order, on the first pass's inputs (true) or the

@@ -8,13 +8,14 @@ namespace hodor {
 struct Knobs {
     int max_log_r;        // HODOR_MAX_LOG_R       largest per-pass NTT radix (log2)                     9
     int tile_log;         // HODOR_TILE_LOG        elements per NTT workgroup tile (log2)               10
+    int min_log_c;        // HODOR_MIN_LOG_C       fewest tile columns of an NTT pass (log2)                2
     int tw_hi_max_log;    // HODOR_TW_HI_MAX_LOG   largest hi-only twiddle split (log2 entries)         17
     int ntt_threads;      // HODOR_NTT_THREADS     workgroup size override of k_ntt_pass (0 = auto)      0
-    int ntt_tiles;        // HODOR_NTT_TILES       tiles per workgroup on the prefetching pass (0 = off)   4
+    int ntt_tw_sub;       // HODOR_NTT_TW_SUB      sub-sampled LDS twiddle table (last step from L2)      1
     int merkle_tail_log;  // HODOR_MERKLE_TAIL_LOG level width at which a throughput chunk stops         6
     int merkle_lat_log;   // HODOR_MERKLE_LAT_LOG  largest level on the latency schedule                19
     int fri_tail;         // HODOR_FRI_TAIL        fused tail of the FRI commit                          1
-    int fri_fuse_fold;    // HODOR_FRI_FUSE_FOLD   fold inside the tree's leaf launch                    1
+    int fri_fuse_fold;    // HODOR_FRI_FUSE_FOLD   fold inside the tree's leaf launch: 0 never, 1 always, 2 small rounds only   1
     int batchinv_seq;     // HODOR_BATCHINV_SEQ    elements per lane and level in batch inversion        8
     char set[256];        // "NAME=value ..." of the variables that were present in the environment
 };

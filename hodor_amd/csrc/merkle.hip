@@ -48,7 +48,7 @@ namespace hodor {
 constexpr uint32_t MERKLE_LOG_CH = HODOR_MERKLE_LOG_CH;   // throughput: 1024 inputs per workgroup, 16 KiB + 8 KiB of LDS (6 workgroups per CU)
 constexpr uint32_t MERKLE_LAT_LOG_CH = 8;    // latency: 256 inputs per workgroup
 
-// FOLD (latency schedule, leaf launch only): the leaves do not exist yet — leaf i is the FRI fold of the
+// FOLD (leaf launch only, either schedule): the leaves do not exist yet — leaf i is the FRI fold of the
 // previous round's values (fri_fold_one), computed here, stored to `fold.dst` and hashed from registers,
 // which saves the separate fold launch and its round trip through memory.
 template <bool LEAF, bool LAT, bool FOLD = false>
@@ -97,8 +97,22 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
         // level 1: pairs of inputs
         uint4 *lvl_out = nodes + 2 * ((m >> 1) + chunk * (ch >> 1));
         for (uint32_t p = tid; p < (ch >> 1); p += nthreads) {
-            const uint4 *q = in + 4 * p;
-            uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
+            uint4 a0, a1, b0, b1;
+            if (FOLD) {
+                // the two leaves of this lane are FRI fold outputs that do not exist yet: compute them
+                // (two products each), store them as the round's values, hash them from registers
+                const uint64_t i = (chunk << log_ch) + 2 * p;
+                Fr y0 = fri_fold_one(fold, i, Q), y1 = fri_fold_one(fold, i + 1, Q);
+                fr_store(fold.dst + 2 * i, y0);
+                fr_store(fold.dst + 2 * i + 2, y1);
+                a0 = make_uint4(y0.v[0], y0.v[1], y0.v[2], y0.v[3]);
+                a1 = make_uint4(y0.v[4], y0.v[5], y0.v[6], y0.v[7]);
+                b0 = make_uint4(y1.v[0], y1.v[1], y1.v[2], y1.v[3]);
+                b1 = make_uint4(y1.v[4], y1.v[5], y1.v[6], y1.v[7]);
+            } else {
+                const uint4 *q = in + 4 * p;
+                a0 = q[0]; a1 = q[1]; b0 = q[2]; b1 = q[3];
+            }
             uint32_t l[8], r[8], out[8];
             if (LEAF) {
                 b2s_leaf(mid, a0, a1, l);
@@ -218,7 +232,9 @@ hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *
 static void merkle_knobs() {}
 bool merkle_fuses_fold(uint64_t n)
 {
-    return knobs().fri_fuse_fold && n <= (1ull << g_lat_log);
+    // fri_fuse_fold: 0 never, 1 every round (both schedules), 2 only the latency-schedule rounds
+    const int f = knobs().fri_fuse_fold;
+    return f == 1 || (f == 2 && n <= (1ull << g_lat_log));
 }
 
 hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,
@@ -251,6 +267,8 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
             hipLaunchKernelGGL((k_merkle_subtree<true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
         else if (first && lat)
             hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
+        else if (first && fold)
+            hipLaunchKernelGGL((k_merkle_subtree<true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
         else if (first)
             hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
         else if (lat)

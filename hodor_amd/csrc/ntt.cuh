@@ -49,13 +49,17 @@ struct PassArgs {
     uint32_t tw_always;      // 1: multiply by the twiddle even when its exponent is 0 (hi carries the iNTT scale)
     uint32_t batch;          // number of independent size-n transforms (grid.y); dst arrays are n elements apart
     uint64_t src_batch_stride;   // distance between the batch's source arrays, in elements
-    uint32_t tiles_per_wg;   // k_ntt_pass<*, EPT > 0>: adjacent tiles one workgroup walks (set by the launcher)
+    uint32_t tw_sub;         // set by the launcher: the LDS twiddle table holds every 2^tw_sub-th entry (see k_ntt_pass)
     uint32_t log_skip;       // first pass of a zero-padded transform: nnz == n >> log_skip (see k_ntt_pass)
     // ---- generalized layouts (k_ntt_pass<1> only; all zero for plain arrays)
     uint32_t col_mode;       // 1: the data is a 2D array [index][width] and the transform runs along `index` for
                              //    every column: the tile's C columns are C adjacent array columns (grid.y = width/C)
                              //    and a workgroup owns ONE sub-transform position j
-    uint32_t log_width;      // col_mode: log2(width)
+    uint32_t log_width;      // col_mode: log2(width) of the destination (and of every intermediate) array
+    uint32_t src_log_width;  // col_mode, first pass: log2(width) of the SOURCE array, and the array column of
+    uint64_t src_col_off;    //   its tile column 0 (a chunk of the columns of a wider array is transformed)
+    uint64_t dst_col_off;    // col_mode, last pass: likewise for a destination wider than the chunk (dst_log_width)
+    uint32_t dst_log_width;
     uint64_t col0;           // col_mode: global index of array column 0, for the 2D twiddle w^(index * (col0 + col))
     TwoLevel tw2d;           // col_mode: that twiddle's table (lo == nullptr: none) ...
     uint32_t tw2d_on_load;   // ... applied to the inputs of the first pass (1) or the outputs of the last pass (0)

@@ -152,13 +152,8 @@ __device__ __forceinline__ uint64_t split_index(const SplitAddr &S, uint64_t x, 
 
 // MODE 0: plain arrays (every transform of the single-GPU API).  MODE 1: the same pass with the
 // generalized layouts of PassArgs (column mode, 2D twiddle, split addressing) compiled in.
-// EPT > 0: every thread loads exactly EPT elements of a tile (tile == EPT * blockDim.x, no zero
-// padding), a workgroup walks A.tiles_per_wg adjacent tiles, and the raw 32-byte elements of the NEXT
-// tile are fetched into registers before the butterflies of the current one, so the HBM latency of
-// all but the first tile hides behind arithmetic (and the LDS twiddle table is staged once per
-// workgroup instead of once per tile).  EPT == 0: one tile per workgroup, any shape.
-template <int MODE, int EPT>
-__global__ void __launch_bounds__(NTT_MAX_THREADS, EPT ? 3 : 1)   // EPT: 3 workgroups of 256 threads per CU (LDS) -> <= 168 VGPRs
+template <int MODE>
+__global__ void __launch_bounds__(NTT_MAX_THREADS)
 k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -176,10 +171,19 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     D.a4 = smem;
     D.b4 = smem + slots;
     uint4 *const T = smem + 2 * slots;
-    D.c1 = reinterpret_cast<uint32_t *>(T + 7 * half_r);
+    // tw_sub = s > 0: only every 2^s-th twiddle is staged (all that the steps before the last one touch:
+    // their table indices are multiples of 4); the last radix-4 step, the one with R/2 distinct twiddles,
+    // reads its W3 entries from the L1/L2-resident global table instead.  A quarter of the LDS table buys
+    // a fourth (R = 256) or third (R = 512) resident workgroup per CU.
+    const uint32_t tw_sub = A.tw_sub;
+    const uint32_t tw_entries = half_r >> tw_sub ? half_r >> tw_sub : 1;
+    D.c1 = reinterpret_cast<uint32_t *>(T + 7 * tw_entries);
 
-    // stage omega_R^e (e < R/2) into LDS
-    for (uint32_t e = tid; e < 7 * (R >> 1); e += nthreads) T[e] = A.rtw[e];
+    // stage omega_R^e (e < R/2, e a multiple of 2^tw_sub) into LDS
+    for (uint32_t e = tid; e < 7 * tw_entries; e += nthreads) {
+        uint32_t ent = e / 7, q = e - 7 * ent;
+        T[e] = A.rtw[7 * (ent << tw_sub) + q];
+    }
 
     // batched transforms: blockIdx.y selects one of `batch` independent size-n arrays
     const uint4 *src_b = A.src + 2ull * blockIdx.y * A.src_batch_stride;   // first LDE pass: n/f apart
@@ -190,54 +194,14 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     const uint64_t Lmask = (1ull << A.log_l) - 1;
     const uint32_t tw_shift = A.log_n - A.log_l - log_r;   // exponent scale N / (L*R)
     const uint32_t tile = R << log_c;
-    const uint32_t tiles = EPT ? A.tiles_per_wg : 1u;
-    const uint64_t bx0 = (uint64_t)blockIdx.x * tiles;
-
-    // EPT path: the raw elements of one tile, EPT (= 4) per thread — element k of a thread is tile element
-    // tid + k * blockDim.x.  Four named values, not an array: an indexed private array lands in scratch.
-    Fr raw0 = {}, raw1 = {}, raw2 = {}, raw3 = {};
-#define FETCH_RAW(bx_)                                                                            \
-    do {                                                                                          \
-        const uint64_t b__ = (uint64_t)(bx_) << log_c;                                            \
-        const uint32_t e0 = tid, e1 = tid + nthreads, e2 = tid + 2 * nthreads, e3 = tid + 3 * nthreads; \
-        raw0 = fr_load(src_b + 2 * (b__ + (e0 & (C - 1)) + (uint64_t)(e0 >> log_c) * n_over_r));   \
-        raw1 = fr_load(src_b + 2 * (b__ + (e1 & (C - 1)) + (uint64_t)(e1 >> log_c) * n_over_r));   \
-        raw2 = fr_load(src_b + 2 * (b__ + (e2 & (C - 1)) + (uint64_t)(e2 >> log_c) * n_over_r));   \
-        raw3 = fr_load(src_b + 2 * (b__ + (e3 & (C - 1)) + (uint64_t)(e3 >> log_c) * n_over_r));   \
-    } while (0)
-    if (EPT) FETCH_RAW(bx0);
-
-  for (uint32_t t = 0; t < tiles; t++) {
-    const uint64_t bx = bx0 + t;
-    const uint64_t j0 = colm ? bx : bx << log_c;
+    const uint64_t j0 = colm ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x << log_c;
 
     // ---- load: global -> (pre-scale, inter-pass twiddle) -> LDS at bit-reversed row
     // Zero padding (LDE, src/fft/lde.rs:28-31 `is_non_zero`): when only the first n >> s inputs are
     // non-zero, only sub-transform inputs i < R >> s are, they land on rows that are multiples of 2^s,
     // and the first s radix-2 stages merely copy each of them to the 2^s rows of its group — so load
     // 1/2^s of the tile, replicate, and start the butterflies at stage s.
-    const uint32_t log_skip = EPT ? 0u : A.log_skip;
-    if (EPT) {
-#define CONSUME_RAW(k_, raw_)                                                                     \
-        do {                                                                                      \
-            const uint32_t e = tid + (uint32_t)(k_) * nthreads;                                   \
-            const uint32_t c = e & (C - 1), i = e >> log_c;                                       \
-            const uint64_t j = j0 + c;                                                            \
-            const uint64_t g = j + (uint64_t)i * n_over_r;                                        \
-            Fr9 x = fr9_unpack(raw_);                                                             \
-            if (A.pre.lo != nullptr) x = mul_two_level(x, A.pre, g, false, Q);                    \
-            if (A.apply_tw) {                                                                     \
-                uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;                            \
-                x = mul_two_level(x, A.tw, ex, A.tw_always != 0, Q);                              \
-            }                                                                                     \
-            const uint32_t row = log_r ? (__brev(i) >> (32 - log_r)) : 0u;                        \
-            lds_put(D, SLOT(row, c), x);                                                          \
-        } while (0)
-        CONSUME_RAW(0, raw0);
-        CONSUME_RAW(1, raw1);
-        CONSUME_RAW(2, raw2);
-        CONSUME_RAW(3, raw3);
-    } else
+    const uint32_t log_skip = A.log_skip;
     for (uint32_t e = tid; e < (tile >> log_skip); e += nthreads) {
         uint32_t c = e & (C - 1), i = e >> log_c;
         uint64_t j = colm ? j0 : j0 + c;
@@ -248,7 +212,9 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 #pragma unroll
                 for (int k = 0; k < 9; k++) x.v[k] = ((uint32_t)g + k) & HODOR_M29;
             } else if (MODE == 1 && colm) {
-                x = fr9_unpack(fr_load(A.src + 2 * ((g << A.log_width) + colbase + c)));
+                // the row of a column-mode source may itself arrive cut into slabs / chunks (src_split)
+                const uint64_t srow = A.src_split.on ? split_index(A.src_split, g, 0) : g;
+                x = fr9_unpack(fr_load(A.src + 2 * ((srow << A.src_log_width) + A.src_col_off + colbase + c)));
                 if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
             } else if (MODE == 1 && A.src_split.on) {
                 x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, blockIdx.y)));
@@ -268,7 +234,6 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, SLOT(row + d, c), x);
     }
     __syncthreads();
-    if (EPT && t + 1 < tiles) FETCH_RAW(bx + 1);   // in flight during the butterflies below
 
     // ---- R-point DIT in LDS (values lazily reduced: limbs re-normalized once per step)
     uint32_t log_m = log_skip;
@@ -282,7 +247,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c);
             Fr9 x0 = lds_get(D, s0), x1 = lds_get(D, s1);
             // m == 1: twiddle 1 and x1 is a stored value (normalized, < 4p), a valid subtrahend
-            if (m > 1) x1 = fr9_mul3(x1, fr9w3_load(T + 7 * (jp << (log_r - log_m - 1))), Q);
+            if (m > 1) x1 = fr9_mul3(x1, fr9w3_load(T + 7 * ((jp << (log_r - log_m - 1)) >> tw_sub)), Q);
             Fr9 y0 = fr9_add(x0, x1), y1 = fr9_sub5(x0, x1, Q);
             fr9_normalize(y0);
             fr9_normalize(y1);
@@ -296,6 +261,11 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
+        // where this step's twiddles come from: the LDS table (index >> tw_sub), or — last step of a
+        // sub-sampled table — the global one
+        const bool tw_global = tw_sub != 0 && log_m + 2 >= log_r;
+        const uint4 *const TW = tw_global ? A.rtw : T;
+        const uint32_t tws = tw_global ? 0u : tw_sub;
         for (uint32_t w = tid; w < items; w += nthreads) {
             uint32_t c = w & (C - 1), q = w >> log_c;
             uint32_t jp = q & (m - 1);
@@ -309,7 +279,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             Fr9 x3 = lds_get(D, s3);
             Fr9 t;
             if (m > 1) {
-                const Fr9W3 wa = fr9w3_load(T + 7 * (jp << (log_r - log_m - 1)));
+                const Fr9W3 wa = fr9w3_load(TW + 7 * ((jp << (log_r - log_m - 1)) >> tws));
                 t = fr9_mul3(x1, wa, Q);
                 x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                 t = fr9_mul3(x3, wa, Q);
@@ -318,7 +288,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 // W3 product sees 87-bit limb groups (its < 4p bound)
                 fr9_normalize(x2);
                 fr9_normalize(x3);
-                t = fr9_mul3(x2, fr9w3_load(T + 7 * (jp << (log_r - log_m - 2))), Q);
+                t = fr9_mul3(x2, fr9w3_load(TW + 7 * ((jp << (log_r - log_m - 2)) >> tws)), Q);
                 x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
             } else {
                 // twiddles are 1: subtrahends are stored values (normalized, < 4p), except the
@@ -330,7 +300,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                 fr9_normalize(x3);
             }
-            t = fr9_mul3(x3, fr9w3_load(T + 7 * ((jp + m) << (log_r - log_m - 2))), Q);
+            t = fr9_mul3(x3, fr9w3_load(TW + 7 * (((jp + m) << (log_r - log_m - 2)) >> tws)), Q);
             x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
             fr9_normalize(x0);
             fr9_normalize(x1);
@@ -362,35 +332,31 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
         if (ABL(8) && y.v[0] != 0x12345u) continue;
-        if (MODE == 1 && colm) fr_store(A.dst + 2 * ((o << A.log_width) + colbase + c), y);
+        if (MODE == 1 && colm) fr_store(A.dst + 2 * ((o << A.dst_log_width) + A.dst_col_off + colbase + c), y);
         else if (MODE == 1 && A.dst_split.on) fr_store(A.dst + 2 * split_index(A.dst_split, o, blockIdx.y), y);
         else fr_store(dst_b + 2 * o, y);
     }
-    if (t + 1 < tiles) __syncthreads();   // the next tile overwrites the LDS this one was stored from
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers (called from the C-ABI layer)
 // ---------------------------------------------------------------------------------------------
-size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c)
+size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c, uint32_t tw_sub)
 {
     size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c;
     size_t half_r = (R / 2) ? R / 2 : 1;
-    return R * C * 36 + half_r * 112;
+    size_t entries = (half_r >> tw_sub) ? half_r >> tw_sub : 1;
+    return R * C * 36 + entries * 112;
 }
 
 hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *scale, const Fr9Params &Q)
 {
-    static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<0, 0>),
+    static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<0>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_rc1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<1, 0>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_rc2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<0, 4>),
+    static const hipError_t attr_rc1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<1>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_rc0 != hipSuccess) return attr_rc0;
     if (attr_rc1 != hipSuccess) return attr_rc1;
-    if (attr_rc2 != hipSuccess) return attr_rc2;
     uint64_t n = 1ull << A.log_n;
     const bool general = A.col_mode || A.src_split.on || A.dst_split.on;
     // column mode: one sub-transform position per workgroup, grid.y walks the array's columns C at a time
@@ -398,10 +364,22 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     unsigned grid_y = A.col_mode ? (1u << (A.log_width - A.log_c)) : (A.batch ? A.batch : 1);
     Fr9 s = {};
     if (scale) s = *scale;
-    size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c);
+    // sub-sampled LDS twiddle table when it raises the number of resident workgroups: every step but the
+    // last indexes multiples of 4 as long as at least two radix-4 steps follow the (optional) radix-2 stage
+    PassArgs B = A;
+    B.tw_sub = 0;
+    {
+        const uint32_t stages = A.log_r - A.log_skip;
+        const bool eligible = knobs().ntt_tw_sub && A.log_r >= 6 && stages >= 4 &&
+                              ((stages & 1) == 0 || A.log_r - A.log_skip - 1 >= 2);
+        if (eligible) {
+            size_t full = ntt_pass_lds_bytes(A.log_r, A.log_c, 0), sub = ntt_pass_lds_bytes(A.log_r, A.log_c, 2);
+            if ((160 * 1024) / sub > (160 * 1024) / full) B.tw_sub = 2;
+        }
+    }
+    size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c, B.tw_sub);
     // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
     const int threads_override = knobs().ntt_threads;
-    PassArgs B = A;
 #ifdef HODOR_ABLATE
     static int dbg = -1;
     if (dbg < 0) {
@@ -413,21 +391,12 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
     unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
-    // multi-tile workgroups with register prefetch: plain layout, full tiles of exactly 4 elements per thread
-    const uint32_t want_tiles = (uint32_t)knobs().ntt_tiles;
-    const bool ept4 = !general && want_tiles >= 1 && A.log_skip == 0 && A.nnz == n &&
-                      (1ull << (A.log_r + A.log_c)) == 4ull * threads && grid % want_tiles == 0;
-    if (general) {
-        hipLaunchKernelGGL((k_ntt_pass<1, 0>), dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
+    if (general)
+        hipLaunchKernelGGL(k_ntt_pass<1>, dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
                            scale ? 1u : 0u, Q);
-    } else if (ept4) {
-        B.tiles_per_wg = want_tiles;
-        hipLaunchKernelGGL((k_ntt_pass<0, 4>), dim3((unsigned)(grid / want_tiles), grid_y), dim3(threads), lds, stream,
-                           B, s, scale ? 1u : 0u, Q);
-    } else {
-        hipLaunchKernelGGL((k_ntt_pass<0, 0>), dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
+    else
+        hipLaunchKernelGGL(k_ntt_pass<0>, dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
                            scale ? 1u : 0u, Q);
-    }
     return hipGetLastError();
 }
 

@@ -34,14 +34,19 @@ class HipBackend:
         self.ctx, self.stream = ctx, stream
 
     # ---- 4-step building blocks
-    def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False):
-        dst = torch.empty_like(src)
-        self.ctx.sixstep_columns_dev(src, dst, log_n1, log_n2, log_p, rank, omega, inverse, stream=self.stream)
+    def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
+        """forward: column group `chunk` of A -> `out` (n/(P*K) elements); inverse: the K received chunk
+        buffers -> A."""
+        dst = out if out is not None else torch.empty_like(src)
+        self.ctx.sixstep_columns_dev(src, dst, log_n1, log_n2, log_p, rank, omega, inverse, log_chunks, chunk,
+                                     stream=self.stream)
         return dst
 
-    def rows(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False):
-        dst = torch.empty_like(src)
-        self.ctx.sixstep_rows_dev(src, dst, log_n1, log_n2, log_p, rank, omega, inverse, stream=self.stream)
+    def rows(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
+        """forward: the K received chunk buffers -> B; inverse: row group `chunk` of B -> `out`."""
+        dst = out if out is not None else torch.empty_like(src)
+        self.ctx.sixstep_rows_dev(src, dst, log_n1, log_n2, log_p, rank, omega, inverse, log_chunks, chunk,
+                                  stream=self.stream)
         return dst
 
     def pack(self, src, log_rows, log_cols, log_p):
@@ -105,22 +110,54 @@ def _log_p(world):
     return log_p
 
 
-def sixstep_forward(backend, a, log_n, omega, rank, world, group=None):
-    """Layout A -> layout B, one exchange.  `omega`: Montgomery integer of a primitive n-th root."""
+def _exchange_chunks(produce, m, world, group, log_chunks):
+    """Runs produce(k, send_chunk_k) for k = 0 .. K-1 and exchanges each chunk as soon as it has been
+    enqueued: the all-to-all of chunk k (asynchronous, on the communicator's own stream, ordered after the
+    kernels that wrote the chunk) overlaps the arithmetic of chunk k+1.  Returns the receive buffer, chunk
+    buffers back to back — the layout the consuming ABI call gathers from."""
+    K = 1 << log_chunks
+    like = produce(None, None)                       # dtype/device probe: a tensor of the caller's kind
+    send = torch.empty((m, 4), dtype=like.dtype, device=like.device)
+    recv = send if world == 1 else torch.empty_like(send)
+    works = []
+    step = m // K
+    for k in range(K):
+        produce(k, send[k * step:(k + 1) * step])
+        if world > 1:
+            works.append(dist.all_to_all_single(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step],
+                                                group=group, async_op=True))
+    for w in works:
+        w.wait()                                     # the current stream waits for the exchange
+    return recv
+
+
+def sixstep_forward(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
+    """Layout A -> layout B, one exchange (cut into 2^log_chunks overlapped pieces).  `omega`: Montgomery
+    integer of a primitive n-th root."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
-    y = backend.columns(a, log_n1, log_n2, log_p, rank, omega, inverse=False)
-    y = all_to_all_slabs(y, world, group)
-    return backend.rows(y, log_n1, log_n2, log_p, rank, omega, inverse=False)
+
+    def produce(k, out):
+        if k is None:
+            return a
+        backend.columns(a, log_n1, log_n2, log_p, rank, omega, False, log_chunks, k, out=out)
+
+    y = _exchange_chunks(produce, a.shape[0], world, group, log_chunks)
+    return backend.rows(y, log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
 
 
-def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None):
+def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None, log_chunks=0):
     """Layout B -> layout A, one exchange; the inverse of sixstep_forward (same `omega`; n^-1 folded in)."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
-    y = backend.rows(b, log_n1, log_n2, log_p, rank, omega, inverse=True)
-    y = all_to_all_slabs(y, world, group)
-    return backend.columns(y, log_n1, log_n2, log_p, rank, omega, inverse=True)
+
+    def produce(k, out):
+        if k is None:
+            return b
+        backend.rows(b, log_n1, log_n2, log_p, rank, omega, True, log_chunks, k, out=out)
+
+    y = _exchange_chunks(produce, b.shape[0], world, group, log_chunks)
+    return backend.columns(y, log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
 
 
 def natural_to_a(backend, x_local, log_n, rank, world, group=None):

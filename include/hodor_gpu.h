@@ -61,7 +61,7 @@ int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
 /* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
- * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TILES,
+ * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_MIN_LOG_C, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TW_SUB,
  * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ.
  * They are read once per process, change schedules only (never results), and a benchmark must echo
  * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
@@ -233,11 +233,19 @@ int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream, const hodor_fr *coe
  *                                            B -> hodor_sixstep_rows_dev(inverse = 1) -> all-to-all
  *                                              -> hodor_sixstep_columns_dev(inverse = 1) -> A
  * src != dst; every buffer holds n/P elements.  With P = 1 the pair is a complete transform whose output
- * is the N1 x N2 matrix X[k1 + N1*k2] (hodor_transpose_dev gives natural order). */
+ * is the N1 x N2 matrix X[k1 + N1*k2] (hodor_transpose_dev gives natural order).
+ * Overlap: with K = 2^log_chunks > 1 the exchange is cut into K all-to-alls of n/(P*K) elements each, so that
+ * the caller can put chunk k on the wire while the library works on chunk k+1:
+ *   forward  columns(chunk = k): column group k (c2/K columns) of A -> dst = chunk buffer k, [P][r1][c2/K] slabs;
+ *            rows(chunk ignored): src = the K received chunk buffers back to back -> B;
+ *   inverse  rows(chunk = b): row group b (r1/K rows) of B -> dst = chunk buffer b, [P][r1/K][c2] slabs;
+ *            columns(chunk ignored): src = the K received chunk buffers back to back -> A. */
 int hodor_sixstep_columns_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n1,
-                              uint32_t log_n2, uint32_t log_p, uint32_t rank, const hodor_fr *omega, int inverse);
+                              uint32_t log_n2, uint32_t log_p, uint32_t rank, const hodor_fr *omega, int inverse,
+                              uint32_t log_chunks, uint32_t chunk);
 int hodor_sixstep_rows_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n1,
-                           uint32_t log_n2, uint32_t log_p, uint32_t rank, const hodor_fr *omega, int inverse);
+                           uint32_t log_n2, uint32_t log_p, uint32_t rank, const hodor_fr *omega, int inverse,
+                           uint32_t log_chunks, uint32_t chunk);
 /* Natural block order on either side costs one more all-to-all each, fed by these two copies:
  * pack: a 2^log_rows x 2^log_cols row-major block cut into the P slabs of an all-to-all,
  *       dst[(t*rows + i)*c + j] = src[i*cols + t*c + j], c = cols / P

@@ -35,36 +35,63 @@ class OracleBackend:
                 vals[r * cols + c] = self.O.mul(vals[r * cols + c], self.O.pow(w, r * (col0 + c)))
         arr[:] = ints_to_array(vals)
 
-    def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False):
+    def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
         O = self.O
         N1, c2 = 1 << log_n1, 1 << (log_n2 - log_p)
+        K, Pn, r1 = 1 << log_chunks, 1 << log_p, 1 << (log_n1 - log_p)
         w = O.inverse(omega) if inverse else omega
         a = self._np(src).copy()                                       # [N1][c2]
+        if log_chunks and not inverse:                                 # column group `chunk` of A
+            cw = c2 // K
+            sub = np.ascontiguousarray(a.reshape(N1, c2, 4)[:, chunk * cw:(chunk + 1) * cw]).reshape(-1, 4)
+            res = self._columns_plain(sub, log_n1, log_n2, cw, rank * c2 + chunk * cw, w, False)
+            return self._ret(res, out)
+        if log_chunks and inverse:                                     # [K][P][rb][c2] received -> [N1][c2]
+            rb = r1 // K
+            a = np.ascontiguousarray(a.reshape(K, Pn, rb, c2, 4).transpose(1, 0, 2, 3, 4)).reshape(-1, 4)
+        return self._ret(self._columns_plain(a, log_n1, log_n2, c2, rank * c2, w, inverse), out)
+
+    def _ret(self, arr, out):
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64))
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
+
+    def _columns_plain(self, a, log_n1, log_n2, c2, col0, w, inverse):
+        O = self.O
+        N1 = 1 << log_n1
         if inverse:
-            self._twiddle(a, N1, c2, rank * c2, w)                     # w^-(k1 * n2) on the way in
+            self._twiddle(a, N1, c2, col0, w)                          # w^-(k1 * n2) on the way in
         t = np.ascontiguousarray(a.reshape(N1, c2, 4).transpose(1, 0, 2)).reshape(c2 * N1, 4)
         self._fft_rows(t, log_n1, O.pow(w, 1 << log_n2))
         a = np.ascontiguousarray(t.reshape(c2, N1, 4).transpose(1, 0, 2)).reshape(N1 * c2, 4)
         if not inverse:
-            self._twiddle(a, N1, c2, rank * c2, w)                     # w^(k1 * n2) on the way out
+            self._twiddle(a, N1, c2, col0, w)                          # w^(k1 * n2) on the way out
         else:
             ninv = np.array([[(O.inverse(O.from_canonical(1 << (log_n1 + log_n2))) >> (64 * i)) & (2**64 - 1)
                               for i in range(4)]], dtype=np.uint64)
             b = np.repeat(ninv, len(a), axis=0)
             O.poly_binary(a, b, "mul")
-        return torch.from_numpy(a.view(np.int64))
+        return a
 
-    def rows(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False):
+    def rows(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
         O = self.O
         Pn, r1, c2 = 1 << log_p, 1 << (log_n1 - log_p), 1 << (log_n2 - log_p)
+        K = 1 << log_chunks
         w = O.inverse(omega) if inverse else omega
         a = self._np(src).copy()
-        if not inverse:                                                # [P][r1][c2] as received -> [r1][N2]
-            a = np.ascontiguousarray(a.reshape(Pn, r1, c2, 4).transpose(1, 0, 2, 3)).reshape(-1, 4)
+        if not inverse:                                      # [K][P][r1][cw] as received -> [r1][N2] (n2 = s*c2 + k*cw + j)
+            cw = c2 // K
+            a = np.ascontiguousarray(a.reshape(K, Pn, r1, cw, 4).transpose(2, 1, 0, 3, 4)).reshape(-1, 4)
+        else:                                                # row group `chunk` of B
+            rb = r1 // K
+            a = np.ascontiguousarray(a.reshape(r1, -1, 4)[chunk * rb:(chunk + 1) * rb]).reshape(-1, 4)
+            r1 = rb
         self._fft_rows(a, log_n2, O.pow(w, 1 << log_n1))
-        if inverse:                                                    # [r1][N2] -> the slabs to send
+        if inverse:                                          # [rb][N2] -> the slabs to send, [P][rb][c2]
             a = np.ascontiguousarray(a.reshape(r1, Pn, c2, 4).transpose(1, 0, 2, 3)).reshape(-1, 4)
-        return torch.from_numpy(a.view(np.int64))
+        return self._ret(a, out)
 
     def pack(self, src, log_rows, log_cols, log_p):
         rows, Pn, c = 1 << log_rows, 1 << log_p, 1 << (log_cols - log_p)

@@ -79,6 +79,65 @@ def test_forward_and_inverse_steps_match_restatement(gpu_ctxs, oracles, field_na
         assert np.array_equal(_host(a2[r]), a[r]), ("columns^-1", r)
 
 
+@pytest.mark.parametrize("world,log_n,log_chunks", [(1, 8, 1), (1, 13, 3), (2, 8, 1), (2, 12, 2), (4, 10, 1), (4, 14, 2)])
+def test_chunked_exchange_steps_match_restatement(gpu_ctxs, oracles, world, log_n, log_chunks):
+    """The exchange cut into K overlappable chunks: every chunk buffer the library writes equals the
+    restatement's, and what it gathers back from the K received chunk buffers is the B (resp. A) layout."""
+    import torch
+    from hodor_amd.sixstep import HipBackend, split_logs
+    from sixstep_ref import OracleBackend, layout_a, layout_b
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    ref = OracleBackend()
+    ref.O = O
+    hip = HipBackend(ctx)
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = world.bit_length() - 1
+    K = 1 << log_chunks
+    n = 1 << log_n
+    m = n // world
+    step = m // K
+    full = O.random_elements(n, 90 + log_n)
+    _, k, w = O.domain(n)
+    spec = full.copy()
+    O.serial_fft(spec, w, k)
+
+    def exchange_chunks(send):           # per chunk: slab s of rank t's chunk <- slab t of rank s's chunk
+        recv = [torch.empty_like(send[0]) for _ in range(world)]
+        sl = step // world
+        for c in range(K):
+            for t in range(world):
+                for s_ in range(world):
+                    recv[t][c * step + s_ * sl:c * step + (s_ + 1) * sl] = send[s_][c * step + t * sl:c * step + (t + 1) * sl]
+        return recv
+
+    a = [layout_a(full, log_n, r, world) for r in range(world)]
+    send = []
+    for r in range(world):
+        buf = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+        for c in range(K):
+            hip.columns(_dev(a[r]), log_n1, log_n2, log_p, r, w, False, log_chunks, c, out=buf[c * step:(c + 1) * step])
+            exp = ref.columns(torch.from_numpy(a[r].view(np.int64)), log_n1, log_n2, log_p, r, w, False, log_chunks, c)
+            ctx.synchronize()
+            assert np.array_equal(_host(buf[c * step:(c + 1) * step]), exp.numpy().view(np.uint64)), ("columns", r, c)
+        send.append(buf)
+    recv = exchange_chunks(send)
+    b = [hip.rows(recv[r], log_n1, log_n2, log_p, r, w, False, log_chunks, 0) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        assert np.array_equal(_host(b[r]), layout_b(spec, log_n, r, world)), ("rows", r)
+    send = []
+    for r in range(world):
+        buf = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+        for c in range(K):
+            hip.rows(b[r], log_n1, log_n2, log_p, r, w, True, log_chunks, c, out=buf[c * step:(c + 1) * step])
+        send.append(buf)
+    recv = exchange_chunks(send)
+    a2 = [hip.columns(recv[r], log_n1, log_n2, log_p, r, w, True, log_chunks, 0) for r in range(world)]
+    ctx.synchronize()
+    for r in range(world):
+        assert np.array_equal(_host(a2[r]), a[r]), ("columns^-1", r)
+
+
 @pytest.mark.parametrize("world,log_n", [(1, 10), (2, 9), (4, 12)])
 def test_natural_order_path_pack_and_transpose(gpu_ctxs, oracles, world, log_n):
     """natural block -> pack -> exchange -> A ... B -> pack -> exchange -> transpose -> natural block."""

@@ -43,6 +43,16 @@ def _worker(rank, world, port, log_n, ret):
         ok_b = np.array_equal(b.numpy().view(np.uint64), layout_b(exp, log_n, rank, world))
         a2 = sixstep_inverse(be, b, log_n, omega, rank, world)
         ok_a = np.array_equal(a2.numpy().view(np.uint64), a.numpy().view(np.uint64))
+        # the exchange cut into overlapped chunks (asynchronous all-to-alls)
+        for log_chunks in (1, 2):
+            from hodor_amd.sixstep import split_logs
+            l1, l2 = split_logs(log_n)
+            if log_chunks > min(l1, l2) - (world.bit_length() - 1):
+                continue
+            bc = sixstep_forward(be, a, log_n, omega, rank, world, log_chunks=log_chunks)
+            ok_b &= np.array_equal(bc.numpy().view(np.uint64), b.numpy().view(np.uint64))
+            ac = sixstep_inverse(be, bc, log_n, omega, rank, world, log_chunks=log_chunks)
+            ok_a &= np.array_equal(ac.numpy().view(np.uint64), a.numpy().view(np.uint64))
         ret[rank] = (ok_fwd, ok_inv, ok_b, ok_a)
     finally:
         dist.destroy_process_group()
