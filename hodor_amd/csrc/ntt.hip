@@ -161,7 +161,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     const uint32_t log_r = A.log_r, log_c = A.log_c;
     const uint32_t R = 1u << log_r, C = 1u << log_c;
     // element (row, c) sits at slot row*C + (c ^ (row & (C-1))): the XOR swizzle spreads a column over
-    // all C 16-byte bank groups without the 1/C padding (three workgroups must fit the 160 KiB of a CU)
+    // all C 16-byte bank groups without the 1/C padding (four workgroups must fit the 160 KiB of a CU)
     const uint32_t Cm = C - 1;
 #define SLOT(row, c) ((((uint32_t)(row)) << log_c) + (((uint32_t)(c)) ^ (((uint32_t)(row)) & Cm)))
     const uint32_t slots = R << log_c;
