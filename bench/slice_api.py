@@ -15,6 +15,19 @@ for log_n in (16, 20, 22, 24):
     print("slice poly_fft 2^%d: %.3f ms  (%.2e elems/s, %.1f GB/s over PCIe both ways)" %
           (log_n, best * 1e3, n / best, 2 * n * 32 / best / 1e9))
 
+# the same with the caller's buffer pinned once (hodor_host_register): DMA at the link rate
+for log_n in (20, 24):
+    n = 1 << log_n
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    ctx.host_register(a)
+    ctx.poly_fft(a)
+    best = 1e9
+    for _ in range(3):
+        t = time.perf_counter(); ctx.poly_fft(a); best = min(best, time.perf_counter() - t)
+    ctx.host_unregister(a)
+    print("slice poly_fft 2^%d, pinned buffer: %.3f ms  (%.2e elems/s, %.1f GB/s over PCIe both ways)" %
+          (log_n, best * 1e3, n / best, 2 * n * 32 / best / 1e9))
+
 # concurrent callers on one context (the reference calls best_fft from several scoped threads,
 # src/arp/per_register/mod.rs:43-49): uploads, kernels and downloads of different callers overlap
 import threading

@@ -40,6 +40,7 @@ EXPORTS = [
     "hodor_transcript_commit_field_element", "hodor_transcript_get_challenge_bytes",
     "hodor_transcript_get_challenge", "hodor_bytes_to_challenge_index",
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
+    "hodor_host_register", "hodor_host_unregister",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
@@ -531,6 +532,13 @@ class Context:
     def transpose_dev(self, src, dst, rows, cols, stream=None):
         self._chk(self.L.hodor_transpose_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
                                              C.c_size_t(rows), C.c_size_t(cols)))
+
+    def host_register(self, a):
+        """Pin a host array the slice API will be called on repeatedly (hipHostRegister)."""
+        self._chk(self.L.hodor_host_register(self.h, _hptr(a), C.c_size_t(a.nbytes)))
+
+    def host_unregister(self, a):
+        self._chk(self.L.hodor_host_unregister(self.h, _hptr(a)))
 
     def gen_elements_dev(self, dst, first_index, count, seed, stream=None):
         """dst[r] = element first_index + r of the SplitMix64 input stream `seed`."""

@@ -513,6 +513,23 @@ extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *de
     return HODOR_OK;
 }
 
+// Pinning of caller-owned host memory: the slice API's copies from/to a registered range are true DMA
+// at the link rate instead of staged copies through the driver's bounce buffers.
+extern "C" int hodor_host_register(hodor_ctx *ctx, void *host_ptr, size_t bytes)
+{
+    NEED_DEVICE();
+    if (!host_ptr || !bytes) return HODOR_ERR_INVALID;
+    HIPCHK(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return HODOR_OK;
+}
+extern "C" int hodor_host_unregister(hodor_ctx *ctx, void *host_ptr)
+{
+    NEED_DEVICE();
+    if (!host_ptr) return HODOR_ERR_INVALID;
+    HIPCHK(hipHostUnregister(host_ptr));
+    return HODOR_OK;
+}
+
 extern "C" int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                              uint32_t log_n, const hodor_fr *omega)
 {

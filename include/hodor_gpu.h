@@ -166,6 +166,10 @@ int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr);
 int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr);
 int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+/* Slice-API callers that reuse their buffers (the prover's Vec<F> per register) can pin them once: copies
+ * from/to a registered range run as DMA at the PCIe rate (hipHostRegister).  Unregister before freeing. */
+int hodor_host_register(hodor_ctx *ctx, void *host_ptr, size_t bytes);
+int hodor_host_unregister(hodor_ctx *ctx, void *host_ptr);
 
 /* out-of-place natural->natural NTT of size 1<<log_n with an arbitrary omega (src == dst allowed) */
 int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n,

@@ -622,6 +622,23 @@ def test_fri_produce_proof(gpu_ctxs, oracles, log_deg, lde_factor, out_deg, inde
 
 
 # ---------------------------------------------------------------- re-entrancy
+def test_slice_api_on_registered_host_memory(gpu_ctxs, oracles):
+    """hodor_host_register: the slice API on a pinned caller buffer gives the same bytes."""
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    a = O.random_elements(1 << 14, 77)
+    exp = a.copy()
+    O.poly_fft(exp)
+    ctx.host_register(a)
+    try:
+        ctx.poly_fft(a)
+        assert np.array_equal(a, exp)
+        ctx.poly_ifft(a)
+    finally:
+        ctx.host_unregister(a)
+    with pytest.raises(Exception):
+        ctx.host_unregister(a)          # not registered any more
+
+
 def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     """The reference calls best_fft concurrently from scoped threads (src/arp/per_register/mod.rs:43-49,
     src/polynomials/mod.rs:446-460); the ABI must be re-entrant on one context (ctypes drops the GIL).
