@@ -60,6 +60,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     do {                                                                               \
         hipError_t e__ = (expr);                                                       \
         if (e__ != hipSuccess) {                                                       \
+            (void)hipGetLastError();                                                   \
             set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));             \
             fri_release(p);                                                            \
             return HODOR_ERR_DEVICE;                                                   \

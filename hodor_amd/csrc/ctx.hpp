@@ -171,6 +171,7 @@ struct hodor_fri_proto {
     do {                                                                              \
         hipError_t e__ = (expr);                                                      \
         if (e__ != hipSuccess) {                                                      \
+            (void)hipGetLastError();   /* reported through the ABI: do not leave it for the next HIP user */ \
             set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));         \
             return HODOR_ERR_DEVICE;                                                  \
         }                                                                             \
