@@ -57,13 +57,17 @@ def digest(t):
 
 def cpu_baseline(seconds_budget=20.0):
     """Reference CPU path (restated, oracle/hodor_oracle.c: best_fft -> parallel_fft,
-    /root/reference/src/fft/fft.rs:5-124) on the host cores: config[0], 2^20-point NTT."""
+    /root/reference/src/fft/fft.rs:5-124) on the host cores: config[0], 2^20-point NTT.
+    `value` is the reference's OWN schedule at the box's core count (P = 2^floor(log2 cores) sub-FFTs, whose
+    O(N*P) shuffle dominates at P = 256); `tuned_port` is the same code with the thread count that is
+    fastest on this box (log_cpus swept 0..6), reported so that the pathological shuffle is not mistaken
+    for the CPU's capability.  Both are C ports timed on a bounded sample; a baseline, not a target."""
     from oracle import pyref as P
     from oracle.oracle import Oracle
     O = Oracle(P.BN256.p, P.BN256.g)
     log_n = 20
     n = 1 << log_n
-    a = O.random_elements(n, 2024)
+    a = O.gen_elements(0, n, FIXTURES["ntt"]["20"]["seed"])
     _, k, w = O.domain(n)
     reps, total = 0, 0.0
     while reps < 1 or (total < seconds_budget / 2 and reps < 8):
@@ -72,9 +76,30 @@ def cpu_baseline(seconds_budget=20.0):
         O.best_fft(b, w, k)
         total += time.perf_counter() - t
         reps += 1
+    assert digest_host(b) == FIXTURES["ntt"]["20"]["fft"], "CPU oracle disagrees with its own committed digest"
+    best = None
+    for log_cpus in range(0, 7):
+        if (1 << log_cpus) > O.cpus:
+            break
+        b = a.copy()
+        t = time.perf_counter()
+        if log_cpus == 0:
+            O.serial_fft(b, w, k)
+        else:
+            O.parallel_fft(b, w, k, log_cpus)
+        dt = time.perf_counter() - t
+        if best is None or dt < best[0]:
+            best = (dt, 1 << log_cpus)
     return {"value": n * reps / total, "unit": "field-elems/s", "cores": O.cpus, "kind": "port",
             "sample": "%d x 2^20-point NTT (config[0]) via the restated Worker/parallel_fft schedule, %.1f s"
-                      % (reps, total)}
+                      % (reps, total),
+            "tuned_port": {"value": n / best[0], "unit": "field-elems/s", "cores": best[1],
+                           "sample": "one 2^20-point NTT, parallel_fft with the fastest thread count of 1..64"}}
+
+
+def digest_host(arr):
+    import hashlib
+    return hashlib.blake2s(memoryview(arr).cast("B"), digest_size=32).hexdigest()
 
 
 def main():

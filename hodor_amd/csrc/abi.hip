@@ -299,7 +299,7 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         // tile = 2^tile_log elements, but never fewer than 2^min_log_c columns: a radix-512 pass gets a
         // 2048-element tile (128-byte runs in HBM) rather than 1024 elements in 64-byte runs
         uint32_t log_c = ctx->tile_log > log_r ? ctx->tile_log - log_r : 0;
-        if (log_c < ctx->min_log_c && log_r + ctx->min_log_c <= 12) log_c = ctx->min_log_c;
+        if (log_c < ctx->min_log_c && log_r + ctx->min_log_c <= 11) log_c = ctx->min_log_c;   // <= 2048 elements: fits LDS with any twiddle table
         if (lay && lay->col_mode) {
             if (log_c > lay->log_width) log_c = lay->log_width;     // the tile's columns are array columns
             A.col_mode = 1;
