@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="sixstep: cut each all-to-all into this many pieces so that piece k is on the wire while "
                          "piece k+1 is being computed (power of two; default 4 when N > 1, 1 otherwise)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="testing aid: issue the RCCL all-to-alls even at world size 1 (needs a torchrun launch)")
     ap.add_argument("--allow-knobs", action="store_true",
                     help="run although HODOR_* tuning variables are set (they are echoed in the JSON line)")
     ap.add_argument("--skip-checks", action="store_true",
@@ -187,7 +189,9 @@ def main():
         # (layout A), the forward transform leaves row block q of the output matrix (layout B), the inverse
         # brings A back — one RCCL all-to-all each way (hodor_amd/sixstep.py; all local work, transposes
         # included, inside the C ABI).
+        import hodor_amd.sixstep as _six
         from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse
+        _six.FORCE_COLLECTIVES = bool(args.force_collectives)
         log_total = log_n + (world.bit_length() - 1)
         assert 1 << (world.bit_length() - 1) == world, "sixstep needs a power-of-two world size"
         omega = ctx.domain(1 << log_total)[2]

@@ -88,6 +88,11 @@ class HipBackend:
         return self.ctx.from_repr(v)
 
 
+# Testing aid: issue the collectives even when world == 1 (a one-rank all-to-all is a valid RCCL call), so
+# that the asynchronous-exchange / stream-ordering path can be exercised on a single-GPU box.
+FORCE_COLLECTIVES = False
+
+
 def split_logs(log_n):
     """n = N1 * N2 with N1 <= N2 (the choice every function of this module makes)."""
     log_n1 = log_n // 2
@@ -97,7 +102,7 @@ def split_logs(log_n):
 def all_to_all_slabs(x, world, group=None):
     """x: (m, 4) seen as `world` equal contiguous slabs; slab t goes to rank t.  Returns (m, 4) whose slab
     s came from rank s.  Bytes on the wire per rank: (world - 1) / world * m * 32."""
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return x
     out = torch.empty_like(x)
     dist.all_to_all_single(out, x, group=group)
@@ -118,12 +123,13 @@ def _exchange_chunks(produce, m, world, group, log_chunks):
     K = 1 << log_chunks
     like = produce(None, None)                       # dtype/device probe: a tensor of the caller's kind
     send = torch.empty((m, 4), dtype=like.dtype, device=like.device)
-    recv = send if world == 1 else torch.empty_like(send)
+    collective = world > 1 or FORCE_COLLECTIVES
+    recv = torch.empty_like(send) if collective else send
     works = []
     step = m // K
     for k in range(K):
         produce(k, send[k * step:(k + 1) * step])
-        if world > 1:
+        if collective:
             works.append(dist.all_to_all_single(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step],
                                                 group=group, async_op=True))
     for w in works:
