@@ -168,6 +168,39 @@ class Polynomial {
         return p;
     }
 
+    // pad_by_factor / pad_to_size / trim_to_degree (:85-138): host-side bookkeeping, the vector stays a
+    // plain `Vec<F>`; `false` stands for Err(SynthesisError::Error)
+    void refresh_domain()
+    {
+        Domain d = Domain::new_for_size(*F, coeffs.size());
+        exp = (uint32_t)d.power_of_two;
+        omega = d.generator;
+        omegainv = F->inverse(d.generator);
+        minv = F->inverse(F->from_u64(d.size));
+    }
+    bool pad_by_factor(size_t factor)
+    {
+        if (factor == 1) return true;
+        if (factor == 0 || (factor & (factor - 1))) return false;
+        coeffs.resize(coeffs.size() * factor, F->zero());
+        refresh_domain();
+        return true;
+    }
+    bool pad_to_size(size_t new_size)
+    {
+        if (new_size < coeffs.size() || new_size == 0 || (new_size & (new_size - 1))) return false;
+        coeffs.resize(new_size, F->zero());
+        refresh_domain();
+        return true;
+    }
+    void trim_to_degree(size_t degree)
+    {
+        const size_t size = coeffs.size();
+        if (size <= degree + 1) return;
+        coeffs.resize(degree + 1);
+        coeffs.resize(size, F->zero());
+    }
+
     void distribute_powers(const Fr &g)   // :55-58 -> src/fft/mod.rs:110
     {
         F->check(hodor_distribute_powers(F->ctx(), coeffs.data(), coeffs.size(), &g), "distribute_powers");

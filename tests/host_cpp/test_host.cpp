@@ -207,6 +207,90 @@ static void test_precomputed_omegas(const Field &F)
     CHECK(w == F.one());
 }
 
+// pad_by_factor / pad_to_size / trim_to_degree (src/polynomials/mod.rs:85-138) and the identity the
+// reference's LDE tests rest on: lde(f) == fft of the coefficients padded by f (:1026-1031)
+static void test_padding_helpers(const Field &F)
+{
+    XorShiftRng rng;
+    std::vector<Fr> c(64);
+    for (auto &v : c) v = rand_fr(rng, BN256_FR, 1);
+    auto p = from_coeffs(F, c);
+    CHECK(!p.pad_by_factor(3) && !p.pad_to_size(100) && !p.pad_to_size(32));
+    CHECK(p.pad_by_factor(1) && p.size() == 64);
+    CHECK(p.pad_by_factor(4) && p.size() == 256 && p.exp == 8);
+    for (size_t i = 64; i < 256; i++) CHECK(p.coeffs[i] == F.zero());
+    auto padded = fft(p);
+    auto direct = lde(from_coeffs(F, c), 4);
+    CHECK(padded.as_ref() == direct.as_ref());
+    auto q = from_coeffs(F, c);
+    CHECK(q.pad_to_size(128) && q.size() == 128 && q.exp == 7);
+    q.trim_to_degree(9);
+    for (size_t i = 0; i < 128; i++) CHECK(i < 10 ? q.coeffs[i] == c[i] : q.coeffs[i] == F.zero());
+}
+
+// The multi-GPU building blocks from compiled host code (what a Rust process per GPU binds): P = 2 ranks
+// played one after the other on the one device, the all-to-all done with plain device copies.
+// forward A -> columns -> exchange -> rows -> B, B transposed back == the single-device transform
+// (parallel_fft, src/fft/fft.rs:68-124, is the same split on one machine); inverse returns A.
+static void test_sixstep_two_ranks(const Field &F)
+{
+    const uint32_t log_n = 10, log_n1 = 5, log_n2 = 5, log_p = 1;
+    const size_t n = (size_t)1 << log_n, P = 2, m = n / P, N1 = 32, N2 = 32, r1 = N1 / P, c2 = N2 / P;
+    XorShiftRng rng;
+    std::vector<Fr> x(n);
+    for (auto &v : x) v = rand_fr(rng, BN256_FR, 1);
+    Domain d = Domain::new_for_size(F, n);
+    std::vector<Fr> spec = x;
+    F.check(hodor_fft(F.ctx(), spec.data(), n, &d.generator, log_n), "fft");
+    Fr *dev[2][4];
+    for (size_t q = 0; q < P; q++)
+        for (int b = 0; b < 4; b++) F.check(hodor_buf_alloc(F.ctx(), m * sizeof(Fr), (void **)&dev[q][b]), "alloc");
+    for (size_t q = 0; q < P; q++) {   // layout A: column block q of the N1 x N2 matrix
+        std::vector<Fr> a(m);
+        for (size_t i = 0; i < N1; i++)
+            for (size_t j = 0; j < c2; j++) a[i * c2 + j] = x[i * N2 + q * c2 + j];
+        F.check(hodor_buf_upload(F.ctx(), dev[q][0], a.data(), m * sizeof(Fr)), "upload");
+        F.check(hodor_sixstep_columns_dev(F.ctx(), nullptr, dev[q][0], dev[q][1], log_n1, log_n2, log_p, (uint32_t)q,
+                                          &d.generator, 0, 0, 0), "columns");
+    }
+    F.check(hodor_ctx_synchronize(F.ctx()), "sync");
+    auto exchange = [&](int from, int to) {   // slab s of rank t's receive buffer = slab t of rank s's send buffer
+        std::vector<Fr> h(m);
+        const size_t slab = m / P;
+        for (size_t t = 0; t < P; t++)
+            for (size_t s_ = 0; s_ < P; s_++) {
+                F.check(hodor_buf_download(F.ctx(), h.data(), dev[s_][from] + t * slab, slab * sizeof(Fr)), "dl");
+                F.check(hodor_buf_upload(F.ctx(), dev[t][to] + s_ * slab, h.data(), slab * sizeof(Fr)), "ul");
+            }
+    };
+    exchange(1, 2);
+    for (size_t q = 0; q < P; q++) {
+        F.check(hodor_sixstep_rows_dev(F.ctx(), nullptr, dev[q][2], dev[q][3], log_n1, log_n2, log_p, (uint32_t)q,
+                                       &d.generator, 0, 0, 0), "rows");
+        std::vector<Fr> b(m);   // layout B: b[i][k2] = X[(q*r1 + i) + N1*k2]
+        F.check(hodor_ctx_synchronize(F.ctx()), "sync");
+        F.check(hodor_buf_download(F.ctx(), b.data(), dev[q][3], m * sizeof(Fr)), "dl");
+        for (size_t i = 0; i < r1; i++)
+            for (size_t k2 = 0; k2 < N2; k2++) CHECK(b[i * N2 + k2] == spec[(q * r1 + i) + N1 * k2]);
+    }
+    for (size_t q = 0; q < P; q++)
+        F.check(hodor_sixstep_rows_dev(F.ctx(), nullptr, dev[q][3], dev[q][1], log_n1, log_n2, log_p, (uint32_t)q,
+                                       &d.generator, 1, 0, 0), "rows^-1");
+    F.check(hodor_ctx_synchronize(F.ctx()), "sync");
+    exchange(1, 2);
+    for (size_t q = 0; q < P; q++) {
+        F.check(hodor_sixstep_columns_dev(F.ctx(), nullptr, dev[q][2], dev[q][3], log_n1, log_n2, log_p, (uint32_t)q,
+                                          &d.generator, 1, 0, 0), "columns^-1");
+        std::vector<Fr> a(m);
+        F.check(hodor_ctx_synchronize(F.ctx()), "sync");
+        F.check(hodor_buf_download(F.ctx(), a.data(), dev[q][3], m * sizeof(Fr)), "dl");
+        for (size_t i = 0; i < N1; i++)
+            for (size_t j = 0; j < c2; j++) CHECK(a[i * c2 + j] == x[i * N2 + q * c2 + j]);
+    }
+    for (size_t q = 0; q < P; q++)
+        for (int b = 0; b < 4; b++) hodor_buf_free(F.ctx(), dev[q][b]);
+}
+
 int main()
 {
     Field F(BN256_FR, 7, 0);
@@ -219,6 +303,8 @@ int main()
     test_make_small_iop(F);
     test_one_fri_step(F);
     test_fri_proof_and_verifier(F);
+    test_sixstep_two_ranks(F);
+    test_padding_helpers(F);
     printf("host_cpp: all tests passed\n");
     return 0;
 }
