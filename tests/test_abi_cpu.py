@@ -165,3 +165,24 @@ def test_fri_verifier_on_host_matches_restated_verifier():
     with pytest.raises(_lib.HodorError):
         ctx.fri_verify_proof(P.fri_proof_to_bytes(proof), 2, F.to_mont(lde[2]))
     ctx.close()
+
+
+def test_knobs_are_reported_and_bench_refuses_them():
+    """hodor_knobs_set() echoes the tuning variables the library saw; bench.py refuses to run with any of
+    them set (and --skip-checks without --allow-knobs) before it touches a GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HODOR_TILE_LOG="9", HODOR_FRI_TAIL="0", HODOR_UNRELATED="1")
+    out = subprocess.run([sys.executable, "-c", "from hodor_amd import _lib; print(_lib.knobs_set())"],
+                         capture_output=True, text=True, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr
+    assert set(out.stdout.split()) == {"HODOR_TILE_LOG=9", "HODOR_FRI_TAIL=0"}
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("HODOR_")}
+    out = subprocess.run([sys.executable, "-c", "from hodor_amd import _lib; print(repr(_lib.knobs_set()))"],
+                         capture_output=True, text=True, cwd=ROOT, env=clean)
+    assert out.stdout.strip() == "''"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "refusing to benchmark" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--skip-checks"], capture_output=True,
+                       text=True, env=clean)
+    assert r.returncode != 0 and "--allow-knobs" in r.stderr
