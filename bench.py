@@ -9,7 +9,7 @@ A "step" = one forward NTT followed by one inverse NTT (Polynomial::fft + Polyno
 /root/reference/src/polynomials/mod.rs:611-624, :773-798) of a device-resident 2^24-element
 polynomial; inputs are resident in HBM before the timed region (generated there by
 hodor_gen_elements_dev, the SplitMix64 stream of SURVEY.md §8(d) that the CPU oracle reproduces).
-With N > 1 ranks the default is ONE transform of N x 2^24 points split over the ranks by the 6-step
+With N > 1 ranks the default is ONE transform of N x 2^24 points split over the ranks by the 4-step
 decomposition with RCCL all-to-all transposes (weak scaling: 2^24 points per GPU; BASELINE config[4]
 at N = 8 with --log-n 27); `--mode replicas` gives every rank its own polynomial instead (the prover
 holds one per register, src/prover/mod.rs:73-76; no data-path collective).  `value` = field elements

@@ -4,14 +4,16 @@
 
 namespace hodor {
 
-// Power tables for one (omega, log_n) pair, all in device memory, Montgomery form.
-//   lo[j]  = omega^j                 j < 2^lo_bits
-//   hi[j]  = scale * omega^(j << lo_bits)   j < 2^(log_n - lo_bits)     (scale folds n^-1 for iNTT)
-//   hi1[j] = omega^(j << lo_bits)    (unscaled copy; == hi when scale == 1)
-// so omega^e = lo[e & mask] * hi1[e >> lo_bits] with one extra product (or none when the low part
-// of e is known to be zero).  The reference recomputes twiddles by running products
-// (src/fft/fft.rs:58) or tabulates all n of them (src/precomputations/mod.rs:14-66); a two-level
-// table keeps the working set L2-resident instead of streaming n x 32 B from HBM.
+// Power tables for one (base, log_n) pair, in device memory:
+//   lo[j] = base^j                          j < 2^lo_bits
+//   hi[j] = scale * base^(j << lo_bits)     j < 2^(log_n - lo_bits)     (scale folds n^-1 for the iNTT)
+// so base^e = hi[e >> lo_bits] * lo[e & mask], one extra product (or none when the low part of e is known
+// to be zero).  Entry format by consumer (get_pow_table's fmt): 112-byte W3 constants for k_ntt_pass, which
+// applies the two halves as two successive data x constant products (fr9w3.cuh); 48-byte R'-form 9 x 29-bit
+// values where the two halves are multiplied together first (FRI fold, distribute_powers, evaluate_at);
+// 32-byte R-form values (twiddle_mul).  The reference recomputes twiddles by running products
+// (src/fft/fft.rs:58) or tabulates all n of them (src/precomputations/mod.rs:14-66); a two-level table
+// keeps the working set L2-sized instead of streaming n entries from HBM.
 struct TwoLevel {
     const uint4 *lo;
     const uint4 *hi;

@@ -8,13 +8,13 @@ rank hashes the top log2(P) levels itself, so all ranks hold the same root and t
 The global heap layout is preserved: local node `w + j` of a local level of width w is global node
 `w*P + r*w + j`; the top levels (global widths < P) are replicated.
 
-`lde_commit_distributed`: zero-padded 6-step transform (`sixstep_ntt`) followed by the distributed
+`lde_commit_distributed`: zero-padded distributed transform (`sixstep_ntt`, natural blocks in and out) followed by the distributed
 commit — BASELINE config[2]'s shape across a node.
 
 `lde_by_cosets_distributed`: the reference's own LDE schedule (`lde_using_multiple_cosets`,
 src/polynomials/mod.rs:418-482: coset i of `factor` is an independent size-n transform of
 coeffs * (W^i)^j) with the cosets dealt round-robin to the ranks — no communication until the
-interleave `out[idx] = res[idx % f][idx / f]` (:466-479), which is ONE all-to-all (the 6-step route
+interleave `out[idx] = res[idx % f][idx / f]` (:466-479), which is ONE all-to-all (the natural-order transform route
 needs three).  The coefficients (n elements, 1/f of the output) are replicated on every rank.
 """
 import torch
