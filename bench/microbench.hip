@@ -597,6 +597,76 @@ __global__ void k_fr9mul3(uint64_t *out, Fr9Params Q, uint32_t seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Two W3 products by the SAME constant, column by column in lock step: two independent accumulator chains
+// (does a wave need instruction-level parallelism of its own, or do the other resident waves hide the
+// dependent-mad latency of the single pinned chain of fr9_mul3?)
+__device__ __forceinline__ void fr9_mul3x2(const Fr9 &a0, const Fr9 &a1, const Fr9W3 &W, const Fr9Params &P,
+                                           Fr9 &r0, Fr9 &r1)
+{
+    uint32_t m0[3], m1[3];
+    uint64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (k - j >= 0 && k - j < 9) {
+                    FR9_MAD(acc0, a0.v[3 * c + j], W.w[c][k - j]);
+                    FR9_MAD(acc1, a1.v[3 * c + j], W.w[c][k - j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j < k && k - j < 9) {
+                FR9_MAD(acc0, m0[j], P.p[k - j]);
+                FR9_MAD(acc1, m1[j], P.p[k - j]);
+            }
+        }
+        if (k < 3) {
+            m0[k] = ((uint32_t)acc0 * P.pinv) & HODOR_M29;
+            m1[k] = ((uint32_t)acc1 * P.pinv) & HODOR_M29;
+            FR9_MAD(acc0, m0[k], P.p[0]);
+            FR9_MAD(acc1, m1[k], P.p[0]);
+        } else {
+            r0.v[k - 3] = (uint32_t)acc0 & HODOR_M29;
+            r1.v[k - 3] = (uint32_t)acc1 & HODOR_M29;
+        }
+        acc0 >>= 29;
+        acc1 >>= 29;
+    }
+    r0.v[8] = (uint32_t)acc0;
+    r1.v[8] = (uint32_t)acc1;
+}
+
+template <int CHAINS>
+__global__ void k_fr9mul3_occ(uint64_t *out, Fr9Params Q, uint32_t seed)
+{
+    extern __shared__ uint32_t occupancy_pad[];   // dynamic LDS only limits the resident workgroups
+    Fr9 x[2], y[2];
+    Fr9W3 w;
+    for (int i = 0; i < 9; i++) {
+        x[0].v[i] = (seed + i + threadIdx.x) & HODOR_M29; x[1].v[i] = (seed * 3 + i + blockIdx.x) & HODOR_M29;
+        for (int c = 0; c < 3; c++) w.w[c][i] = (seed * (7 + c) + i) & HODOR_M29;
+    }
+    x[0].v[8] &= 0xfffff; x[1].v[8] &= 0xfffff;
+    for (int c = 0; c < 3; c++) w.w[c][8] &= 0xfffff;
+    for (int it = 0; it < MUL_ITERS; it++) {
+        if (CHAINS == 2) {
+            fr9_mul3x2(x[0], x[1], w, Q, y[0], y[1]);
+            x[0] = y[0]; x[1] = y[1];
+        } else {
+            x[0] = fr9_mul3(x[0], w, Q);
+            x[1] = fr9_mul3(x[1], w, Q);
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 9; i++) s += x[0].v[i] + x[1].v[i];
+    if (seed == 0xffffffffu) occupancy_pad[threadIdx.x] = (uint32_t)s;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // Instruction-mix proxy of a 5 x 52-bit double-precision-FMA Montgomery product (the scheme of Emmart,
 // Zheng, Weems: hi = fma(a, b, 2^104), lo = fma(a, b, (2^104 + 2^52) - hi), bit patterns summed as
 // 64-bit integers): per limb product 2 v_fma_f64 + 1 v_add_f64 + 2 64-bit integer adds, 50 limb products
@@ -661,6 +731,32 @@ k_stride_probe(const uint4 *src, uint4 *dst, int strided_store, int xcd_aware)
         uint4 *d = strided_store ? dst + 2 * ((uint64_t)j + ((uint64_t)i << 12)) : dst + 2 * (((uint64_t)j << 12) + i);
         d[0] = lds[r & 4095];
         d[1] = lds[4096 + (r & 4095)];
+    }
+}
+
+// The pass kernel's read pattern in isolation: a workgroup of 256 threads gathers a 1024-element tile =
+// 256 rows of 128 contiguous bytes, the rows `row_stride` bytes apart (n/R elements = 2 MiB at 2^24, R = 256),
+// four elements per thread all requested before the first is used, and writes the 32 KiB contiguously.
+// 16384 workgroups cover 512 MiB.  Varying the stride by a few hundred bytes separates DRAM channel /
+// bank aliasing of the power-of-two stride from everything else.
+__global__ void __launch_bounds__(256)
+k_row_gather(const uint4 *src, uint4 *dst, uint64_t row_stride_bytes)
+{
+    const uint32_t tid = threadIdx.x;
+    const char *base = reinterpret_cast<const char *>(src) + (uint64_t)blockIdx.x * 128;
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t e = tid + 256 * k, c = e & 3, i = e >> 2;
+        const uint4 *p = reinterpret_cast<const uint4 *>(base + (uint64_t)i * row_stride_bytes + c * 32);
+        v[2 * k] = p[0];
+        v[2 * k + 1] = p[1];
+    }
+    uint4 *out = dst + 2 * ((uint64_t)blockIdx.x * 1024);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        out[2 * (tid + 256 * k)] = v[2 * k];
+        out[2 * (tid + 256 * k) + 1] = v[2 * k + 1];
     }
 }
 
@@ -755,6 +851,16 @@ int main()
         printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr9_mul (9x29)", ms, muls / ms * 1e-6);
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9mul3, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
         printf("%-16s %8.3f ms  %8.2f Gmul/s\n", "fr9_mul3 (W3)", ms, muls / ms * 1e-6);
+        // the product rate against resident waves per SIMD (256-thread workgroups, dynamic LDS as the limiter):
+        // the pass kernel runs at 4; one pinned chain (fr9_mul3) against two interleaved chains
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fr9mul3_occ<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fr9mul3_occ<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int wgs = 1; wgs <= 8; wgs *= 2) {
+            size_t lds = wgs == 8 ? 0 : (size_t)(160 * 1024 / wgs) - 1024;
+            ms = time_it([&] { hipLaunchKernelGGL(k_fr9mul3_occ<1>, dim3(blocks), dim3(threads), lds, 0, out, Q, 12345u); });
+            float ms2 = time_it([&] { hipLaunchKernelGGL(k_fr9mul3_occ<2>, dim3(blocks), dim3(threads), lds, 0, out, Q, 12345u); });
+            printf("fr9_mul3 at %d waves/SIMD: 1 chain %8.2f Gmul/s   2 chains %8.2f Gmul/s\n", wgs, muls / ms * 1e-6, muls / ms2 * 1e-6);
+        }
         ms = time_it([&] { hipLaunchKernelGGL(k_dpfma_proxy, dim3(blocks), dim3(threads), 0, 0, out, 3u, 5u); });
         printf("%-16s %8.3f ms  %8.2f Gmul/s (issue-cost proxy, 5x52-bit DP-FMA Montgomery: 100 fma + 50 add_f64 + 100 add_u64)\n", "dp-fma proxy", ms, lanes * MUL_ITERS / ms * 1e-6);
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9addsub, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
@@ -767,6 +873,16 @@ int main()
         hipMemset(a, 1, n * 16);
         float ms = time_it([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(threads), 0, 0, a, b, n); });
         printf("%-16s %8.3f ms  %8.2f GB/s (read+write)\n", "copy 1GiB", ms, 2.0 * n * 16 / ms * 1e-6);
+        // the pass kernel's gather against the row stride (bytes): 2 MiB = n/R rows of the 2^24 transform
+        {
+            const uint64_t strides[] = {2097152, 2097152 + 128, 2097152 + 256, 2097152 + 512, 2097152 + 4096, 2097152 + 65536,
+                                        1048576, 524288};
+            for (uint64_t st : strides) {
+                ms = time_it([&] { hipLaunchKernelGGL(k_row_gather, dim3(16384), dim3(256), 0, 0, a, b, st); });
+                printf("row gather, stride %8llu B (2 MiB %+8lld): %8.3f ms  %8.2f GB/s (read+write)\n", (unsigned long long)st,
+                       (long long)st - 2097152, ms, 2.0 * 512 * 1048576 / ms * 1e-6);
+            }
+        }
         // 2^24 elements of 32 B = 512 MiB: the two-pass plan's memory patterns
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_stride_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         for (int strided = 0; strided < 2; strided++)

@@ -140,8 +140,18 @@ constexpr int NTT_MAX_THREADS = 512;
 // switches used to apportion the kernel's time; the shipped library is compiled without them.
 #ifdef HODOR_ABLATE
 #define ABL(bit) (A.dbg & (bit))
+// HODOR_DBG bit 16: wave 0 of every 64th workgroup stamps the shader clock at its phase boundaries into
+// hodor_ablate_stamps (read back by bench/phase_timeline.py); bits 8-9 select the pass (log_l / 8)
+__device__ unsigned long long hodor_ablate_stamps[1024 * 16];
+#define STAMP(slot)                                                                                   \
+    do {                                                                                              \
+        if ((A.dbg & 16) && ((A.dbg >> 8) & 3) == (A.log_l >> 3) && threadIdx.x == 0 &&               \
+            (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 1024)                    \
+            hodor_ablate_stamps[(blockIdx.x >> 6) * 16 + (slot)] = __builtin_readcyclecounter();      \
+    } while (0)
 #else
 #define ABL(bit) false
+#define STAMP(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ uint64_t split_index(const SplitAddr &S, uint64_t x, uint32_t b)
@@ -179,6 +189,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     const uint32_t tw_entries = half_r >> tw_sub ? half_r >> tw_sub : 1;
     D.c1 = reinterpret_cast<uint32_t *>(T + 7 * tw_entries);
 
+    STAMP(0);
     // stage omega_R^e (e < R/2, e a multiple of 2^tw_sub) into LDS
     for (uint32_t e = tid; e < 7 * tw_entries; e += nthreads) {
         uint32_t ent = e / 7, q = e - 7 * ent;
@@ -233,7 +244,9 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         uint32_t row = log_r ? (__brev(i) >> (32 - log_r)) : 0u;
         for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, SLOT(row + d, c), x);
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     // ---- R-point DIT in LDS (values lazily reduced: limbs re-normalized once per step)
     uint32_t log_m = log_skip;
@@ -311,7 +324,9 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             lds_put(D, s2, x2);
             lds_put(D, s3, x3);
         }
+        STAMP(3 + log_m);          // 3, 5, 7, 9: end of the arithmetic of the step with half-size 2^log_m
         __syncthreads();
+        STAMP(4 + log_m);          // 4, 6, 8, 10: released from its barrier
     }
 
     // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
@@ -336,6 +351,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         else if (MODE == 1 && A.dst_split.on) fr_store(A.dst + 2 * split_index(A.dst_split, o, blockIdx.y), y);
         else fr_store(dst_b + 2 * o, y);
     }
+    STAMP(11);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,3 +435,12 @@ hipError_t pow_table_w3_launch(hipStream_t stream, uint4 *out, const Fr &base, c
 }
 
 }  // namespace hodor
+
+#ifdef HODOR_ABLATE
+extern "C" int hodor_ablate_read_stamps(unsigned long long *host, size_t count)
+{
+    if (count > 1024 * 16) count = 1024 * 16;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hodor::hodor_ablate_stamps), count * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
