@@ -262,6 +262,24 @@ __global__ void k_lshrrev64x(uint64_t *out, uint32_t a, uint32_t b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the carry extraction of the 9 x 29 products: acc >>= 29 on a 64-bit accumulator
+__global__ void k_lshr64(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint64_t acc[ILP];
+    for (int i = 0; i < ILP; i++) acc[i] = ((uint64_t)(a + i + threadIdx.x) << 33) | (b + blockIdx.x);
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            uint64_t r;
+            asm volatile("v_lshrrev_b64 %0, 1, %1" : "=v"(r) : "v"(acc[i]));
+            acc[i] = r;
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_alignbit2(uint64_t *out, uint32_t a, uint32_t b)
 {
     uint32_t acc[ILP];
@@ -817,6 +835,7 @@ int main()
     RUN("v_add3_u32", k_add3)
     RUN("v_perm_b32", k_perm)
     RUN("v_and_b32", k_lshrrev64x)
+    RUN("v_lshrrev_b64", k_lshr64)
     RUN("v_alignbit_b32", k_alignbit2)
     RUN("v_xor_b32_sdwa", k_xor_sdwa)
     RUN("rot16: 2x sdwa", k_rot16_sdwa)
