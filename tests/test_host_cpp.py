@@ -31,3 +31,34 @@ def test_reference_tests_in_cpp(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+# ---------------------------------------------------------------- plain C (the boundary is a C ABI)
+C_SRC = os.path.join(ROOT, "tests", "host_c", "test_abi.c")
+
+
+def _build_c(tmp_path):
+    import hodor_amd
+    hodor_amd.build()
+    exe = str(tmp_path / "test_abi_c")
+    libdir = os.path.join(ROOT, "hodor_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-O2", C_SRC, "-L" + libdir, "-lhodor_gpu",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_header_is_c11_and_compute_refuses_without_a_device(tmp_path):
+    """CPU: include/hodor_gpu.h compiles as strict C11, a C program links against the library, host-side
+    helpers work and compute entry points return HODOR_ERR_DEVICE (no CPU fallback)."""
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "hodor_gpu.h")])
+    out = subprocess.run([_build_c(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "compute refused as designed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_program_on_device(tmp_path):
+    out = subprocess.run([_build_c(tmp_path), "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
