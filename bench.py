@@ -116,7 +116,7 @@ def main():
                          "'replicas' = one independent 2^log_n polynomial per GPU, no data-path collective")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="sixstep: cut each all-to-all into this many pieces so that piece k is on the wire while "
-                         "piece k+1 is being computed (power of two; default 4 when N > 1, 1 otherwise)")
+                         "piece k+1 is being computed (power of two; default 4 at N = 2, 8 at N >= 4, 1 at N = 1)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="testing aid: issue the RCCL all-to-alls even at world size 1 (needs a torchrun launch)")
     ap.add_argument("--allow-knobs", action="store_true",
@@ -197,7 +197,7 @@ def main():
         omega = ctx.domain(1 << log_total)[2]
         be = HipBackend(ctx, stream=stream)
         holder = {}
-        chunks = args.exchange_chunks or (4 if world > 1 else 1)
+        chunks = args.exchange_chunks or (1 if world == 1 else (4 if world == 2 else 8))
         log_chunks = chunks.bit_length() - 1
         assert 1 << log_chunks == chunks, "--exchange-chunks must be a power of two"
 
