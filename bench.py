@@ -209,13 +209,40 @@ def main():
             ctx.poly_fft_dev(a, b, log_n, stream=stream)
             ctx.poly_ifft_dev(b, c, log_n, stream=stream)
 
-    t_warm = time.perf_counter()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    while (time.perf_counter() - t_warm) * 1e3 < WARM_MS:     # untimed, beyond the W requested steps
-        step()
+    def warm_up():
+        """The W requested steps, then as many more as it takes to have the GPU under load for WARM_MS.  The
+        number of extra steps is agreed between the ranks (max of the elapsed times): a per-rank time-based
+        loop would let the ranks issue different numbers of collectives."""
+        t_warm = time.perf_counter()
+        for _ in range(max(args.warmup, 1)):
+            step()
         torch.cuda.synchronize()
+        spent = (time.perf_counter() - t_warm) * 1e3
+        if world > 1:
+            t = torch.tensor([spent], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            spent = float(t.item())
+        per_step = spent / max(args.warmup, 1)
+        extra = 0 if spent >= WARM_MS else int((WARM_MS - spent) / max(per_step, 1e-3)) + 1
+        for _ in range(extra):
+            step()
+        torch.cuda.synchronize()
+        return extra
+
+    fallback = None
+    try:
+        extra_warm = warm_up()
+    except Exception as exc:   # noqa: BLE001 — a failure of the multi-GPU schedule must not lose the whole line
+        if args.mode != "sixstep" or world == 1:
+            raise
+        fallback = "sixstep failed on this node (%s: %s); every rank transformed its own polynomial instead" % (
+            type(exc).__name__, str(exc)[:200])
+        args.mode = "replicas"
+
+        def step():
+            ctx.poly_fft_dev(a, b, log_n, stream=stream)
+            ctx.poly_ifft_dev(b, c, log_n, stream=stream)
+        extra_warm = warm_up()
     if args.mode == "sixstep":
         c = holder["c"]
     # correctness gates (outside the timed region): the round trip, and — where the CPU oracle's answer
@@ -303,7 +330,10 @@ def main():
                    else ("1 polynomial per GPU" if world > 1 else "1 GPU")},
         "checks": checks,
         "knobs": knobs,
+        "warmup_extra_steps": extra_warm,
     }
+    if fallback:
+        result["fallback"] = fallback
     if exchange:
         result["exchange"] = exchange
 
