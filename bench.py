@@ -247,9 +247,14 @@ def main():
         c = holder["c"]
     # correctness gates (outside the timed region): the round trip, and — where the CPU oracle's answer
     # for this exact input is committed — every element of the forward transform through its digest
-    checks = {"skipped": True} if args.skip_checks else {"roundtrip": bool(torch.equal(a, c))}
-    if not args.skip_checks and not checks["roundtrip"]:
-        raise SystemExit("iNTT(NTT(x)) != x — refusing to report a number")
+    ok = True if args.skip_checks else bool(torch.equal(a, c))
+    if world > 1:      # every rank must reach the same verdict (a lone SystemExit would hang the others)
+        t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() > 0.5)
+    checks = {"skipped": True} if args.skip_checks else {"roundtrip": ok}
+    if not ok:
+        raise SystemExit("iNTT(NTT(x)) != x on some rank — refusing to report a number")
     fx = FIXTURES["ntt"].get(str(log_n))
     if fx and rank == 0 and world == 1 and not args.skip_checks:
         if args.mode == "sixstep":      # layout B = the N1 x N2 matrix X[k1 + N1*k2]: transpose to natural order
