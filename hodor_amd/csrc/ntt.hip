@@ -31,6 +31,7 @@
 // <= 6 steps of a pass of radix <= 2^11.  Every subtrahend is a fresh product (< 4 p) except in the
 // twiddle-free first step, handled explicitly; every product takes a normalized operand.
 #include <cstdlib>
+#include <type_traits>
 
 #include "knobs.hpp"
 #include "ntt.cuh"
@@ -275,55 +276,63 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
         // where this step's twiddles come from: the LDS table (index >> tw_sub), or — last step of a
-        // sub-sampled table — the global one
+        // sub-sampled table — the global one.  Two instantiations of the item loop, so that each uses its own
+        // address space (one merged pointer would turn every twiddle access into a flat load).
         const bool tw_global = tw_sub != 0 && log_m + 2 >= log_r;
-        const uint4 *const TW = tw_global ? A.rtw : T;
-        const uint32_t tws = tw_global ? 0u : tw_sub;
-        for (uint32_t w = tid; w < items; w += nthreads) {
-            uint32_t c = w & (C - 1), q = w >> log_c;
-            uint32_t jp = q & (m - 1);
-            uint32_t k = (q >> log_m) << (log_m + 2);
-            const uint32_t r0 = k + jp;
-            const uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c), s2 = SLOT(r0 + 2 * m, c),
-                           s3 = SLOT(r0 + 3 * m, c);
-            Fr9 x0 = lds_get(D, s0);
-            Fr9 x1 = lds_get(D, s1);
-            Fr9 x2 = lds_get(D, s2);
-            Fr9 x3 = lds_get(D, s3);
-            Fr9 t;
-            if (m > 1) {
-                const Fr9W3 wa = fr9w3_load(TW + 7 * ((jp << (log_r - log_m - 1)) >> tws));
-                t = fr9_mul3(x1, wa, Q);
-                x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
-                t = fr9_mul3(x3, wa, Q);
-                x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
-                // the second stage multiplies the lazy sums: carry-propagate them first so that the
-                // W3 product sees 87-bit limb groups (its < 4p bound)
+        auto step_items = [&](auto from_global) {
+            constexpr bool G = decltype(from_global)::value;
+            auto twiddle = [&](uint32_t idx) -> Fr9W3 {
+                if constexpr (G) return fr9w3_load(A.rtw + 7 * idx);
+                else return fr9w3_load(T + 7 * (idx >> tw_sub));
+            };
+            for (uint32_t w = tid; w < items; w += nthreads) {
+                uint32_t c = w & (C - 1), q = w >> log_c;
+                uint32_t jp = q & (m - 1);
+                uint32_t k = (q >> log_m) << (log_m + 2);
+                const uint32_t r0 = k + jp;
+                const uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c), s2 = SLOT(r0 + 2 * m, c),
+                               s3 = SLOT(r0 + 3 * m, c);
+                Fr9 x0 = lds_get(D, s0);
+                Fr9 x1 = lds_get(D, s1);
+                Fr9 x2 = lds_get(D, s2);
+                Fr9 x3 = lds_get(D, s3);
+                Fr9 t;
+                if (m > 1) {
+                    const Fr9W3 wa = twiddle(jp << (log_r - log_m - 1));
+                    t = fr9_mul3(x1, wa, Q);
+                    x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                    t = fr9_mul3(x3, wa, Q);
+                    x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
+                    // the second stage multiplies the lazy sums: carry-propagate them first so that the
+                    // W3 product sees 87-bit limb groups (its < 4p bound)
+                    fr9_normalize(x2);
+                    fr9_normalize(x3);
+                    t = fr9_mul3(x2, twiddle(jp << (log_r - log_m - 2)), Q);
+                    x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                } else {
+                    // twiddles are 1: subtrahends are stored values (normalized, < 4p), except the
+                    // stage-B one, a lazy sum that is first brought back under 2p
+                    t = x1; x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                    t = x3; x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
+                    t = x2;
+                    fr9_reduce_partial(t, Q);
+                    x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                    fr9_normalize(x3);
+                }
+                t = fr9_mul3(x3, twiddle((jp + m) << (log_r - log_m - 2)), Q);
+                x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
+                fr9_normalize(x0);
+                fr9_normalize(x1);
                 fr9_normalize(x2);
                 fr9_normalize(x3);
-                t = fr9_mul3(x2, fr9w3_load(TW + 7 * ((jp << (log_r - log_m - 2)) >> tws)), Q);
-                x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
-            } else {
-                // twiddles are 1: subtrahends are stored values (normalized, < 4p), except the
-                // stage-B one, a lazy sum that is first brought back under 2p
-                t = x1; x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
-                t = x3; x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
-                t = x2;
-                fr9_reduce_partial(t, Q);
-                x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
-                fr9_normalize(x3);
+                lds_put(D, s0, x0);
+                lds_put(D, s1, x1);
+                lds_put(D, s2, x2);
+                lds_put(D, s3, x3);
             }
-            t = fr9_mul3(x3, fr9w3_load(TW + 7 * (((jp + m) << (log_r - log_m - 2)) >> tws)), Q);
-            x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
-            fr9_normalize(x0);
-            fr9_normalize(x1);
-            fr9_normalize(x2);
-            fr9_normalize(x3);
-            lds_put(D, s0, x0);
-            lds_put(D, s1, x1);
-            lds_put(D, s2, x2);
-            lds_put(D, s3, x3);
-        }
+        };
+        if (tw_global) step_items(std::true_type{});
+        else step_items(std::false_type{});
         STAMP(3 + log_m);          // 3, 5, 7, 9: end of the arithmetic of the step with half-size 2^log_m
         __syncthreads();
         STAMP(4 + log_m);          // 4, 6, 8, 10: released from its barrier
