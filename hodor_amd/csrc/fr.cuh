@@ -62,6 +62,16 @@ __device__ __forceinline__ void fr_store(void *ptr, const Fr &a)
     q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
 
+// streaming store (`nt`): for data that crosses the chip once and must not push the twiddle tables out of L2
+__device__ __forceinline__ void fr_store_nt(void *ptr, const Fr &a)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u *q = reinterpret_cast<v4u *>(ptr);
+    v4u lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    __builtin_nontemporal_store(lo, q);
+    __builtin_nontemporal_store(hi, q + 1);
+}
+
 __device__ __forceinline__ bool fr_is_zero(const Fr &a)
 {
     uint32_t o = 0;
