@@ -32,6 +32,17 @@ def stats(sub):
         for r in list(csv.DictReader(open(f)))[:14]:
             print("  %-60s calls %6s avg_ns %12s total_ns %14s pct %s" % (r["Name"][:60], r["Calls"], r["AverageNs"], r["TotalDurationNs"], r["Percentage"]))
 stats("trace"); stats("trace_full")
+# per-pass split of the NTT + iNTT step: the k_ntt_pass dispatches repeat with period 6 (3 forward, 3 inverse)
+for f in glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "k_ntt_pass" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[len(rows) % 6:]          # drop table-building stragglers at the front, keep whole steps
+    rows = rows[len(rows) // 2 // 6 * 6:]   # second half: clocks settled
+    per = collections.defaultdict(list)
+    for i, r in enumerate(rows):
+        per[i % 6].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k in sorted(per):
+        print("k_ntt_pass dispatch %d of 6 (%s pass %d): avg %.1f us over %d" % (k, "forward" if k < 3 else "inverse", k % 3 + 1, sum(per[k]) / len(per[k]) / 1e3, len(per[k])))
 for sub in ("pmc_fetch","pmc_write","pmc_sq","pmc_lds","pmc_l2","full_fetch","full_write","full_sq"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
         agg = collections.defaultdict(lambda: [0, 0.0])

@@ -191,6 +191,11 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     D.c1 = reinterpret_cast<uint32_t *>(T + 7 * tw_entries);
 
     STAMP(0);
+    // The load phase (table staging, element requests, pre-scale / inter-pass products) runs at raised wave
+    // priority: a wave that has not yet put its part of the tile into LDS holds up its whole workgroup at the
+    // first barrier, while the other workgroups' butterfly steps on the same SIMD can wait (-3 % on the 2^24
+    // step; raising any later phase, or every phase by a different amount, measured neutral or worse).
+    __builtin_amdgcn_s_setprio(1);
     // stage omega_R^e (e < R/2, e a multiple of 2^tw_sub) into LDS
     for (uint32_t e = tid; e < 7 * tw_entries; e += nthreads) {
         uint32_t ent = e / 7, q = e - 7 * ent;
@@ -246,6 +251,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, SLOT(row + d, c), x);
     }
     STAMP(1);
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     STAMP(2);
 
