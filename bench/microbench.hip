@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include "../hodor_amd/csrc/fr9.cuh"
 #include "../hodor_amd/csrc/fr9w3.cuh"
+#include "../hodor_amd/csrc/blake2s.cuh"
 
 using namespace hodor;
 #define ITERS 2048
@@ -685,6 +686,32 @@ __global__ void k_fr9mul3_occ(uint64_t *out, Fr9Params Q, uint32_t seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// BLAKE2s compression rate (blake2s.cuh, one hash per lane) against resident waves per SIMD: NODE = 64-byte
+// message (all 16 words live), leaf = 32-byte message (words 8..15 zero).  Chained: each digest is the next
+// message, so nothing can be hoisted.
+constexpr int B2S_ITERS = 64;
+template <bool NODE>
+__global__ void k_b2s_occ(uint32_t *out, B2Mid mid, uint32_t seed)
+{
+    extern __shared__ uint32_t occupancy_pad[];
+    uint32_t l[8], r[8], o[8];
+    for (int i = 0; i < 8; i++) { l[i] = seed + i + threadIdx.x; r[i] = seed * 3 + i + blockIdx.x; }
+    for (int it = 0; it < B2S_ITERS; it++) {
+        if (NODE) {
+            b2s_node(mid, l, r, o);
+            for (int i = 0; i < 8; i++) { r[i] = l[i]; l[i] = o[i]; }
+        } else {
+            b2s_leaf(mid, make_uint4(l[0], l[1], l[2], l[3]), make_uint4(l[4], l[5], l[6], l[7]), o);
+            for (int i = 0; i < 8; i++) l[i] = o[i];
+        }
+    }
+    uint32_t x = 0;
+    for (int i = 0; i < 8; i++) x ^= l[i];
+    if (seed == 0xffffffffu) occupancy_pad[threadIdx.x] = x;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+
 // Instruction-mix proxy of a 5 x 52-bit double-precision-FMA Montgomery product (the scheme of Emmart,
 // Zheng, Weems: hi = fma(a, b, 2^104), lo = fma(a, b, (2^104 + 2^52) - hi), bit patterns summed as
 // 64-bit integers): per limb product 2 v_fma_f64 + 1 v_add_f64 + 2 64-bit integer adds, 50 limb products
@@ -884,6 +911,24 @@ int main()
         printf("%-16s %8.3f ms  %8.2f Gmul/s (issue-cost proxy, 5x52-bit DP-FMA Montgomery: 100 fma + 50 add_f64 + 100 add_u64)\n", "dp-fma proxy", ms, lanes * MUL_ITERS / ms * 1e-6);
         ms = time_it([&] { hipLaunchKernelGGL(k_fr9addsub, dim3(blocks), dim3(threads), 0, 0, out, Q, 12345u); });
         printf("%-16s %8.3f ms  %8.2f Gop/s (incl. normalize)\n", "fr9_add+sub", ms, muls / ms * 1e-6);
+    }
+    {
+        B2Mid mid;
+        for (int i = 0; i < 8; i++) mid.h[i] = 0x9e3779b9u * (i + 1);
+        uint32_t *o32;
+        hipMalloc(&o32, (size_t)4096 * 256 * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_b2s_occ<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_b2s_occ<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const double compr = 4096.0 * 256 * B2S_ITERS;
+        const int occs[] = {1, 2, 4, 6, 8};
+        for (int wgs : occs) {
+            size_t lds = wgs == 8 ? 0 : (size_t)(160 * 1024 / wgs) - 1024;
+            float ms = time_it([&] { hipLaunchKernelGGL(k_b2s_occ<true>, dim3(4096), dim3(256), lds, 0, o32, mid, 12345u); });
+            float ms2 = time_it([&] { hipLaunchKernelGGL(k_b2s_occ<false>, dim3(4096), dim3(256), lds, 0, o32, mid, 12345u); });
+            printf("blake2s compression at %d waves/SIMD: node %8.2f G/s (%5.1f ps)   leaf %8.2f G/s (%5.1f ps)\n", wgs,
+                   compr / ms * 1e-6, ms * 1e9 / compr, compr / ms2 * 1e-6, ms2 * 1e9 / compr);
+        }
+        hipFree(o32);
     }
     {
         size_t n = (size_t)1 << 26;   // 1 GiB of uint4
