@@ -354,6 +354,45 @@ __global__ void k_rot16_plain(uint64_t *out, uint32_t a, uint32_t b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// the same xor + rotate pairs, but the ILP xors first and the ILP rotates after them (dependency distance
+// ILP instead of 1): does a dependent instruction directly behind its producer cost an issue slot?
+__global__ void k_rot16_grouped(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(acc[i]) : "v"(y));
+#pragma unroll
+        for (int i = 0; i < ILP; i++) asm volatile("v_alignbit_b32 %0, %0, %0, 16" : "+v"(acc[i]));
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// distance 2: xor_i, xor_i+1, align_i, align_i+1
+__global__ void k_rot16_dist2(uint64_t *out, uint32_t a, uint32_t b)
+{
+    uint32_t acc[ILP];
+    uint32_t y = b + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i += 2) {
+            asm volatile("v_xor_b32 %0, %0, %1" : "+v"(acc[i]) : "v"(y));
+            asm volatile("v_xor_b32 %0, %0, %1" : "+v"(acc[i + 1]) : "v"(y));
+            asm volatile("v_alignbit_b32 %0, %0, %0, 16" : "+v"(acc[i]));
+            asm volatile("v_alignbit_b32 %0, %0, %0, 16" : "+v"(acc[i + 1]));
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_xad(uint64_t *out, uint32_t a, uint32_t b)
 {
     uint32_t acc[ILP];
@@ -867,6 +906,8 @@ int main()
     RUN("v_xor_b32_sdwa", k_xor_sdwa)
     RUN("rot16: 2x sdwa", k_rot16_sdwa)
     RUN("rot16: xor+align", k_rot16_plain)
+    RUN("rot16: distance 2", k_rot16_dist2)
+    RUN("rot16: grouped", k_rot16_grouped)
     RUN("v_xad_u32", k_xad)
     RUN("v_xor_b32_dpp", k_xor_dpp)
     RUN("v_add_u32_dpp", k_add_dpp)
