@@ -201,6 +201,18 @@ def test_sixstep_world1_2_24_equals_cpu_oracle_digest(gpu_ctxs):
     assert torch.equal(back, a)
 
 
+@pytest.mark.parametrize("world,log_n,log_chunks", [(8, 24, 3), (4, 25, 0), (2, 23, 2)])
+def test_ranks_played_on_one_gpu_equal_single_device_transform(gpu_ctxs, world, log_n, log_chunks):
+    """The bench's multi-GPU shapes, all ranks played on the one device with the all-to-all done by hand: every
+    row block of the forward transform equals the single-device transform of the same input, the inverse returns
+    the input (bench/sixstep_fullsize.py runs the same check at BASELINE config[4]'s 2^30 over 8 ranks:
+    profiles/r02/sixstep_fullsize.txt)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
+    import sixstep_fullsize
+    assert sixstep_fullsize.run(gpu_ctxs["bn256"], log_n, world, log_chunks, verbose=False)
+
+
 def test_rccl_exchange_when_two_devices_are_visible():
     """world = 2 over RCCL (one process per GPU); skipped on the single-GPU test box."""
     import torch
