@@ -192,8 +192,22 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
     return hipSuccess;
 }
 
-int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes)
+// Caller holds ctx->mu.  `user`: the stream whose work is about to use the pool.  The previous user's work
+// was enqueued completely (under the same mutex) on its own stream; if that is a different stream, the new
+// one is made to wait for it, so calls on different streams are ordered on the pool instead of racing for it.
+int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes, hipStream_t user)
 {
+    if (ctx->scratch_owned && ctx->scratch_owner != user) {
+        if (!ctx->scratch_ev) HIPCHK(hipEventCreateWithFlags(&ctx->scratch_ev, hipEventDisableTiming));
+        if (hipEventRecord(ctx->scratch_ev, ctx->scratch_owner) == hipSuccess) {
+            HIPCHK(hipStreamWaitEvent(user, ctx->scratch_ev, 0));
+        } else {                       // the previous user's stream no longer exists: nothing finer to wait on
+            (void)hipGetLastError();
+            HIPCHK(hipDeviceSynchronize());
+        }
+    }
+    ctx->scratch_owner = user;
+    ctx->scratch_owned = true;
     if (ctx->scratch_bytes[which] >= bytes) return HODOR_OK;
     if (ctx->scratch[which]) {
         HIPCHK(hipDeviceSynchronize());
@@ -264,7 +278,7 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         outs[0] = dst;
     } else {
         bool in_place = (src == dst);
-        if ((rc = ensure_scratch(ctx, 0, bytes))) return rc;
+        if ((rc = ensure_scratch(ctx, 0, bytes, stream))) return rc;
         uint4 *s0 = (uint4 *)ctx->scratch[0], *s1 = nullptr;
         // walk backwards: pass P-1 -> dst, P-2 -> s0, P-3 -> dst (or s1 if that would clobber src)...
         for (size_t i = 0; i < passes; i++) {
@@ -273,7 +287,7 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         }
         if (in_place && outs[0] == dst) {
             // pass 0 would overwrite its own (strided) input: route passes 0 and 1 through s1/s0
-            if ((rc = ensure_scratch(ctx, 1, bytes))) return rc;
+            if ((rc = ensure_scratch(ctx, 1, bytes, stream))) return rc;
             s1 = (uint4 *)ctx->scratch[1];
             outs[0] = s1;   // then pass 1 -> s0, pass 2 -> dst, ... parity preserved
         }
@@ -449,6 +463,7 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
         for (int i = 0; i < 2; i++)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+        if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
         if (ctx->fri_slab) (void)hipFree(ctx->fri_slab);
         for (auto &L : ctx->lanes) {
             for (int i = 0; i < 2; i++)
@@ -740,7 +755,7 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
         levels.push_back(L);
         m = T;
     }
-    int rc = ensure_scratch(ctx, 0, off + 256);
+    int rc = ensure_scratch(ctx, 0, off + 256, stream);
     if (rc) return rc;
     uint8_t *base = (uint8_t *)ctx->scratch[0];
     uint32_t *flag = (uint32_t *)(base + off);
@@ -789,7 +804,7 @@ extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const h
     while (((size_t)1 << log_n) < n) log_n++;
     const bool table = n >= ((size_t)1 << 16);   // below that a table is not worth its two allocations
     const size_t blocks = table ? evaluate_at_table_blocks(log_n) : 256;
-    int rc = ensure_scratch(ctx, 0, 32 * (blocks + 2) + 64);
+    int rc = ensure_scratch(ctx, 0, 32 * (blocks + 2) + 64, stream);
     if (rc) return rc;
     uint4 *partials = (uint4 *)ctx->scratch[0];
     uint4 *res = partials + 2 * blocks;

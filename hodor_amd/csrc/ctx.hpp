@@ -121,6 +121,11 @@ struct hodor_ctx {
     std::vector<RadixTable> radix_tables;
     void *scratch[2] = {nullptr, nullptr};
     size_t scratch_bytes[2] = {0, 0};
+    // the scratch pool is handed from stream to stream: a new user first waits for everything the previous
+    // user's stream has been given so far (ensure_scratch)
+    hipStream_t scratch_owner = nullptr;
+    bool scratch_owned = false;
+    hipEvent_t scratch_ev = nullptr;
     // slice API staging: IO_LANES independent (copy stream, in/out device buffers) sets, so that
     // concurrent callers (src/arp/per_register/mod.rs:43-49 calls best_fft from several scoped threads)
     // overlap one caller's upload with another's kernels and a third's download; see with_device_copy
@@ -216,7 +221,7 @@ static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
 int trim_table_cache(hodor_ctx *ctx);
 int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
                   uint32_t lo_bits = 0xffffffffu, const HFr *hi_mult_p = nullptr);
-int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes);
+int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes, hipStream_t user);
 struct NttLayout {
     bool col_mode = false;           // transform along the slow axis of a [2^log_n][2^log_width] array
     uint32_t log_width = 0;          // columns transformed (and the width of the intermediate arrays)

@@ -160,8 +160,11 @@ size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t l
  *     evaluate_at and fri_commit use it too), one twiddle-table cache and one parked FRI slab;
  *   - the slice API runs on streams the context creates itself (one non-blocking compute stream + three
  *     copy lanes, invisible to the caller) and is internally serialised on them;
- *   - therefore `_dev` calls of one context must all use the SAME stream, and must not overlap slice-API
- *     calls of that context from other threads.  Use one context per concurrently active stream. */
+ *   - `_dev` calls of one context on DIFFERENT streams are ordered on the scratch pool by the library (the
+ *     stream of a call that needs the pool first waits for everything the previous user's stream had been
+ *     given), so they are safe — also next to slice-API calls of other threads — but they do not overlap
+ *     there.  Buffers the caller passes in are the caller's to order.  Use one context per stream when the
+ *     streams are meant to run concurrently. */
 int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr);
 int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr);
 int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);

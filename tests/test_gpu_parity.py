@@ -698,6 +698,65 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     assert sum(r is not None for r in results_fri) == 3
 
 
+def test_dev_calls_on_different_streams_are_ordered_on_the_scratch_pool(gpu_ctxs, oracles):
+    """`_dev` calls of ONE context on DIFFERENT streams share the context's ping-pong scratch: the library orders
+    them on it (the new user's stream waits for what the previous user's stream was given), so interleaved
+    multi-pass transforms, an LDE, batch inversions and evaluations from three streams and three threads give the
+    results of a serial run."""
+    import threading
+    import torch
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    sizes = [18, 16, 17]
+    hosts = [O.random_elements(1 << lg, 900 + t) for t, lg in enumerate(sizes)]
+    ins = [torch.from_numpy(h.view(np.int64)).cuda() for h in hosts]
+    expected = []
+    for a, lg in zip(ins, sizes):                       # serial run on the default stream
+        b = torch.empty_like(a)
+        ctx.poly_fft_dev(a, b, lg)
+        c = torch.empty_like(a)
+        ctx.poly_ifft_dev(b, c, lg)
+        inv = a.clone()
+        ctx.poly_batch_inversion_dev(inv, 1 << lg)
+        expected.append((b.clone(), c.clone(), inv))
+    torch.cuda.synchronize()
+    for t in range(3):
+        assert torch.equal(expected[t][1], ins[t])
+    e = hosts[0].copy()
+    O.serial_fft(e, O.domain(1 << sizes[0])[2], sizes[0])
+    assert np.array_equal(expected[0][0].cpu().numpy().view(np.uint64), e)
+    streams = [torch.cuda.Stream() for _ in sizes]
+    outs = [None] * 3
+    errors = []
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0)
+            st = streams[t]
+            with torch.cuda.stream(st):
+                a, lg = ins[t], sizes[t]
+                b, c, inv = torch.empty_like(a), torch.empty_like(a), a.clone()
+                for _ in range(25):
+                    ctx.poly_fft_dev(a, b, lg, stream=st.cuda_stream)
+                    ctx.poly_ifft_dev(b, c, lg, stream=st.cuda_stream)
+                    inv.copy_(a)
+                    ctx.poly_batch_inversion_dev(inv, 1 << lg, stream=st.cuda_stream)
+                st.synchronize()
+                outs[t] = (b, c, inv)
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(3):
+        for got, want, what in zip(outs[t], expected[t], ("fft", "ifft", "batch_inversion")):
+            assert torch.equal(got, want), (t, what)
+
+
 # ---------------------------------------------------------------- value-form polynomial ops (§8 f.1)
 @pytest.mark.parametrize("n", [1, 5, 1 << 10, 1025, (1 << 16) + 3, 1 << 18, (1 << 21) + 1])
 def test_value_form_ops_dev(gpu_ctxs, oracles, field_name, n):
