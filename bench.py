@@ -16,9 +16,12 @@ holds one per register, src/prover/mod.rs:73-76; no data-path collective).  `val
 transformed by all ranks / max-over-ranks time.
 
 The line is self-checking: it is printed only if iNTT(NTT(x)) == x, the forward output's whole-buffer
-digest equals the CPU oracle's committed one (tests/golden/fullsize_digests.json), the LDE+commit root
-and the FRI prototype bytes equal the oracle's, and no HODOR_* tuning variable is set (--allow-knobs
-overrides and echoes them).
+digest equals the CPU oracle's committed one (tests/golden/fullsize_digests.json; with N > 1 ranks the
+distributed output is brought to natural order, gathered on rank 0 and hashed against the oracle's digest
+of the N x 2^24-point transform of the same stream), the LDE+commit root and the FRI prototype bytes equal
+the oracle's, and no HODOR_* tuning variable is set (--allow-knobs overrides and echoes them).
+`--backend gloo` is a testing aid: ranks may then share one GPU (exchanges staged through the host) so that
+the N > 1 path can be exercised on a single-GPU box; its line is marked as not a measurement.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -117,6 +120,11 @@ def main():
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="sixstep: cut each all-to-all into this many pieces so that piece k is on the wire while "
                          "piece k+1 is being computed (power of two; default 4 at N = 2, 8 at N >= 4, 1 at N = 1)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1: 'nccl' = RCCL over xGMI (the measurement); 'gloo' is a "
+                         "testing aid that stages every exchange through the host, so that several ranks can share "
+                         "ONE GPU and the whole multi-rank path can be exercised on a single-GPU box (the line is "
+                         "then marked \"backend\": \"gloo\" and is not a measurement)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="testing aid: issue the RCCL all-to-alls even at world size 1 (needs a torchrun launch)")
     ap.add_argument("--allow-knobs", action="store_true",
@@ -144,7 +152,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()          # ranks may share a device
     torch.cuda.set_device(local_rank)
+    ctl_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the control all-reduces live
+
+    def all_reduce_scalar(v, op):
+        t = torch.tensor([v], device=ctl_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
     if world > 1 or "RANK" in os.environ:
         # RCCL prints banner lines ("Hostname : ...", "Librccl path : ...") on STDOUT when the first
         # communicator is created; keep stdout to the single JSON line by parking fd 1 meanwhile.
@@ -153,8 +170,11 @@ def main():
         devnull = os.open(os.devnull, os.O_WRONLY)
         os.dup2(devnull, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(1, device="cuda")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            warm = torch.zeros(1, device=ctl_dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
         finally:
@@ -171,7 +191,7 @@ def main():
     seed = FIXTURES["ntt"].get(str(log_n), {"seed": 0x484F444F52})["seed"]
     a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     if args.mode == "sixstep":
-        ctx.gen_elements_dev(a, rank * n, n, seed)            # natural block `rank` of ONE big input
+        ctx.gen_elements_dev(a, rank * n, n, seed)            # natural block `rank` of ONE big input (-> layout A below)
     else:
         ctx.gen_elements_dev(a, 0, n, seed + 1000 * rank)
     ctx.synchronize()
@@ -197,6 +217,11 @@ def main():
         omega = ctx.domain(1 << log_total)[2]
         be = HipBackend(ctx, stream=stream)
         holder = {}
+        if world > 1:
+            # the generator's natural block -> this rank's column block (layout A): pack + one exchange, untimed
+            from hodor_amd.sixstep import natural_to_a
+            a = natural_to_a(be, a, log_total, rank, world)
+            torch.cuda.synchronize()
         chunks = args.exchange_chunks or (1 if world == 1 else (4 if world == 2 else 8))
         log_chunks = chunks.bit_length() - 1
         assert 1 << log_chunks == chunks, "--exchange-chunks must be a power of two"
@@ -219,9 +244,7 @@ def main():
         torch.cuda.synchronize()
         spent = (time.perf_counter() - t_warm) * 1e3
         if world > 1:
-            t = torch.tensor([spent], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            spent = float(t.item())
+            spent = all_reduce_scalar(spent, dist.ReduceOp.MAX)
         per_step = spent / max(args.warmup, 1)
         extra = 0 if spent >= WARM_MS else int((WARM_MS - spent) / max(per_step, 1e-3)) + 1
         for _ in range(extra):
@@ -249,12 +272,35 @@ def main():
     # for this exact input is committed — every element of the forward transform through its digest
     ok = True if args.skip_checks else bool(torch.equal(a, c))
     if world > 1:      # every rank must reach the same verdict (a lone SystemExit would hang the others)
-        t = torch.tensor([1.0 if ok else 0.0], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(t.item() > 0.5)
+        ok = all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
     checks = {"skipped": True} if args.skip_checks else {"roundtrip": ok}
     if not ok:
         raise SystemExit("iNTT(NTT(x)) != x on some rank — refusing to report a number")
+    if world > 1 and args.mode == "sixstep" and not args.skip_checks:
+        # the whole forward transform against the CPU oracle's committed digest of the 2^log_total-point transform
+        # of the same generator stream: layout B -> natural blocks (one more exchange), gathered on rank 0
+        fx_big = FIXTURES["ntt"].get(str(log_total))
+        if fx_big and fx_big["seed"] == seed:
+            from hodor_amd.sixstep import b_to_natural
+            nat = b_to_natural(be, holder["b"], log_total, rank, world)
+            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                parts = [torch.empty_like(nat) for _ in range(world)] if rank == 0 else None
+                dist.gather(nat, parts, dst=0)
+            else:
+                hp = [torch.empty(nat.shape, dtype=nat.dtype) for _ in range(world)] if rank == 0 else None
+                dist.gather(nat.cpu(), hp, dst=0)
+                parts = hp
+            good = 1.0
+            if rank == 0:
+                good = 1.0 if digest(torch.cat([p.to(nat.device) for p in parts])) == fx_big["fft"] else 0.0
+                del parts
+            good = all_reduce_scalar(good, dist.ReduceOp.MIN)
+            if good < 0.5:
+                raise SystemExit("forward NTT over %d ranks differs from the CPU oracle's committed digest — refusing "
+                                 "to report" % world)
+            checks["fft_digest_vs_cpu_oracle"] = True
+            del nat
     fx = FIXTURES["ntt"].get(str(log_n))
     if fx and rank == 0 and world == 1 and not args.skip_checks:
         if args.mode == "sixstep":      # layout B = the N1 x N2 matrix X[k1 + N1*k2]: transpose to natural order
@@ -283,9 +329,7 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = all_reduce_scalar(dt, dist.ReduceOp.MAX)
 
     exchange = None
     if args.mode == "sixstep":
@@ -337,6 +381,8 @@ def main():
         "knobs": knobs,
         "warmup_extra_steps": extra_warm,
     }
+    if args.backend != "nccl":
+        result["backend"] = args.backend + " (exchanges staged through the host: a test of the multi-rank path, not a measurement)"
     if fallback:
         result["fallback"] = fallback
     if exchange:

@@ -99,13 +99,31 @@ def split_logs(log_n):
     return log_n1, log_n - log_n1
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_to_all(out, inp, group=None, async_op=False):
+    """dist.all_to_all_single; device tensors on a "gloo" group (which has no device all-to-all) are staged
+    through the host — a testing aid: two processes on ONE GPU can then run the real schedule end to end."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        hin = inp.cpu()                              # waits for the current stream's kernels
+        hout = torch.empty_like(hin)
+        dist.all_to_all_single(hout, hin, group=group)
+        out.copy_(hout)
+        return _Done()
+    work = dist.all_to_all_single(out, inp, group=group, async_op=async_op)
+    return work if async_op else _Done()
+
+
 def all_to_all_slabs(x, world, group=None):
     """x: (m, 4) seen as `world` equal contiguous slabs; slab t goes to rank t.  Returns (m, 4) whose slab
     s came from rank s.  Bytes on the wire per rank: (world - 1) / world * m * 32."""
     if world == 1 and not FORCE_COLLECTIVES:
         return x
     out = torch.empty_like(x)
-    dist.all_to_all_single(out, x, group=group)
+    _all_to_all(out, x, group)
     return out
 
 
@@ -130,8 +148,7 @@ def _exchange_chunks(produce, m, world, group, log_chunks):
     for k in range(K):
         produce(k, send[k * step:(k + 1) * step])
         if collective:
-            works.append(dist.all_to_all_single(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step],
-                                                group=group, async_op=True))
+            works.append(_all_to_all(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step], group, async_op=True))
     for w in works:
         w.wait()                                     # the current stream waits for the exchange
     return recv

@@ -50,7 +50,27 @@ def test_generator_twin_matches_oracle(gpu_ctxs, oracles, field_name, log_n):
         assert np.array_equal(d.cpu().numpy().view(np.uint64), O.gen_elements(first, n, seed))
 
 
-@pytest.mark.parametrize("log_n", sorted(int(k) for k in FULL["ntt"]))
+@pytest.mark.parametrize("log_n", sorted(int(k) for k in FULL["ntt"] if "coset_fft" not in FULL["ntt"][k] and int(k) <= 27))
+def test_multi_gpu_bench_sizes_on_one_device_every_element(gpu_ctxs, log_n):
+    """2^25 .. 2^27 (the totals of `bench.py --gpus 2 / 4 / 8`): the single-device transform of the generator
+    stream equals the CPU oracle's digest, and its inverse returns the input (2^28 and 2^29 the same way through
+    bench/big_digest.py: profiles/r02/big_digest.txt)."""
+    import torch
+    ctx, e = gpu_ctxs["bn256"], FULL["ntt"][str(log_n)]
+    n = 1 << log_n
+    a = dev_elements(ctx, n, e["seed"])
+    ctx.synchronize()
+    assert digest(a) == e["input"]
+    b = torch.empty_like(a)
+    ctx.poly_fft_dev(a, b, log_n)
+    ctx.synchronize()
+    assert digest(b) == e["fft"]
+    ctx.poly_ifft_dev(b, b, log_n)
+    ctx.synchronize()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("log_n", sorted(int(k) for k in FULL["ntt"] if "coset_fft" in FULL["ntt"][k]))
 def test_config1_ntt_every_element(gpu_ctxs, log_n):
     """BASELINE config[1] (2^24) and the CPU config's size (2^20): fft / coset_fft / ifft digests equal
     the CPU oracle's; ifft(fft(x)) == x bit for bit."""

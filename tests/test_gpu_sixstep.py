@@ -228,3 +228,29 @@ def test_rccl_exchange_when_two_devices_are_visible():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["checks"]["roundtrip"] is True
+
+
+@pytest.mark.parametrize("world,log_n,chunks", [(2, 21, 4), (4, 20, 8), (2, 19, 1)])
+def test_bench_multi_rank_path_with_ranks_sharing_the_gpu(world, log_n, chunks):
+    """The multi-rank bench exactly as the driver launches it (torchrun, one process per rank, the 4-step
+    schedule with chunked exchanges, the collective warm-up agreement and verdicts), except that the ranks
+    share the one GPU and the exchanges are staged through the host over gloo (`--backend gloo`).  At
+    2^22 points in total the gathered forward transform must equal the CPU oracle's committed digest."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29540 + world + log_n),
+                          os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "2",
+                          "--warmup", "1", "--log-n", str(log_n), "--exchange-chunks", str(chunks),
+                          "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["checks"]["roundtrip"] is True
+    assert "fallback" not in line, line["fallback"]
+    assert line["exchange"]["chunks_per_all_to_all"] == chunks
+    total = log_n + world.bit_length() - 1
+    if str(total) in FULL["ntt"]:
+        assert line["checks"].get("fft_digest_vs_cpu_oracle") is True
