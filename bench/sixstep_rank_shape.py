@@ -4,7 +4,7 @@ ABI calls per direction (columns + rows) for a transform of P * 2^log_local poin
 exchange left out (the received buffer is simply the sent one, so the VALUES are meaningless — only the
 time is read).  This is the compute part of `bench.py --gpus P` per step; what the RCCL all-to-all adds on
 top cannot be measured on the pool's single-GPU boxes.
-    python bench/sixstep_rank_shape.py [log_local]"""
+    python bench/sixstep_rank_shape.py [log_local] [log_n1 override]"""
 import os
 import sys
 
@@ -29,6 +29,8 @@ def main():
         log_p = world.bit_length() - 1
         log_n = log_local + log_p
         l1, l2 = split_logs(log_n)
+        if len(sys.argv) > 2:
+            l1 = int(sys.argv[2]); l2 = log_n - l1
         omega = ctx.domain(1 << log_n)[2]
         for chunks in sorted({1, 1 if world == 1 else (4 if world == 2 else 8)}):
             lc = chunks.bit_length() - 1

@@ -94,8 +94,12 @@ FORCE_COLLECTIVES = False
 
 
 def split_logs(log_n):
-    """n = N1 * N2 with N1 <= N2 (the choice every function of this module makes)."""
-    log_n1 = log_n // 2
+    """n = N1 * N2 with N1 <= N2 (the choice every function of this module makes).  From 2^19 to 2^27 points
+    N1 = 2^9: the column transforms are then ONE pass of the transform kernel (a 512-point sub-transform per
+    workgroup tile) and the rows two, three passes over the data in all like the single-device plan, where the
+    balanced split costs four (-4 ... -6 % local arithmetic at 2, 4, 8 ranks, profiles/r02/sixstep_rank_shape.txt).
+    Outside that range the split is balanced."""
+    log_n1 = 9 if 19 <= log_n <= 27 else log_n // 2
     return log_n1, log_n - log_n1
 
 
@@ -139,6 +143,7 @@ def _exchange_chunks(produce, m, world, group, log_chunks):
     kernels that wrote the chunk) overlaps the arithmetic of chunk k+1.  Returns the receive buffer, chunk
     buffers back to back — the layout the consuming ABI call gathers from."""
     K = 1 << log_chunks
+    assert m % (K * world) == 0, "too many chunks for this transform"
     like = produce(None, None)                       # dtype/device probe: a tensor of the caller's kind
     send = torch.empty((m, 4), dtype=like.dtype, device=like.device)
     collective = world > 1 or FORCE_COLLECTIVES
