@@ -218,7 +218,11 @@ static Knobs read_knobs()
         int v = atoi(e);
         return (v < lo || v > hi) ? dflt : v;
     };
+#ifdef HODOR_TWOPASS
+    k.max_log_r = get("HODOR_MAX_LOG_R", 9, 2, 12);
+#else
     k.max_log_r = get("HODOR_MAX_LOG_R", 9, 2, 11);
+#endif
     k.tile_log = get("HODOR_TILE_LOG", 10, 6, 12);
     k.min_log_c = get("HODOR_MIN_LOG_C", 2, 0, 4);
     k.tw_hi_max_log = get("HODOR_TW_HI_MAX_LOG", 17, 0, 20);

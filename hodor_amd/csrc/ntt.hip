@@ -135,7 +135,11 @@ __device__ __forceinline__ Fr9 mul_two_level(Fr9 x, const TwoLevel &t, uint64_t 
 //   twiddle       w_(L*R)^(i*p)        p = j mod L, L = product of earlier radices
 //   output index  (j - p)*R + p + c*L  c < R (sub-transform output)
 // ---------------------------------------------------------------------------------------------
+#ifdef HODOR_TWOPASS   // experiment build (bench/twopass.sh): 4096-point tiles, one workgroup of 1024 threads per CU
+constexpr int NTT_MAX_THREADS = 1024;
+#else
 constexpr int NTT_MAX_THREADS = 512;
+#endif
 
 // HODOR_ABLATE builds (csrc/Makefile target `ablate`, bench/ablate.sh) carry the phase-skipping
 // switches used to apportion the kernel's time; the shipped library is compiled without them.
@@ -284,7 +288,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         // where this step's twiddles come from: the LDS table (index >> tw_sub), or — last step of a
         // sub-sampled table — the global one.  Two instantiations of the item loop, so that each uses its own
         // address space (one merged pointer would turn every twiddle access into a flat load).
-        const bool tw_global = tw_sub != 0 && log_m + 2 >= log_r;
+        const bool tw_global = tw_sub != 0 && log_r - log_m - 2 < tw_sub;   // finest index of this step: jp << (log_r - log_m - 2)
         auto step_items = [&](auto from_global) {
             constexpr bool G = decltype(from_global)::value;
             auto twiddle = [&](uint32_t idx) -> Fr9W3 {
@@ -410,6 +414,13 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
             if ((160 * 1024) / sub > (160 * 1024) / full) B.tw_sub = 2;
         }
     }
+#ifdef HODOR_TWOPASS
+    // a tile that does not fit with a quarter table: keep thinning the LDS table (the steps whose indices fall
+    // between its entries read the global one), even-radix un-padded passes only
+    while (ntt_pass_lds_bytes(A.log_r, A.log_c, B.tw_sub) > 160 * 1024 && B.tw_sub + 1 < A.log_r && A.log_skip == 0 &&
+           (A.log_r & 1) == 0)
+        B.tw_sub = B.tw_sub ? B.tw_sub + 1 : 2;
+#endif
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c, B.tw_sub);
     // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
     const int threads_override = knobs().ntt_threads;
@@ -423,6 +434,9 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
 #endif
     uint32_t items = 1u << (A.log_r + A.log_c >= 2 ? A.log_r + A.log_c - 2 : 0);
     unsigned threads = items >= 512 ? 512 : (items >= 256 ? 256 : (items >= 128 ? 128 : 64));
+#ifdef HODOR_TWOPASS
+    if (items >= 1024) threads = 1024;
+#endif
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
     if (general)
         hipLaunchKernelGGL(k_ntt_pass<1>, dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
