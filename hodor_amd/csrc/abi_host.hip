@@ -223,7 +223,11 @@ static Knobs read_knobs()
 #else
     k.max_log_r = get("HODOR_MAX_LOG_R", 9, 2, 11);
 #endif
+#ifdef HODOR_TWOPASS
     k.tile_log = get("HODOR_TILE_LOG", 10, 6, 12);
+#else
+    k.tile_log = get("HODOR_TILE_LOG", 10, 6, 11);   // 2048 elements x 36 B + a quarter twiddle table is the largest tile that fits 160 KB
+#endif
     k.min_log_c = get("HODOR_MIN_LOG_C", 2, 0, 4);
     k.tw_hi_max_log = get("HODOR_TW_HI_MAX_LOG", 17, 0, 20);
     k.ntt_threads = get("HODOR_NTT_THREADS", 0, 0, 1024);

@@ -407,11 +407,11 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     B.tw_sub = 0;
     {
         const uint32_t stages = A.log_r - A.log_skip;
-        const bool eligible = knobs().ntt_tw_sub && A.log_r >= 6 && stages >= 4 &&
-                              ((stages & 1) == 0 || A.log_r - A.log_skip - 1 >= 2);
+        const bool eligible = A.log_r >= 6 && stages >= 4 && ((stages & 1) == 0 || A.log_r - A.log_skip - 1 >= 2);
         if (eligible) {
             size_t full = ntt_pass_lds_bytes(A.log_r, A.log_c, 0), sub = ntt_pass_lds_bytes(A.log_r, A.log_c, 2);
-            if ((160 * 1024) / sub > (160 * 1024) / full) B.tw_sub = 2;
+            // the knob only switches the optimisation off: a tile whose full table does not fit is thinned anyway
+            if ((knobs().ntt_tw_sub || full > 160 * 1024) && (160 * 1024) / sub > (160 * 1024) / full) B.tw_sub = 2;
         }
     }
 #ifdef HODOR_TWOPASS
@@ -422,6 +422,7 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
         B.tw_sub = B.tw_sub ? B.tw_sub + 1 : 2;
 #endif
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c, B.tw_sub);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;   // the planner (abi.hip) never asks for such a tile
     // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
     const int threads_override = knobs().ntt_threads;
 #ifdef HODOR_ABLATE
