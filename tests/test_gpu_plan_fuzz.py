@@ -34,3 +34,28 @@ def test_transforms_are_plan_independent(idx):
     out = subprocess.run([sys.executable, os.path.join(HERE, "plan_fuzz_worker.py"), logs], capture_output=True,
                          text=True, timeout=900, env=env)
     assert out.returncode == 0 and "PLAN-FUZZ-OK" in out.stdout, (knobs, out.stdout[-1500:], out.stderr[-3000:])
+
+
+COMMIT_SETTINGS = [
+    ({"HODOR_MERKLE_TAIL_LOG": "0", "HODOR_MERKLE_LAT_LOG": "0", "HODOR_FRI_TAIL": "0", "HODOR_FRI_FUSE_FOLD": "0",
+      "HODOR_BATCHINV_SEQ": "2"}, "1,2,5,9,12,16"),
+    ({"HODOR_MERKLE_TAIL_LOG": "3", "HODOR_MERKLE_LAT_LOG": "8", "HODOR_FRI_FUSE_FOLD": "2", "HODOR_BATCHINV_SEQ": "3"},
+     "3,6,8,11,13,17"),
+    ({"HODOR_MERKLE_TAIL_LOG": "9", "HODOR_MERKLE_LAT_LOG": "30", "HODOR_FRI_FUSE_FOLD": "1", "HODOR_BATCHINV_SEQ": "64"},
+     "4,7,10,12,15"),
+    ({"HODOR_MERKLE_TAIL_LOG": "6", "HODOR_MERKLE_LAT_LOG": "11", "HODOR_FRI_TAIL": "0", "HODOR_FRI_FUSE_FOLD": "1",
+      "HODOR_BATCHINV_SEQ": "17"}, "5,10,13,14,18"),
+    ({"HODOR_MERKLE_TAIL_LOG": "30", "HODOR_MERKLE_LAT_LOG": "14", "HODOR_FRI_FUSE_FOLD": "2"}, "6,9,11,16"),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(COMMIT_SETTINGS)))
+def test_trees_fri_commits_and_inversions_are_schedule_independent(idx):
+    """Merkle throughput / latency schedules and their hand-over levels, the fused FRI tail, the fold inside the
+    leaf launch, the batch-inversion fan-in: whatever the knobs select, the bytes are the oracle's."""
+    knobs, logs = COMMIT_SETTINGS[idx]
+    env = dict(os.environ)
+    env.update(knobs)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "commit_fuzz_worker.py"), logs], capture_output=True,
+                         text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "COMMIT-FUZZ-OK" in out.stdout, (knobs, out.stdout[-1500:], out.stderr[-3000:])
