@@ -11,7 +11,9 @@ polynomial; inputs are resident in HBM before the timed region (generated there 
 hodor_gen_elements_dev, the SplitMix64 stream of SURVEY.md §8(d) that the CPU oracle reproduces).
 With N > 1 ranks the default is ONE transform of N x 2^24 points split over the ranks by the 4-step
 decomposition with RCCL all-to-all transposes (weak scaling: 2^24 points per GPU; BASELINE config[4]
-at N = 8 with --log-n 27); `--mode replicas` gives every rank its own polynomial instead (the prover
+at N = 8 with --log-n 27), the exchanges cut into chunks and the inverse of one step interleaved with the
+forward of the next so that every all-to-all runs behind arithmetic (K steps remain K forward + K inverse
+transforms); `--mode replicas` gives every rank its own polynomial instead (the prover
 holds one per register, src/prover/mod.rs:73-76; no data-path collective).  `value` = field elements
 transformed by all ranks / max-over-ranks time.
 
@@ -119,12 +121,18 @@ def main():
                          "'replicas' = one independent 2^log_n polynomial per GPU, no data-path collective")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="sixstep: cut each all-to-all into this many pieces so that piece k is on the wire while "
-                         "piece k+1 is being computed (power of two; default 4 at N = 2, 8 at N >= 4, 1 at N = 1)")
+                         "piece k+1 is being computed (power of two; default 4 at N >= 2 — 8 from N = 4 with "
+                         "--no-pipeline — and 1 at N = 1)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1: 'nccl' = RCCL over xGMI (the measurement); 'gloo' is a "
                          "testing aid that stages every exchange through the host, so that several ranks can share "
                          "ONE GPU and the whole multi-rank path can be exercised on a single-GPU box (the line is "
                          "then marked \"backend\": \"gloo\" and is not a measurement)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="sixstep with collectives: finish each step's inverse transform before the next step's forward "
+                         "transform starts (default: the inverse of step i and the forward of step i+1 — independent, "
+                         "both read-only on the input — are interleaved so that the exchange of one runs behind the "
+                         "arithmetic of the other; K timed steps are still K forward + K inverse transforms)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="testing aid: issue the RCCL all-to-alls even at world size 1 (needs a torchrun launch)")
     ap.add_argument("--allow-knobs", action="store_true",
@@ -222,17 +230,51 @@ def main():
             from hodor_amd.sixstep import natural_to_a
             a = natural_to_a(be, a, log_total, rank, world)
             torch.cuda.synchronize()
-        chunks = args.exchange_chunks or (1 if world == 1 else (4 if world == 2 else 8))
+        pipelined = (world > 1 or args.force_collectives) and not args.no_pipeline
+        # chunks: each costs a little arithmetic (shorter launches); pipelined, an exchange also hides behind the
+        # other transform's arithmetic, so 4 pieces are enough at any N
+        chunks = args.exchange_chunks or (1 if world == 1 else (4 if (world == 2 or pipelined) else 8))
         log_chunks = chunks.bit_length() - 1
         assert 1 << log_chunks == chunks, "--exchange-chunks must be a power of two"
 
-        def step():
-            holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
-            holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=log_chunks)
+        if pipelined:
+            # Software pipeline across steps: forward(i+1) does not depend on inverse(i) (every step transforms the
+            # same input), so the two are interleaved — columns(i+1) + its exchange, inverse rows(i) + its exchange,
+            # rows(i+1), inverse columns(i) — and each all-to-all runs behind the other transform's arithmetic as
+            # well as behind its own chunks.  drain() finishes the inverse that is still pending.
+            from hodor_amd.sixstep import (sixstep_forward_begin, sixstep_forward_end, sixstep_inverse_begin,
+                                           sixstep_inverse_end)
+
+            def step():
+                f = sixstep_forward_begin(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
+                prev = holder.pop("pending", None)
+                inv = (sixstep_inverse_begin(be, prev, log_total, omega, rank, world, log_chunks=log_chunks)
+                       if prev is not None else None)
+                holder["b"] = sixstep_forward_end(be, f)
+                if inv is not None:
+                    holder["c"] = sixstep_inverse_end(be, inv)
+                holder["pending"] = holder["b"]
+
+            def drain():
+                prev = holder.pop("pending", None)
+                if prev is not None:
+                    holder["c"] = sixstep_inverse(be, prev, log_total, omega, rank, world, log_chunks=log_chunks)
+        else:
+            def step():
+                holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
+                holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=log_chunks)
+
+            def drain():
+                pass
     else:
+        pipelined = False
+
         def step():
             ctx.poly_fft_dev(a, b, log_n, stream=stream)
             ctx.poly_ifft_dev(b, c, log_n, stream=stream)
+
+        def drain():
+            pass
 
     def warm_up():
         """The W requested steps, then as many more as it takes to have the GPU under load for WARM_MS.  The
@@ -241,6 +283,7 @@ def main():
         t_warm = time.perf_counter()
         for _ in range(max(args.warmup, 1)):
             step()
+        drain()
         torch.cuda.synchronize()
         spent = (time.perf_counter() - t_warm) * 1e3
         if world > 1:
@@ -249,6 +292,7 @@ def main():
         extra = 0 if spent >= WARM_MS else int((WARM_MS - spent) / max(per_step, 1e-3)) + 1
         for _ in range(extra):
             step()
+        drain()
         torch.cuda.synchronize()
         return extra
 
@@ -265,6 +309,10 @@ def main():
         def step():
             ctx.poly_fft_dev(a, b, log_n, stream=stream)
             ctx.poly_ifft_dev(b, c, log_n, stream=stream)
+
+        def drain():
+            pass
+        pipelined = False
         extra_warm = warm_up()
     if args.mode == "sixstep":
         c = holder["c"]
@@ -298,6 +346,7 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         step()
+    drain()
     ev1.record()
     torch.cuda.synchronize()
     barrier()
@@ -388,6 +437,8 @@ def main():
         "knobs": knobs,
         "warmup_extra_steps": extra_warm,
     }
+    if pipelined:
+        result["pipelined_across_steps"] = True
     if args.backend != "nccl":
         result["backend"] = args.backend + " (exchanges staged through the host: a test of the multi-rank path, not a measurement)"
     if fallback:

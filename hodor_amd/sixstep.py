@@ -137,11 +137,12 @@ def _log_p(world):
     return log_p
 
 
-def _exchange_chunks(produce, m, world, group, log_chunks):
-    """Runs produce(k, send_chunk_k) for k = 0 .. K-1 and exchanges each chunk as soon as it has been
+def _exchange_begin(produce, m, world, group, log_chunks):
+    """Runs produce(k, send_chunk_k) for k = 0 .. K-1 and puts each chunk on the wire as soon as it has been
     enqueued: the all-to-all of chunk k (asynchronous, on the communicator's own stream, ordered after the
-    kernels that wrote the chunk) overlaps the arithmetic of chunk k+1.  Returns the receive buffer, chunk
-    buffers back to back — the layout the consuming ABI call gathers from."""
+    kernels that wrote the chunk) overlaps the arithmetic of chunk k+1 — and whatever the caller enqueues next.
+    Returns (receive buffer, pending works); the receive buffer holds the chunk buffers back to back, the layout
+    the consuming ABI call gathers from, once _exchange_end has been called."""
     K = 1 << log_chunks
     assert m % (K * world) == 0, "too many chunks for this transform"
     like = produce(None, None)                       # dtype/device probe: a tensor of the caller's kind
@@ -154,14 +155,18 @@ def _exchange_chunks(produce, m, world, group, log_chunks):
         produce(k, send[k * step:(k + 1) * step])
         if collective:
             works.append(_all_to_all(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step], group, async_op=True))
+    return recv, works
+
+
+def _exchange_end(works):
     for w in works:
         w.wait()                                     # the current stream waits for the exchange
-    return recv
 
 
-def sixstep_forward(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
-    """Layout A -> layout B, one exchange (cut into 2^log_chunks overlapped pieces).  `omega`: Montgomery
-    integer of a primitive n-th root."""
+def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
+    """First half of sixstep_forward: the column transforms, chunk by chunk, each chunk's all-to-all started
+    behind it.  The caller may enqueue unrelated work (the other half of another transform) before
+    sixstep_forward_end, which waits for the exchange and runs the row transforms."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
 
@@ -170,12 +175,24 @@ def sixstep_forward(backend, a, log_n, omega, rank, world, group=None, log_chunk
             return a
         backend.columns(a, log_n1, log_n2, log_p, rank, omega, False, log_chunks, k, out=out)
 
-    y = _exchange_chunks(produce, a.shape[0], world, group, log_chunks)
-    return backend.rows(y, log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
+    recv, works = _exchange_begin(produce, a.shape[0], world, group, log_chunks)
+    return {"recv": recv, "works": works, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
 
-def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None, log_chunks=0):
-    """Layout B -> layout A, one exchange; the inverse of sixstep_forward (same `omega`; n^-1 folded in)."""
+def sixstep_forward_end(backend, h):
+    log_n1, log_n2, log_p, rank, omega, log_chunks = h["args"]
+    _exchange_end(h["works"])
+    return backend.rows(h["recv"], log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
+
+
+def sixstep_forward(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
+    """Layout A -> layout B, one exchange (cut into 2^log_chunks overlapped pieces).  `omega`: Montgomery
+    integer of a primitive n-th root."""
+    return sixstep_forward_end(backend, sixstep_forward_begin(backend, a, log_n, omega, rank, world, group, log_chunks))
+
+
+def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log_chunks=0):
+    """First half of sixstep_inverse: the inverse row transforms chunk by chunk with their all-to-alls."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
 
@@ -184,8 +201,19 @@ def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None, log_chunk
             return b
         backend.rows(b, log_n1, log_n2, log_p, rank, omega, True, log_chunks, k, out=out)
 
-    y = _exchange_chunks(produce, b.shape[0], world, group, log_chunks)
-    return backend.columns(y, log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
+    recv, works = _exchange_begin(produce, b.shape[0], world, group, log_chunks)
+    return {"recv": recv, "works": works, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
+
+
+def sixstep_inverse_end(backend, h):
+    log_n1, log_n2, log_p, rank, omega, log_chunks = h["args"]
+    _exchange_end(h["works"])
+    return backend.columns(h["recv"], log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
+
+
+def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None, log_chunks=0):
+    """Layout B -> layout A, one exchange; the inverse of sixstep_forward (same `omega`; n^-1 folded in)."""
+    return sixstep_inverse_end(backend, sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group, log_chunks))
 
 
 def natural_to_a(backend, x_local, log_n, rank, world, group=None):
