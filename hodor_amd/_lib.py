@@ -42,7 +42,7 @@ EXPORTS = [
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_host_register", "hodor_host_unregister",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
-    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_precomputed_omegas_dev",
+    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_poly_degree_one_on_domain_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
@@ -474,6 +474,12 @@ class Context:
     def iop_create_batch_dev(self, leafs, n, batch, nodes, stream=None):
         self._chk(self.L.hodor_iop_create_batch_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n),
                                                     C.c_size_t(batch), _dptr(nodes)))
+
+    def poly_degree_one_on_domain_dev(self, out, n, alpha, c, coset=False, stream=None):
+        """out[i] = alpha * u_i + c over the size-n domain (coset: g * w^i): src/polynomials/mod.rs:229-290"""
+        aa, cc = _fr(alpha), _fr(c)
+        self._chk(self.L.hodor_poly_degree_one_on_domain_dev(self.h, C.c_void_p(stream), _dptr(out), C.c_size_t(n),
+                                                             C.byref(aa), C.byref(cc), C.c_int(1 if coset else 0)))
 
     def distribute_powers_dev(self, a, n, g, stream=None):
         gg = _fr(g)

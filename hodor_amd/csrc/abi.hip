@@ -635,6 +635,33 @@ extern "C" int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_f
     return distribute_powers_exec(ctx, pick_stream(ctx, stream), (uint4 *)a, n, to_h(g));
 }
 
+extern "C" int hodor_poly_degree_one_on_domain_dev(hodor_ctx *ctx, void *stream_, hodor_fr *out, size_t n,
+                                                  const hodor_fr *alpha, const hodor_fr *c, int coset)
+{
+    NEED_DEVICE();
+    if (!out || !alpha || !c) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_n;
+    HFr w;
+    if (n == 0 || (n & (n - 1)) || !ctx->F.domain(n, &size, &log_n, &w) || size != n) {
+        set_err(ctx, "degree_one_on_domain: the size must be a power of two within the field's two-adicity");
+        return HODOR_ERR_SIZE;
+    }
+    hipStream_t stream = pick_stream(ctx, stream_);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const HFr a = coset ? ctx->F.mul(to_h(alpha), ctx->F.generator) : to_h(alpha);   // :277 u starts at the coset factor
+    if (n < ((size_t)1 << 16)) {
+        HIPCHK(degree_one_small_launch(stream, (uint4 *)out, n, to_dev(w), to_dev(a), to_dev(to_h(c)), ctx->P));
+        return HODOR_OK;
+    }
+    int rc = trim_table_cache(ctx);
+    if (rc) return rc;
+    TwoLevel t;
+    if ((rc = get_pow_table(ctx, w, log_n, &t, 1))) return rc;
+    HIPCHK(degree_one_launch(stream, (uint4 *)out, n, t, fr9_from_host(a), fr9_from_host(to_h(c)), ctx->Q));
+    return HODOR_OK;
+}
+
 extern "C" int hodor_precomputed_omegas_dev(hodor_ctx *ctx, void *stream, uint32_t log_n, hodor_fr *omegas,
                                             hodor_fr *coset, hodor_fr *omegas_inv)
 {

@@ -23,6 +23,10 @@ namespace hodor {
 hipError_t ntt_launch_pass(hipStream_t, const PassArgs &, const Fr9 *scale, const Fr9Params &);
 hipError_t pow_table_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
                             uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &);
+hipError_t degree_one_small_launch(hipStream_t s, uint4 *out, uint64_t n, const Fr &u, const Fr &alpha, const Fr &c,
+                                   const FrParams &P);
+hipError_t degree_one_launch(hipStream_t s, uint4 *out, uint64_t n, const TwoLevel &t, const Fr9 &alpha, const Fr9 &c,
+                             const Fr9Params &Q);
 hipError_t pow_table_w3_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
                                uint32_t log_stride, uint64_t count, const W3Consts &, const FrParams &);
 hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &);
@@ -86,6 +90,14 @@ static inline Fr9 to_dev9(const HostField &F, const HFr &a)
     for (int i = 0; i < 5; i++) t = F.add(t, t);
     Fr9 r;
     split29(t.l, r.v);
+    return r;
+}
+
+// R-form host element as it is, in 9 limbs of 29 bits (a data operand of fr9_mul / fr9_add)
+static inline Fr9 fr9_from_host(const HFr &a)
+{
+    Fr9 r;
+    split29(a.l, r.v);
     return r;
 }
 

@@ -201,6 +201,13 @@ int hodor_poly_lde_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, 
 int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, size_t batch,
                                uint8_t *nodes);
 int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
+/* Polynomial<F, Coefficients>::evaluate_at_domain_for_degree_one (coset != 0: coset_evaluate_at_...) —
+ * src/polynomials/mod.rs:229-258, :260-290: out[i] = alpha * u_i + c for q(x) = c + alpha x, u_i = w^i over the
+ * size-n domain's generator w (coset: multiplicative_generator * w^i).  n must be a power of two (the reference
+ * rounds the requested size up to one); HODOR_ERR_SIZE otherwise.  The divisor polynomials of the DEEP step
+ * (src/ali/per_register/deep.rs:59-66, :128-135) before their batch inversion. */
+int hodor_poly_degree_one_on_domain_dev(hodor_ctx *ctx, void *stream, hodor_fr *out, size_t n,
+                                        const hodor_fr *alpha, const hodor_fr *c, int coset);
 /* PrecomputedOmegas::new_for_domain — src/precomputations/mod.rs:14-66: for the domain of size
  * n = 1<<log_n with generator w: omegas[i] = w^i (n entries), coset[i] = g*w^i (n entries, g the
  * multiplicative generator), omegas_inv[i] = w^-i (n/2 entries).  A NULL output is skipped. */

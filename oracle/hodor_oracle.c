@@ -587,6 +587,26 @@ void o_distribute_powers(const ofield *f, ofr *a, size_t n, const ofr *g, uint32
     worker_scope(cpus, n, dp_chunk, &c);
 }
 
+/* Polynomial<F, Coefficients>::evaluate_at_domain_for_degree_one / coset_evaluate_at_domain_for_degree_one
+ * (src/polynomials/mod.rs:229-258, :260-290): for q(x) = c + alpha x,  out[i] = alpha * u_i + c  with
+ * u_i = g^i (g = generator of the size-n domain), resp. u_i = multiplicative_generator * g^i.  The reference
+ * splits the range into Worker chunks that each restart u at g^(i * chunk); the values do not depend on it. */
+int o_poly_degree_one_on_domain(const ofield *f, ofr *out, size_t n, const ofr *alpha, const ofr *c, int coset)
+{
+    odomain d;
+    if (odomain_new_for_size(f, n, &d) || d.size != n) return -1;
+    ofr u = f->r;                                   /* :245 g.pow(0) */
+    if (coset) ofr_mul(f, &u, &f->generator);       /* :277 */
+    for (size_t i = 0; i < n; i++) {
+        ofr tmp = *alpha;                           /* :247-250 */
+        ofr_mul(f, &tmp, &u);
+        ofr_add(f, &tmp, c);
+        out[i] = tmp;
+        ofr_mul(f, &u, &d.generator);               /* :251 */
+    }
+    return 0;
+}
+
 void o_naive_dft(const ofield *f, const ofr *in, ofr *out, size_t n, const ofr *omega)
 {
     for (size_t k = 0; k < n; k++) {

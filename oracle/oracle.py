@@ -269,6 +269,15 @@ class Oracle:
         cc = self.fr(c)
         self.L.o_poly_unary(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.c_int(code), C.byref(cc), C.c_uint64(e))
 
+    def poly_degree_one_on_domain(self, n, alpha, c, coset=False):
+        """values of q(x) = c + alpha x on the size-n domain (or its coset): src/polynomials/mod.rs:229-290"""
+        out = np.zeros((n, 4), dtype=np.uint64)
+        aa, cc = self.fr(alpha), self.fr(c)
+        if self.L.o_poly_degree_one_on_domain(C.byref(self.f), _ptr(out), C.c_size_t(n), C.byref(aa), C.byref(cc),
+                                              C.c_int(1 if coset else 0)) != 0:
+            raise ValueError("SynthesisError::Error")
+        return out
+
     def poly_batch_inversion(self, a):
         if self.L.o_poly_batch_inversion(C.byref(self.f), _ptr(a), C.c_size_t(len(a))) != 0:
             raise ValueError("SynthesisError::Error")

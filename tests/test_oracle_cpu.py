@@ -220,6 +220,25 @@ def test_value_form_ops_against_bigint(oracles, field_name):
     assert np.array_equal(z, before)
 
 
+def test_degree_one_on_domain_against_bigint(oracles, field_name):
+    """evaluate_at_domain_for_degree_one / coset_evaluate_at_domain_for_degree_one (src/polynomials/mod.rs:229-290):
+    q(x) = c + alpha x on the domain points w^i (coset: g w^i), against Python big-int arithmetic; equal to
+    evaluating the coefficient pair by the oracle's own (coset) FFT; a size that is no power of two is an error."""
+    O, F = oracles[field_name], PYF[field_name]
+    n = 64
+    w = F.domain_generator(n)[0]
+    alpha, c = 0x1234567890ABCDEF1234567 % F.p, (F.p - 5)
+    for coset in (False, True):
+        got = canon_list(F, O.poly_degree_one_on_domain(n, F.to_mont(alpha), F.to_mont(c), coset=coset))
+        shift = F.g if coset else 1
+        assert got == [(alpha * shift * pow(w, i, F.p) + c) % F.p for i in range(n)]
+        q = mont_array(F, [c, alpha] + [0] * (n - 2))
+        (O.poly_coset_fft if coset else O.poly_fft)(q)
+        assert canon_list(F, q) == got
+    with pytest.raises(ValueError):
+        O.poly_degree_one_on_domain(48, F.to_mont(alpha), F.to_mont(c))
+
+
 def test_restated_verifier_accepts_oracle_proofs(oracles):
     """verify_proof_queries (src/fri/verifier.rs:131-289) over a proof assembled from the oracle's commit
     + get_path, the way produce_proof does (src/fri/query_producer.rs:10-53)."""
