@@ -42,7 +42,8 @@ EXPORTS = [
     "hodor_buf_alloc", "hodor_buf_free", "hodor_buf_upload", "hodor_buf_download",
     "hodor_host_register", "hodor_host_unregister",
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
-    "hodor_poly_icoset_fft_dev", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_poly_degree_one_on_domain_dev", "hodor_precomputed_omegas_dev",
+    "hodor_poly_icoset_fft_dev", "hodor_poly_coset_fft_for_generator_dev", "hodor_poly_icoset_fft_for_generator_dev",
+    "hodor_poly_coset_fft_for_generator", "hodor_poly_icoset_fft_for_generator", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_poly_degree_one_on_domain_dev", "hodor_precomputed_omegas_dev",
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
@@ -380,6 +381,14 @@ class Context:
     def poly_icoset_fft(self, a):
         self._chk(self.L.hodor_poly_icoset_fft(self.h, _hptr(a), C.c_size_t(len(a))))
 
+    def poly_coset_fft_for_generator(self, a, gen):
+        g = _fr(gen)
+        self._chk(self.L.hodor_poly_coset_fft_for_generator(self.h, _hptr(a), C.c_size_t(len(a)), C.byref(g)))
+
+    def poly_icoset_fft_for_generator(self, a, geninv):
+        g = _fr(geninv)
+        self._chk(self.L.hodor_poly_icoset_fft_for_generator(self.h, _hptr(a), C.c_size_t(len(a)), C.byref(g)))
+
     def poly_lde(self, coeffs, factor, coset=False):
         out = np.zeros((len(coeffs) * factor, 4), dtype=np.uint64)
         fn = self.L.hodor_poly_coset_lde if coset else self.L.hodor_poly_lde
@@ -461,6 +470,16 @@ class Context:
 
     def poly_icoset_fft_dev(self, src, dst, log_n, stream=None):
         self._poly_dev("hodor_poly_icoset_fft_dev", src, dst, log_n, stream)
+
+    def poly_coset_fft_for_generator_dev(self, src, dst, log_n, gen, stream=None):
+        g = _fr(gen)
+        self._chk(self.L.hodor_poly_coset_fft_for_generator_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                                C.c_uint32(log_n), C.byref(g)))
+
+    def poly_icoset_fft_for_generator_dev(self, src, dst, log_n, geninv, stream=None):
+        g = _fr(geninv)
+        self._chk(self.L.hodor_poly_icoset_fft_for_generator_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                                 C.c_uint32(log_n), C.byref(g)))
 
     def poly_lde_dev(self, src, dst, log_n, factor, coset=False, stream=None):
         self._chk(self.L.hodor_poly_lde_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),

@@ -363,7 +363,8 @@ int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega)
     return HODOR_OK;
 }
 
-int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op)
+int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op,
+                   const HFr *gen)
 {
     HFr omega;
     int rc = poly_domain(ctx, log_n, &omega);
@@ -372,14 +373,15 @@ int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *
     switch (op) {
     case OP_FFT:
         return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, nullptr, nullptr, 1, nullptr);
-    case OP_COSET_FFT:   // distribute_powers(g) then fft — src/polynomials/mod.rs:626-631
-        return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, &ctx->F.generator, nullptr);
+    case OP_COSET_FFT:   // distribute_powers(g) then fft — src/polynomials/mod.rs:626-631; `gen`: coset_fft_for_generator :633-638
+        return ntt_exec(ctx, stream, src, dst, log_n, omega, n, nullptr, gen ? gen : &ctx->F.generator, nullptr);
     case OP_IFFT:
     case OP_ICOSET_FFT: {   // best_fft(omegainv) then * minv (then * geninv^i) — :773-807
         HFr oinv, minv, ginv;
         ctx->F.inverse(omega, &oinv);
         ctx->F.inverse(ctx->F.from_u64(n), &minv);
         ctx->F.inverse(ctx->F.generator, &ginv);
+        if (gen) ginv = *gen;      // icoset_fft_for_generator (:809-815) is handed the INVERSE generator
         return ntt_exec(ctx, stream, src, dst, log_n, oinv, n, &minv, nullptr,
                         op == OP_ICOSET_FFT ? &ginv : nullptr);
     }
@@ -557,13 +559,21 @@ extern "C" int hodor_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, 
 }
 
 static int poly_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n,
-                    PolyOp op)
+                    PolyOp op, const hodor_fr *gen = nullptr)
 {
     NEED_DEVICE();
     if (!src || !dst) return HODOR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    return poly_transform(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, op);
+    HFr g;
+    if (gen) g = to_h(gen);
+    return poly_transform(ctx, pick_stream(ctx, stream), (const uint4 *)src, (uint4 *)dst, log_n, op, gen ? &g : nullptr);
 }
+extern "C" int hodor_poly_coset_fft_for_generator_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst,
+                                                      uint32_t log_n, const hodor_fr *gen)
+{ return gen ? poly_dev(ctx, s, src, dst, log_n, OP_COSET_FFT, gen) : HODOR_ERR_INVALID; }
+extern "C" int hodor_poly_icoset_fft_for_generator_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst,
+                                                       uint32_t log_n, const hodor_fr *geninv)
+{ return geninv ? poly_dev(ctx, s, src, dst, log_n, OP_ICOSET_FFT, geninv) : HODOR_ERR_INVALID; }
 extern "C" int hodor_poly_fft_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst, uint32_t log_n)
 { return poly_dev(ctx, s, src, dst, log_n, OP_FFT); }
 extern "C" int hodor_poly_ifft_dev(hodor_ctx *ctx, void *s, const hodor_fr *src, hodor_fr *dst, uint32_t log_n)
@@ -945,16 +955,22 @@ extern "C" int hodor_distribute_powers(hodor_ctx *ctx, hodor_fr *a, size_t n, co
     });
 }
 
-static int poly_slice(hodor_ctx *ctx, hodor_fr *a, size_t n, PolyOp op)
+static int poly_slice(hodor_ctx *ctx, hodor_fr *a, size_t n, PolyOp op, const hodor_fr *gen = nullptr)
 {
     NEED_DEVICE();
     if (!a) return HODOR_ERR_INVALID;
     if (!is_pow2(n)) { set_err(ctx, "polynomial size must be a power of two"); return HODOR_ERR_SIZE; }
     uint32_t log_n = log2u(n);
+    HFr g;
+    if (gen) g = to_h(gen);
     return with_device_copy(ctx, a, n, a, n, [&](const uint4 *s, uint4 *d) {
-        return poly_transform(ctx, ctx->stream, s, d, log_n, op);
+        return poly_transform(ctx, ctx->stream, s, d, log_n, op, gen ? &g : nullptr);
     });
 }
+extern "C" int hodor_poly_coset_fft_for_generator(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *gen)
+{ return gen ? poly_slice(ctx, a, n, OP_COSET_FFT, gen) : HODOR_ERR_INVALID; }
+extern "C" int hodor_poly_icoset_fft_for_generator(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *geninv)
+{ return geninv ? poly_slice(ctx, a, n, OP_ICOSET_FFT, geninv) : HODOR_ERR_INVALID; }
 extern "C" int hodor_poly_fft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_FFT); }
 extern "C" int hodor_poly_coset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_COSET_FFT); }
 extern "C" int hodor_poly_ifft(hodor_ctx *ctx, hodor_fr *a, size_t n) { return poly_slice(ctx, a, n, OP_IFFT); }

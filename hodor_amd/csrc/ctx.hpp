@@ -250,4 +250,5 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
              const NttLayout *lay = nullptr);
 int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega);
 enum PolyOp { OP_FFT, OP_COSET_FFT, OP_IFFT, OP_ICOSET_FFT };
-int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op);
+int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op,
+                   const HFr *gen = nullptr);   // gen: the coset generator (OP_COSET_FFT) / its inverse (OP_ICOSET_FFT) instead of the field's

@@ -236,6 +236,13 @@ inline Polynomial<Values> coset_fft(Polynomial<Coefficients> p)
     p.F->check(hodor_poly_coset_fft(p.F->ctx(), p.coeffs.data(), p.coeffs.size()), "coset_fft");
     return std::move(p).retype<Values>();
 }
+// coset_fft_for_generator (:633-638)
+inline Polynomial<Values> coset_fft_for_generator(Polynomial<Coefficients> p, const Fr &gen)
+{
+    p.F->check(hodor_poly_coset_fft_for_generator(p.F->ctx(), p.coeffs.data(), p.coeffs.size(), &gen),
+               "coset_fft_for_generator");
+    return std::move(p).retype<Values>();
+}
 // Polynomial<F, Values>::ifft / icoset_fft (:773-807)
 inline Polynomial<Coefficients> ifft(Polynomial<Values> p)
 {
@@ -245,6 +252,13 @@ inline Polynomial<Coefficients> ifft(Polynomial<Values> p)
 inline Polynomial<Coefficients> icoset_fft(Polynomial<Values> p)
 {
     p.F->check(hodor_poly_icoset_fft(p.F->ctx(), p.coeffs.data(), p.coeffs.size()), "icoset_fft");
+    return std::move(p).retype<Coefficients>();
+}
+// icoset_fft_for_generator (:809-815): `geninv` is the inverse of the coset generator, as in the reference
+inline Polynomial<Coefficients> icoset_fft_for_generator(Polynomial<Values> p, const Fr &geninv)
+{
+    p.F->check(hodor_poly_icoset_fft_for_generator(p.F->ctx(), p.coeffs.data(), p.coeffs.size(), &geninv),
+               "icoset_fft_for_generator");
     return std::move(p).retype<Coefficients>();
 }
 // lde / coset_lde (:343-349 -> :418-482, :544-609)

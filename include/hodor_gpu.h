@@ -99,6 +99,10 @@ int hodor_poly_coset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n);
 /* Polynomial<F, Values>::{ifft, icoset_fft} — src/polynomials/mod.rs:773-807 */
 int hodor_poly_ifft(hodor_ctx *ctx, hodor_fr *a, size_t n);
 int hodor_poly_icoset_fft(hodor_ctx *ctx, hodor_fr *a, size_t n);
+/* coset_fft_for_generator (:633-638: distribute_powers(gen) then fft) and icoset_fft_for_generator (:809-815:
+ * ifft then distribute_powers(geninv) — the caller passes the INVERSE, as the Rust caller does) */
+int hodor_poly_coset_fft_for_generator(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *gen);
+int hodor_poly_icoset_fft_for_generator(hodor_ctx *ctx, hodor_fr *a, size_t n, const hodor_fr *geninv);
 /* Polynomial::lde / coset_lde (-> lde_using_multiple_cosets / coset_lde_using_multiple_cosets)
  * — src/polynomials/mod.rs:343, 349, 418-482, 544-609.  out has n*factor elements:
  * out[idx] = P(Omega^idx)  resp.  P(g * Omega^idx), natural order on the size n*factor domain. */
@@ -190,6 +194,10 @@ int hodor_poly_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_
 int hodor_poly_ifft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
 int hodor_poly_coset_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
 int hodor_poly_icoset_fft_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_n);
+int hodor_poly_coset_fft_for_generator_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                                           uint32_t log_n, const hodor_fr *gen);
+int hodor_poly_icoset_fft_for_generator_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
+                                            uint32_t log_n, const hodor_fr *geninv);
 /* LDE: src has 1<<log_n coefficients, dst has (1<<log_n)*factor values; coset != 0 -> coset_lde */
 int hodor_poly_lde_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                        uint32_t log_n, size_t factor, int coset);

@@ -649,6 +649,14 @@ static void scale_chunk(void *vctx, size_t ci, size_t start, size_t len)
     for (size_t i = start; i < start + len; i++) ofr_mul(c->f, &c->a[i], &c->s);
 }
 
+/* coset_fft_for_generator (src/polynomials/mod.rs:633-638) */
+int o_poly_coset_fft_for_generator(const ofield *f, ofr *a, size_t n, const ofr *gen, uint32_t cpus)
+{
+    if (!is_pow2(n)) return -1;
+    o_distribute_powers(f, a, n, gen, cpus);
+    return o_poly_fft(f, a, n, cpus);
+}
+
 int o_poly_ifft(const ofield *f, ofr *a, size_t n, uint32_t cpus)
 {
     odomain d;
@@ -669,6 +677,14 @@ int o_poly_icoset_fft(const ofield *f, ofr *a, size_t n, uint32_t cpus)
     ofr_inverse(f, &geninv, &f->generator);
     if (o_poly_ifft(f, a, n, cpus)) return -1;
     o_distribute_powers(f, a, n, &geninv, cpus);                       /* :800-807 */
+    return 0;
+}
+
+/* icoset_fft_for_generator (src/polynomials/mod.rs:809-815): the caller passes the inverse generator */
+int o_poly_icoset_fft_for_generator(const ofield *f, ofr *a, size_t n, const ofr *geninv, uint32_t cpus)
+{
+    if (o_poly_ifft(f, a, n, cpus)) return -1;
+    o_distribute_powers(f, a, n, geninv, cpus);
     return 0;
 }
 

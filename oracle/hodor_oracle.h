@@ -95,6 +95,8 @@ int o_poly_lde(const ofield *f, const ofr *coeffs, size_t n, size_t factor, int 
  * include/hodor_gpu.h (binary: 0 add 1 sub 2 mul; unary: 0 negate 1 square 2 pow 3 scale 4 add_constant 5 sub_constant) */
 void o_poly_binary(const ofield *f, ofr *a, const ofr *b, size_t n, int op);
 void o_poly_add_scaled(const ofield *f, ofr *a, const ofr *b, size_t n, const ofr *scaling);
+int o_poly_coset_fft_for_generator(const ofield *f, ofr *a, size_t n, const ofr *gen, uint32_t cpus);      /* src/polynomials/mod.rs:633-638 */
+int o_poly_icoset_fft_for_generator(const ofield *f, ofr *a, size_t n, const ofr *geninv, uint32_t cpus);  /* :809-815 */
 int o_poly_degree_one_on_domain(const ofield *f, ofr *out, size_t n, const ofr *alpha, const ofr *c, int coset);   /* src/polynomials/mod.rs:229-290 */
 void o_poly_unary(const ofield *f, ofr *a, size_t n, int op, const ofr *c, uint64_t e);
 int  o_poly_batch_inversion(const ofield *f, ofr *a, size_t n);   /* -1 (a untouched) if any zero, :909 */

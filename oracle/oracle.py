@@ -269,6 +269,18 @@ class Oracle:
         cc = self.fr(c)
         self.L.o_poly_unary(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.c_int(code), C.byref(cc), C.c_uint64(e))
 
+    def poly_coset_fft_for_generator(self, a, gen, cpus=None):
+        g = self.fr(gen)
+        if self.L.o_poly_coset_fft_for_generator(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(g),
+                                                 C.c_uint32(cpus or self.cpus)) != 0:
+            raise ValueError("SynthesisError::Error")
+
+    def poly_icoset_fft_for_generator(self, a, geninv, cpus=None):
+        g = self.fr(geninv)
+        if self.L.o_poly_icoset_fft_for_generator(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(g),
+                                                  C.c_uint32(cpus or self.cpus)) != 0:
+            raise ValueError("SynthesisError::Error")
+
     def poly_degree_one_on_domain(self, n, alpha, c, coset=False):
         """values of q(x) = c + alpha x on the size-n domain (or its coset): src/polynomials/mod.rs:229-290"""
         out = np.zeros((n, 4), dtype=np.uint64)

@@ -51,6 +51,13 @@ static void test_fft_inverse_identity(const Field &F)
     CHECK(back.coeffs == a);
     auto cv = coset_fft(from_coeffs(F, a));
     CHECK(icoset_fft(std::move(cv)).coeffs == a);
+    // any coset generator (coset_fft_for_generator / icoset_fft_for_generator, :633-638, :809-815); with the
+    // field's own generator it is coset_fft
+    const Fr gen = rand_fr(rng, BN256_FR, 1);
+    auto gv = coset_fft_for_generator(from_coeffs(F, a), gen);
+    CHECK(icoset_fft_for_generator(std::move(gv), F.inverse(gen)).coeffs == a);
+    CHECK(coset_fft_for_generator(from_coeffs(F, a), F.multiplicative_generator()).coeffs ==
+          coset_fft(from_coeffs(F, a)).coeffs);
 }
 
 // test_lde_correctness / test_various_ldes (src/polynomials/mod.rs:988-1130):

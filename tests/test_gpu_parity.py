@@ -698,6 +698,41 @@ def test_concurrent_callers_on_one_context(gpu_ctxs, oracles):
     assert sum(r is not None for r in results_fri) == 3
 
 
+@pytest.mark.parametrize("log_n", [0, 1, 5, 10, 13, 17])
+def test_coset_transforms_for_generator(gpu_ctxs, oracles, field_name, log_n):
+    """coset_fft_for_generator / icoset_fft_for_generator (src/polynomials/mod.rs:633-638, :809-815): any coset
+    generator, device and slice API, against the oracle; with the field's own generator they are coset_fft /
+    icoset_fft; the inverse with gen^-1 undoes the forward with gen."""
+    import torch
+    from oracle.oracle import array_to_ints
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    if field_name != "bn256" and log_n > 10:
+        pytest.skip("large cases on the bn256.rs field only")
+    n = 1 << log_n
+    a = O.random_elements(n, 6100 + log_n)
+    gen = array_to_ints(O.random_elements(1, 6200 + log_n))[0]
+    geninv = O.inverse(gen)
+    e = a.copy(); O.poly_coset_fft_for_generator(e, gen)
+    d = torch.from_numpy(a.view(np.int64)).cuda()
+    out = torch.empty_like(d)
+    ctx.poly_coset_fft_for_generator_dev(d, out, log_n, gen); ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), e)
+    h = a.copy(); ctx.poly_coset_fft_for_generator(h, gen)
+    assert np.array_equal(h, e)
+    back = torch.empty_like(d)
+    ctx.poly_icoset_fft_for_generator_dev(out, back, log_n, geninv); ctx.synchronize()
+    assert torch.equal(back, d)
+    e2 = a.copy(); O.poly_icoset_fft_for_generator(e2, geninv)
+    ctx.poly_icoset_fft_for_generator_dev(d, out, log_n, geninv); ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), e2)
+    h = a.copy(); ctx.poly_icoset_fft_for_generator(h, geninv)
+    assert np.array_equal(h, e2)
+    g0 = O.const("generator")
+    e3 = a.copy(); O.poly_coset_fft(e3)
+    ctx.poly_coset_fft_for_generator_dev(d, out, log_n, g0); ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), e3)
+
+
 def test_dev_calls_on_different_streams_are_ordered_on_the_scratch_pool(gpu_ctxs, oracles):
     """`_dev` calls of ONE context on DIFFERENT streams share the context's ping-pong scratch: the library orders
     them on it (the new user's stream waits for what the previous user's stream was given), so interleaved
