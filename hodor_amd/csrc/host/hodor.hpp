@@ -285,6 +285,14 @@ inline Polynomial<Values> filtering_lde(const Polynomial<Coefficients> &p, size_
     return from_values(*p.F, std::move(v));
 }
 
+// coset_filtering_lde (:484-499): distribute_powers(multiplicative_generator), zero-pad, best_lde
+inline Polynomial<Values> coset_filtering_lde(Polynomial<Coefficients> p, size_t factor)
+{
+    if (factor == 1) return coset_fft(std::move(p));
+    p.distribute_powers(p.F->multiplicative_generator());
+    return filtering_lde(p, factor);
+}
+
 typedef std::vector<uint8_t> Hash32;   // [u8; 32]
 
 // src/iop/blake2s_trivial_iop.rs:106-280

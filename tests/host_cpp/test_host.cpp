@@ -81,6 +81,7 @@ static void test_lde_correctness(const Field &F)
     Fr g = F.multiplicative_generator(), x = F.one(), acc = F.zero();
     for (size_t i = 0; i < N; i++) { acc = F.add(acc, F.mul(coeffs[i], x)); x = F.mul(x, g); }
     CHECK(cl.coeffs[0] == acc);
+    CHECK(coset_filtering_lde(from_coeffs(F, coeffs), LDE_FACTOR).coeffs == cl.coeffs);   // :484-499 == :349
     bool threw = false;
     try { lde(poly, 3); } catch (const SynthesisError &) { threw = true; }
     CHECK(threw);
