@@ -298,7 +298,22 @@ def main():
 
     fallback = None
     try:
-        extra_warm = warm_up()
+        try:
+            extra_warm = warm_up()
+        except Exception as exc:   # noqa: BLE001 — first retreat: the same schedule without the cross-step pipeline
+            if not pipelined:
+                raise
+            fallback = "pipelined schedule failed (%s: %s); steps run in strict order" % (type(exc).__name__, str(exc)[:160])
+            pipelined = False
+            holder.pop("pending", None)
+
+            def step():
+                holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
+                holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=log_chunks)
+
+            def drain():
+                pass
+            extra_warm = warm_up()
     except Exception as exc:   # noqa: BLE001 — a failure of the multi-GPU schedule must not lose the whole line
         if args.mode != "sixstep" or world == 1:
             raise
