@@ -186,6 +186,11 @@ def main():
             dist.all_reduce(warm)
             torch.cuda.synchronize()
         finally:
+            try:   # the banner may still sit in the C library's buffer: push it out while fd 1 is parked
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:   # noqa: BLE001
+                pass
             os.dup2(saved, 1)
             os.close(saved)
             os.close(devnull)
