@@ -150,6 +150,9 @@ def main():
         raise SystemExit("refusing to benchmark with tuning variables set (%s); pass --allow-knobs for an "
                          "A/B run" % " ".join("%s=%s" % kv for kv in knobs.items()))
 
+    # the host driver only supports dmabuf IPC: without this RCCL cannot share buffers between the ranks' processes
+    # (already exported on the pool's boxes; set here so that a bare torchrun works too — before HSA initialises)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
