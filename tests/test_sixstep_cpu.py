@@ -53,6 +53,21 @@ def _worker(rank, world, port, log_n, ret):
             ok_b &= np.array_equal(bc.numpy().view(np.uint64), b.numpy().view(np.uint64))
             ac = sixstep_inverse(be, bc, log_n, omega, rank, world, log_chunks=log_chunks)
             ok_a &= np.array_equal(ac.numpy().view(np.uint64), a.numpy().view(np.uint64))
+        # the split-phase form as bench.py pipelines it across steps: forward(i+1) begun, then the inverse of step i
+        # begun, then both finished — two exchanges in flight at once
+        from hodor_amd.sixstep import (sixstep_forward_begin, sixstep_forward_end, sixstep_inverse_begin,
+                                       sixstep_inverse_end)
+        pending = None
+        for it in range(3):
+            f = sixstep_forward_begin(be, a, log_n, omega, rank, world, log_chunks=1)
+            inv = sixstep_inverse_begin(be, pending, log_n, omega, rank, world, log_chunks=1) if pending is not None else None
+            bb = sixstep_forward_end(be, f)
+            ok_b &= np.array_equal(bb.numpy().view(np.uint64), b.numpy().view(np.uint64))
+            if inv is not None:
+                ok_a &= np.array_equal(sixstep_inverse_end(be, inv).numpy().view(np.uint64), a.numpy().view(np.uint64))
+            pending = bb
+        ok_a &= np.array_equal(sixstep_inverse(be, pending, log_n, omega, rank, world, log_chunks=1).numpy().view(np.uint64),
+                               a.numpy().view(np.uint64))
         ret[rank] = (ok_fwd, ok_inv, ok_b, ok_a)
     finally:
         dist.destroy_process_group()
