@@ -22,6 +22,13 @@ digest equals the CPU oracle's committed one (tests/golden/fullsize_digests.json
 distributed output is brought to natural order, gathered on rank 0 and hashed against the oracle's digest
 of the N x 2^24-point transform of the same stream), the LDE+commit root and the FRI prototype bytes equal
 the oracle's, and no HODOR_* tuning variable is set (--allow-knobs overrides and echoes them).
+With N > 1 the line also carries the other half of BASELINE's metric and config[4]: `extra.lde_commit` = LDE x8 of
+2^22 + Merkle commit across the ranks (cosets dealt to the ranks, one all-to-all for the interleave, subtree commit
++ one 32-byte all-gather; gated on the CPU oracle's committed root) and `extra.config4` = ONE un-pipelined transform
+of 2^30 points over the ranks (--big-log-n, default 30 at N = 8) with the exchange rate against the xGMI peak;
+`ms_per_step_strict` is the un-pipelined cost of a step next to the pipelined `ms_per_step`; and if the 4-step
+schedule fails on the node and the ranks retreat to independent replicas the line says so in machine-readable keys
+("scaling": "replicas-fallback", "collective_on_data_path": false).
 `--backend gloo` is a testing aid: ranks may then share one GPU (exchanges staged through the host) so that
 the N > 1 path can be exercised on a single-GPU box; its line is marked as not a measurement.
 
@@ -102,6 +109,20 @@ def cpu_baseline(seconds_budget=20.0):
                            "sample": "one 2^20-point NTT, parallel_fft with the fastest thread count of 1..64"}}
 
 
+KERNEL_SOURCES = ("ntt.hip", "ntt.cuh", "fr.cuh", "fr9.cuh", "fr9w3.cuh", "abi.hip", "ctx.hpp", "knobs.hpp", "Makefile")
+
+
+def kernel_sources_sha256():
+    """sha256 over the sources the dominant kernel and its launch plan are built from (hodor_amd/csrc): what
+    bench/profile.sh stamps into profiles/rNN/pmc_traffic.json and `roofline.traffic` is checked against."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(ROOT, "hodor_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 def digest_host(arr):
     import hashlib
     return hashlib.blake2s(memoryview(arr).cast("B"), digest_size=32).hexdigest()
@@ -128,11 +149,21 @@ def main():
                          "testing aid that stages every exchange through the host, so that several ranks can share "
                          "ONE GPU and the whole multi-rank path can be exercised on a single-GPU box (the line is "
                          "then marked \"backend\": \"gloo\" and is not a measurement)")
+    ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
+                    help="who runs the all-to-alls of the 4-step schedule: 'torch' = torch.distributed (all_to_all_single, "
+                         "async); 'native' = the library's own exchange behind the C ABI (hodor_sixstep_exchange_dev: "
+                         "grouped ncclSend/ncclRecv on a communicator and communication stream it owns — what a Rust "
+                         "caller links); needs RCCL and one GPU per rank")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sixstep with collectives: finish each step's inverse transform before the next step's forward "
                          "transform starts (default: the inverse of step i and the forward of step i+1 — independent, "
                          "both read-only on the input — are interleaved so that the exchange of one runs behind the "
                          "arithmetic of the other; K timed steps are still K forward + K inverse transforms)")
+    ap.add_argument("--big-log-n", type=int, default=None,
+                    help="N > 1: log2 of the ONE transform of `extra.config4` (BASELINE config[4]: 2^30 points over "
+                         "8 GPUs, strict order, 8 chunks per exchange); default 30 at N = 8 on RCCL, 0 (= skip) otherwise")
+    ap.add_argument("--strict-steps", type=int, default=10,
+                    help="N > 1, pipelined: number of steps of the strict-order (un-pipelined) timing reported beside it")
     ap.add_argument("--force-collectives", action="store_true",
                     help="testing aid: issue the RCCL all-to-alls even at world size 1 (needs a torchrun launch)")
     ap.add_argument("--allow-knobs", action="store_true",
@@ -153,6 +184,7 @@ def main():
     # the host driver only supports dmabuf IPC: without this RCCL cannot share buffers between the ranks' processes
     # (already exported on the pool's boxes; set here so that a bare torchrun works too — before HSA initialises)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: the control group below never leaves it
     import torch
     import torch.distributed as dist
 
@@ -166,11 +198,11 @@ def main():
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()          # ranks may share a device
     torch.cuda.set_device(local_rank)
-    ctl_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the control all-reduces live
+    ctl = {"dev": "cuda" if args.backend == "nccl" else "cpu", "group": None}   # where the control all-reduces live
 
     def all_reduce_scalar(v, op):
-        t = torch.tensor([v], device=ctl_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=op)
+        t = torch.tensor([v], device=ctl["dev"], dtype=torch.float64)
+        dist.all_reduce(t, op=op, group=ctl["group"])
         return float(t.item())
 
     if world > 1 or "RANK" in os.environ:
@@ -185,9 +217,23 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:
                 dist.init_process_group("gloo")
-            warm = torch.zeros(1, device=ctl_dev)
+            warm = torch.zeros(1, device=ctl["dev"])
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            if args.backend == "nccl" and world > 1:
+                # verdicts and retreat decisions travel on a host-side (gloo) group of their own: they must still get
+                # through when the RCCL communicator is what failed, and must not queue behind its pending exchanges
+                g, have = None, 1.0
+                try:
+                    g = dist.new_group(backend="gloo")
+                    probe = torch.zeros(1)
+                    dist.all_reduce(probe, group=g)
+                except Exception:   # noqa: BLE001 — no usable host interface: control stays on RCCL
+                    have = 0.0
+                flag = torch.tensor([have], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # every rank or none
+                if flag.item() > 0.5:
+                    ctl["dev"], ctl["group"] = "cpu", g
         finally:
             try:   # the banner may still sit in the C library's buffer: push it out while fd 1 is parked
                 import ctypes
@@ -219,6 +265,7 @@ def main():
     side.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
+    holder = {}
 
     if args.mode == "sixstep":
         # ONE transform of world * 2^log_n points: rank q holds column block q of the N1 x N2 input matrix
@@ -231,8 +278,12 @@ def main():
         log_total = log_n + (world.bit_length() - 1)
         assert 1 << (world.bit_length() - 1) == world, "sixstep needs a power-of-two world size"
         omega = ctx.domain(1 << log_total)[2]
-        be = HipBackend(ctx, stream=stream)
-        holder = {}
+        native = None
+        if args.exchange == "native" and (world > 1 or args.force_collectives):
+            if args.backend != "nccl":
+                raise SystemExit("--exchange native needs one GPU per rank (RCCL); the gloo aid shares one device")
+            native = hodor_amd.Exchange.over_process_group(ctx, rank, world, group=ctl["group"])
+        be = HipBackend(ctx, stream=stream, exchange=native)
         if world > 1:
             # the generator's natural block -> this rank's column block (layout A): pack + one exchange, untimed
             from hodor_amd.sixstep import natural_to_a
@@ -245,46 +296,56 @@ def main():
         log_chunks = chunks.bit_length() - 1
         assert 1 << log_chunks == chunks, "--exchange-chunks must be a power of two"
 
-        if pipelined:
-            # Software pipeline across steps: forward(i+1) does not depend on inverse(i) (every step transforms the
-            # same input), so the two are interleaved — columns(i+1) + its exchange, inverse rows(i) + its exchange,
-            # rows(i+1), inverse columns(i) — and each all-to-all runs behind the other transform's arithmetic as
-            # well as behind its own chunks.  drain() finishes the inverse that is still pending.
-            from hodor_amd.sixstep import (sixstep_forward_begin, sixstep_forward_end, sixstep_inverse_begin,
-                                           sixstep_inverse_end)
+        from hodor_amd.sixstep import (sixstep_forward_begin, sixstep_forward_end, sixstep_inverse_begin,
+                                       sixstep_inverse_end)
 
-            def step():
-                f = sixstep_forward_begin(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
-                prev = holder.pop("pending", None)
-                inv = (sixstep_inverse_begin(be, prev, log_total, omega, rank, world, log_chunks=log_chunks)
-                       if prev is not None else None)
-                holder["b"] = sixstep_forward_end(be, f)
-                if inv is not None:
-                    holder["c"] = sixstep_inverse_end(be, inv)
-                holder["pending"] = holder["b"]
+        def make_steps(pipe, lc):
+            """(step, drain) of the 4-step schedule with 2^lc chunks per exchange.  pipe: software pipeline across
+            steps — forward(i+1) does not depend on inverse(i) (every step transforms the same input), so the two are
+            interleaved: columns(i+1) + its exchange, inverse rows(i) + its exchange, rows(i+1), inverse columns(i) —
+            and each all-to-all runs behind the other transform's arithmetic as well as behind its own chunks;
+            drain() finishes the inverse that is still pending.  Strict order otherwise."""
+            if pipe:
+                def step():
+                    f = sixstep_forward_begin(be, a, log_total, omega, rank, world, log_chunks=lc)
+                    prev = holder.pop("pending", None)
+                    inv = (sixstep_inverse_begin(be, prev, log_total, omega, rank, world, log_chunks=lc)
+                           if prev is not None else None)
+                    holder["b"] = sixstep_forward_end(be, f)
+                    if inv is not None:
+                        holder["c"] = sixstep_inverse_end(be, inv)
+                    holder["pending"] = holder["b"]
 
-            def drain():
-                prev = holder.pop("pending", None)
-                if prev is not None:
-                    holder["c"] = sixstep_inverse(be, prev, log_total, omega, rank, world, log_chunks=log_chunks)
-        else:
-            def step():
-                holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
-                holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=log_chunks)
+                def drain():
+                    prev = holder.pop("pending", None)
+                    if prev is not None:
+                        holder["c"] = sixstep_inverse(be, prev, log_total, omega, rank, world, log_chunks=lc)
+            else:
+                def step():
+                    holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=lc)
+                    holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=lc)
 
-            def drain():
-                pass
+                def drain():
+                    pass
+            return step, drain
+
+        step, drain = make_steps(pipelined, log_chunks)
     else:
         pipelined = False
 
+    def replica_steps():
         def step():
             ctx.poly_fft_dev(a, b, log_n, stream=stream)
             ctx.poly_ifft_dev(b, c, log_n, stream=stream)
 
         def drain():
             pass
+        return step, drain
 
-    def warm_up():
+    if args.mode != "sixstep":
+        step, drain = replica_steps()
+
+    def warm_up(step, drain):
         """The W requested steps, then as many more as it takes to have the GPU under load for WARM_MS.  The
         number of extra steps is agreed between the ranks (max of the elapsed times): a per-rank time-based
         loop would let the ranks issue different numbers of collectives."""
@@ -304,39 +365,46 @@ def main():
         torch.cuda.synchronize()
         return extra
 
-    fallback = None
-    try:
+    def attempt(step, drain):
+        """warm_up with the verdict agreed between the ranks: a schedule is kept only if it ran on EVERY rank (a rank
+        that retreated alone would stop issuing the collectives the others wait in).  Returns (extra steps, error
+        text or None)."""
+        err, extra = None, 0
         try:
-            extra_warm = warm_up()
-        except Exception as exc:   # noqa: BLE001 — first retreat: the same schedule without the cross-step pipeline
-            if not pipelined:
-                raise
-            fallback = "pipelined schedule failed (%s: %s); steps run in strict order" % (type(exc).__name__, str(exc)[:160])
-            pipelined = False
+            extra = warm_up(step, drain)
+        except Exception as exc:   # noqa: BLE001
+            err = "%s: %s" % (type(exc).__name__, str(exc)[:160])
+        failed = 1.0 if err else 0.0
+        if world > 1:
+            failed = all_reduce_scalar(failed, dist.ReduceOp.MAX)
+        if failed > 0.5 and err is None:
+            err = "failed on another rank"
+        if failed > 0.5:
             holder.pop("pending", None)
-
-            def step():
-                holder["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
-                holder["c"] = sixstep_inverse(be, holder["b"], log_total, omega, rank, world, log_chunks=log_chunks)
-
-            def drain():
+            try:                   # nothing of the abandoned schedule may still be in flight when the next one starts
+                torch.cuda.synchronize()
+            except Exception:   # noqa: BLE001
                 pass
-            extra_warm = warm_up()
-    except Exception as exc:   # noqa: BLE001 — a failure of the multi-GPU schedule must not lose the whole line
-        if args.mode != "sixstep" or world == 1:
-            raise
-        fallback = "sixstep failed on this node (%s: %s); every rank transformed its own polynomial instead" % (
-            type(exc).__name__, str(exc)[:200])
-        args.mode = "replicas"
+        return extra, (err if failed > 0.5 else None)
 
-        def step():
-            ctx.poly_fft_dev(a, b, log_n, stream=stream)
-            ctx.poly_ifft_dev(b, c, log_n, stream=stream)
-
-        def drain():
-            pass
+    fallback = None
+    extra_warm, err = attempt(step, drain)
+    if err and args.mode == "sixstep" and pipelined:
+        # first retreat: the same schedule without the cross-step pipeline
+        fallback = "pipelined schedule failed (%s); steps run in strict order" % err
         pipelined = False
-        extra_warm = warm_up()
+        step, drain = make_steps(False, log_chunks)
+        extra_warm, err = attempt(step, drain)
+    if err and args.mode == "sixstep" and world > 1:
+        # second retreat — a failure of the multi-GPU schedule must not lose the whole line, but the line then says in
+        # machine-readable keys that no collective carried the data ("scaling": "replicas-fallback")
+        fallback = "sixstep failed on this node (%s); every rank transformed its own polynomial instead" % err
+        args.mode = "replicas"
+        pipelined = False
+        step, drain = replica_steps()
+        extra_warm, err = attempt(step, drain)
+    if err:
+        raise SystemExit("the benchmark step fails: %s" % err)
     if args.mode == "sixstep":
         c = holder["c"]
     # correctness gates (outside the timed region): the round trip, and — where the CPU oracle's answer
@@ -378,6 +446,30 @@ def main():
     if world > 1:
         dt = all_reduce_scalar(dt, dist.ReduceOp.MAX)
 
+    def timed(step, drain, steps):
+        """`steps` steps between barrier + synchronize on both sides, max over the ranks, in ms per step."""
+        barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        barrier()
+        d = time.perf_counter() - t
+        if world > 1:
+            d = all_reduce_scalar(d, dist.ReduceOp.MAX)
+        return d / steps * 1e3
+
+    # what ONE forward + inverse transform costs end to end when nothing of another step overlaps it: the same
+    # schedule in strict order, a few steps, reported beside the pipelined figure (equal to it when the measured
+    # schedule already is strict)
+    ms_strict = dt / args.steps * 1e3
+    if args.mode == "sixstep" and pipelined and args.strict_steps > 0:
+        s_step, s_drain = make_steps(False, log_chunks)
+        s_step()
+        ms_strict = timed(s_step, s_drain, args.strict_steps)
+
     exchange = None
     if args.mode == "sixstep":
         # the exchange alone, timed apart from the step: bytes each rank puts on xGMI per transform and the
@@ -394,7 +486,9 @@ def main():
         torch.cuda.synchronize()
         sent = n * 32 * (world - 1) / world
         ms = e0.elapsed_time(e1) / reps
-        exchange = {"all_to_alls_per_transform": 1, "chunks_per_all_to_all": chunks,
+        exchange = {"transport": ("C ABI: hodor_sixstep_exchange_dev (grouped ncclSend/ncclRecv on the library's stream)"
+                                  if native is not None else "torch.distributed all_to_all_single (async)"),
+                    "all_to_alls_per_transform": 1, "chunks_per_all_to_all": chunks,
                     "bytes_sent_per_rank_per_transform": sent,
                     "all_to_all_ms_unoverlapped": ms, "gb_per_s_per_rank": (sent / (ms * 1e-3) / 1e9) if world > 1 else None,
                     "share_of_step": 2 * ms / (dt / args.steps * 1e3) if world > 1 else 0.0}
@@ -441,7 +535,9 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "replicas-fallback" if fallback and args.mode == "replicas" else "weak",
+        "mode": args.mode if world > 1 or args.mode == "sixstep" else "single",
+        "collective_on_data_path": bool(args.mode == "sixstep" and (world > 1 or args.force_collectives)),
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
@@ -460,8 +556,9 @@ def main():
         "knobs": knobs,
         "warmup_extra_steps": extra_warm,
     }
-    if pipelined:
-        result["pipelined_across_steps"] = True
+    if args.mode == "sixstep":
+        result["pipelined_across_steps"] = bool(pipelined)
+        result["ms_per_step_strict"] = ms_strict      # un-pipelined: one NTT + iNTT end to end, exchanges hidden only behind their own chunks
     if args.backend != "nccl":
         result["backend"] = args.backend + " (exchanges staged through the host: a test of the multi-rank path, not a measurement)"
     if fallback:
@@ -483,13 +580,23 @@ def main():
         avg_launch_ms = kernel_ms / launches
         alg_bytes_per_launch = 2.0 * n * 32 / passes
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = profiled_ms = None   # from the committed rocprofv3 passes of the same command (not live)
+        # HBM traffic and the kernel-trace launch time come from the committed rocprofv3 passes of the same command
+        # (bench/profile.sh; counters cannot be read from inside the process).  They are quoted only if that profile
+        # was taken from THIS build: profile.sh stamps the sha256 of the kernel's sources into pmc_traffic.json and the
+        # line carries "traffic": null, "traffic_stale": true when they have changed since.
+        traffic = profiled_ms = None
+        traffic_stale = None
         try:
-            pmcs = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r"))
+            pmcs = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r")
+                          and os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_traffic.json")))
             t = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1], "pmc_traffic.json")))
             if t.get("log_n") == log_n and args.mode == "replicas":
-                traffic = t["hbm_bytes_per_launch"]
-                profiled_ms = t.get("kernel_trace_avg_launch_ms")
+                if t.get("sources_sha256") == kernel_sources_sha256():
+                    traffic = t["hbm_bytes_per_launch"]
+                    profiled_ms = t.get("kernel_trace_avg_launch_ms")
+                    traffic_stale = False
+                else:
+                    traffic_stale = True
         except Exception:
             pass
         # the resource that actually binds: v_mad_u64_u32 issue.  Products per element and transform =
@@ -504,7 +611,7 @@ def main():
         mad_floor_ms = n * (products * 108 + 9 * passes) / (MAD_PEAK_TOPS * 1e12) * 1e3
         hbm_target_ms = 2.0 * n * 32 / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
                               "kernel": "k_ntt_pass", "avg_launch_ms": avg_launch_ms,
                               "rocprofv3_avg_launch_ms": profiled_ms,
                               "launches_per_transform": passes,
@@ -528,20 +635,32 @@ def main():
             result["extra"] = extra_lde_commit(ctx, torch, stream)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
+    if world > 1 and not args.no_extra:
+        # the other half of BASELINE's metric and config[4], every rank takes part (collectives inside)
+        del b, c
+        holder.clear()
+        torch.cuda.empty_cache()
+        extra = {}
+        try:
+            extra["lde_commit"] = extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_reduce_scalar, barrier)
+        except SystemExit:
+            raise
+        except Exception as exc:   # noqa: BLE001
+            extra["lde_commit"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        big = args.big_log_n if args.big_log_n is not None else (30 if (world == 8 and args.backend == "nccl") else 0)
+        if big and args.mode == "sixstep":
+            try:
+                extra["config4"] = extra_config4(ctx, torch, dist, stream, rank, world, big, all_reduce_scalar, barrier,
+                                                 args.backend, ctl["group"])
+            except SystemExit:
+                raise
+            except Exception as exc:   # noqa: BLE001
+                extra["config4"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        result["extra"] = extra
+    if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()
-
-
-def random_elements(torch, n, seed):
-    """n random elements of the src/bn256.rs field as (n, 4) int64 limbs on the current device:
-    three uniform 64-bit limbs and a top limb below floor(p / 2^224) * 2^32, hence value < p."""
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
-    out[:, :3] = torch.randint(-2**63, 2**63 - 1, (n, 3), dtype=torch.int64, device="cuda", generator=g)
-    out[:, 3] = torch.randint(0, 0x73EDA753 << 32, (n,), dtype=torch.int64, device="cuda", generator=g)
-    return out
 
 
 def extra_lde_commit(ctx, torch, stream):
@@ -587,6 +706,174 @@ def extra_lde_commit(ctx, torch, stream):
            "root": root, "root_equals_cpu_oracle": True}
     del lde, nodes, coeffs
     out["fri_commit"] = extra_fri_commit(ctx, torch, stream)
+    return out
+
+
+XGMI_PEAK_GBS_PER_RANK = 7 * 153.0     # seven xGMI links per GPU, one to every peer of the node (MI355X_MICROARCH.md)
+
+
+def extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_reduce_scalar, barrier):
+    """config[2] across the node — the second half of BASELINE's metric at N > 1: LDE x8 of the 2^22-coefficient
+    polynomial + IOP Merkle commit with the cosets dealt to the ranks (the reference's own LDE schedule,
+    /root/reference/src/polynomials/mod.rs:446-460, interleave :466-479 = ONE all-to-all) and the tree built by
+    subtrees (one 32-byte all-gather, top log2(N) levels replicated).  Strong scaling: the workload is config[2]'s
+    whatever N.  Printed only if the root equals the CPU oracle's committed root of the single-device LDE + tree."""
+    from hodor_amd.distributed import HipTreeBackend, lde_commit_by_cosets_distributed
+    from hodor_amd.sixstep import HipBackend
+    fx = FIXTURES["lde"][str(LDE_LOG_N)]
+    assert fx["factor"] == LDE_FACTOR
+    if LDE_FACTOR % world:
+        return {"skipped": "the world size must divide the LDE factor %d" % LDE_FACTOR}
+    n = 1 << LDE_LOG_N
+    big = n * LDE_FACTOR
+    coeffs = torch.empty((n, 4), dtype=torch.int64, device="cuda")       # replicated: 1/8 of the output
+    ctx.gen_elements_dev(coeffs, 0, n, fx["seed"], stream=stream)
+    omega_big = ctx.domain(big)[2]
+    nb, tb = HipBackend(ctx, stream=stream), HipTreeBackend(ctx, stream=stream)
+
+    def run():
+        return lde_commit_by_cosets_distributed(nb, tb, coeffs, LDE_LOG_N, LDE_FACTOR, omega_big, rank, world)
+
+    _, root, _, _ = run()
+    torch.cuda.synchronize()
+    good = 1.0 if bytes(root).hex() == fx["root"] else 0.0
+    if all_reduce_scalar(good, dist.ReduceOp.MIN) < 0.5:
+        raise SystemExit("LDE x8 + commit over %d ranks: Merkle root differs from the CPU oracle's — refusing to report" % world)
+    reps, total = 5, 0.0
+    for _ in range(reps):
+        barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = run()
+        torch.cuda.synchronize()
+        barrier()
+        total += all_reduce_scalar(time.perf_counter() - t, dist.ReduceOp.MAX)
+        del out
+    ms = total / reps * 1e3
+    alg_bytes = n * 32 + big * 32 + big * 32      # SURVEY §8d: read coeffs + write LDE + write nodes, whole job
+    return {"workload": "LDE x8 of 2^22 + BLAKE2s Merkle commit (BASELINE config[2]) over %d ranks: cosets dealt to the "
+                        "ranks, one all-to-all interleave, subtree commit + 32-byte all-gather" % world,
+            "scaling": "strong", "ms": ms,
+            "lde_commit_gib_per_s": alg_bytes / 2**30 / (ms * 1e-3),
+            "hbm_frac_per_rank": alg_bytes / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "bytes_sent_per_rank": big * 32 / world * (world - 1) / world,
+            "root": bytes(root).hex(), "root_equals_cpu_oracle": True}
+
+
+def extra_config4(ctx, torch, dist, stream, rank, world, log_total, all_reduce_scalar, barrier, backend, ctl_group):
+    """BASELINE config[4]: ONE transform of 2^log_total points (2^30 on 8 GPUs) over the ranks, strict order (no
+    overlap with any other transform), 8 chunks per exchange; forward (A -> B) and inverse (B -> A) timed together
+    like a step of the headline.  Gates: the inverse returns the input on every rank; output points against the
+    direct evaluation sum_i x[i] w^(ik) with the partial sums of the ranks' natural blocks combined on the host
+    (hodor_poly_evaluate_at_dev — another kernel and another table format than the transform, but the same
+    library: the element-for-element comparison of this shape with the single-device transform, itself anchored on
+    the CPU oracle, is tests/test_gpu_sixstep.py::test_config4_2_30_points_over_8_ranks_at_full_size); and, where the
+    CPU oracle's digest of this size is committed (<= 2^29), every element through the gathered digest."""
+    from hodor_amd.sixstep import (HipBackend, all_to_all_slabs, b_to_natural, natural_to_a, sixstep_forward,
+                                   sixstep_inverse, split_logs)
+    log_p = world.bit_length() - 1
+    log_m = log_total - log_p
+    m = 1 << log_m
+    free, _ = torch.cuda.mem_get_info()
+    if free < 7.5 * m * 32:
+        return {"skipped": "not enough free HBM for 2^%d points per rank" % log_m}
+    be = HipBackend(ctx, stream=stream)
+    fx = FIXTURES["ntt"].get(str(log_total))
+    seed = fx["seed"] if fx else 0x484F444F52
+    omega = ctx.domain(1 << log_total)[2]
+    x = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(x, rank * m, m, seed, stream=stream)              # natural block `rank` of the ONE input
+    # direct evaluation of two output points from the natural blocks: X[k] = sum_r w^(k r m) * sum_j x_r[j] (w^k)^j
+    l1, l2 = split_logs(log_total)
+    n1, r1 = 1 << l1, (1 << l1) >> log_p
+    points = [5, ((1 << log_total) // 7) * 4 + 3]
+    partial = []
+    for k in points:
+        wk = ctx.pow(omega, k)
+        part = ctx.poly_evaluate_at_dev(x, m, wk, stream=stream)
+        partial.append(ctx.mul(part, ctx.pow(wk, rank * m)))
+    a = natural_to_a(be, x, log_total, rank, world)
+    del x
+    torch.cuda.synchronize()
+    log_chunks = min(3, l2 - log_p, l1 - log_p)
+    hold = {}
+
+    def step():
+        hold["b"] = sixstep_forward(be, a, log_total, omega, rank, world, log_chunks=log_chunks)
+        hold["c"] = sixstep_inverse(be, hold["b"], log_total, omega, rank, world, log_chunks=log_chunks)
+
+    step()
+    torch.cuda.synchronize()
+    ok = 1.0 if torch.equal(hold["c"], a) else 0.0
+    # the checked points as this rank's layout B holds them: b[i][k2] = X[(rank*r1 + i) + N1*k2]
+    mine = []
+    for k in points:
+        k1, k2 = k % n1, k // n1
+        if k1 // r1 == rank:
+            idx = (k1 % r1) * (1 << l2) + k2
+            mine.append(hold["b"][idx].cpu().numpy().view("uint64").tolist())
+        else:
+            mine.append([0, 0, 0, 0])
+    # gather partial sums and the owners' values on every rank (32-byte scalars, host side)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"partial": partial, "mine": mine}, group=ctl_group)
+    for j, k in enumerate(points):
+        total = 0
+        for g in gathered:
+            total = ctx.add(total, g["partial"][j])
+        owner = (k % n1) // r1
+        got = sum(int(v) << (64 * i) for i, v in enumerate(gathered[owner]["mine"][j]))
+        if got != total:
+            ok = 0.0
+    if all_reduce_scalar(ok, dist.ReduceOp.MIN) < 0.5:
+        raise SystemExit("config[4]: the 2^%d-point transform over %d ranks fails its checks — refusing to report" % (log_total, world))
+    checks = {"roundtrip": True, "output_points_vs_direct_evaluation": len(points)}
+    reps = 3
+    barrier()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ms = all_reduce_scalar(time.perf_counter() - t, dist.ReduceOp.MAX) / reps * 1e3
+    # the exchange alone: one all-to-all of this size with nothing else running
+    all_to_all_slabs(hold["b"], world)
+    torch.cuda.synchronize()
+    barrier()
+    t = time.perf_counter()
+    for _ in range(reps):
+        all_to_all_slabs(hold["b"], world)
+    torch.cuda.synchronize()
+    ex_ms = all_reduce_scalar(time.perf_counter() - t, dist.ReduceOp.MAX) / reps * 1e3
+    sent = m * 32 * (world - 1) / world
+    out = {"workload": "ONE 2^%d-point NTT + iNTT over %d ranks (BASELINE config[4]), 2^%d x 2^%d, layouts A -> B -> A, "
+                       "strict order, %d chunks per exchange" % (log_total, world, l1, l2, 1 << log_chunks),
+           "ms_per_transform_pair": ms, "field_elems_per_s": 2.0 * (1 << log_total) / (ms * 1e-3),
+           "hbm_frac_per_rank": 2.0 * 2 * m * 32 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "exchange": {"bytes_sent_per_rank_per_transform": sent, "all_to_all_ms_unoverlapped": ex_ms,
+                        "gb_per_s_per_rank": sent / (ex_ms * 1e-3) / 1e9,
+                        "xgmi_peak_gb_per_s_per_rank": XGMI_PEAK_GBS_PER_RANK,
+                        "frac_of_xgmi_peak": sent / (ex_ms * 1e-3) / 1e9 / XGMI_PEAK_GBS_PER_RANK,
+                        "share_of_transform_pair_if_not_hidden": 2 * ex_ms / ms},
+           "checks": checks}
+    if backend != "nccl":
+        out["exchange"]["note"] = "staged through the host over gloo: not a measurement"
+    if fx:   # every element: layout B -> natural blocks (one more exchange), gathered on rank 0, hashed
+        nat = b_to_natural(be, hold["b"], log_total, rank, world)
+        torch.cuda.synchronize()
+        if backend == "nccl":
+            parts = [torch.empty_like(nat) for _ in range(world)] if rank == 0 else None
+            dist.gather(nat, parts, dst=0)
+        else:
+            parts = [torch.empty(nat.shape, dtype=nat.dtype) for _ in range(world)] if rank == 0 else None
+            dist.gather(nat.cpu(), parts, dst=0)
+        good = 1.0
+        if rank == 0:
+            good = 1.0 if digest(torch.cat([p.to(nat.device) for p in parts])) == fx["fft"] else 0.0
+        if all_reduce_scalar(good, dist.ReduceOp.MIN) < 0.5:
+            raise SystemExit("config[4]: forward transform differs from the CPU oracle's committed digest — refusing to report")
+        out["checks"]["fft_digest_vs_cpu_oracle"] = True
     return out
 
 

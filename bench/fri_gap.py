@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hodor_amd
-from bench import random_elements
+from inputs import random_elements
 log_code = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ctx = hodor_amd.Context(device=0)
 f = 8

@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hodor_amd
-from bench import random_elements
+from inputs import random_elements
 ctx = hodor_amd.Context(device=0)
 f = 8
 for log_deg in (5, 9, 11, 13, 15, 17, 19, 21, 23):

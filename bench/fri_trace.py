@@ -1,7 +1,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hodor_amd
-from bench import random_elements
+from inputs import random_elements
 ctx = hodor_amd.Context(device=0)
 log_deg, f = 23, 8
 n = (1 << log_deg) * f

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hodor_amd
-from bench import random_elements  # noqa
+from inputs import random_elements  # noqa
 
 ctx = hodor_amd.Context(device=0)
 def timeit(f, reps=20):

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hodor_amd
-from bench import random_elements
+from inputs import random_elements
 ctx = hodor_amd.Context(device=0)
 n = 1 << 24
 a = random_elements(torch, n, 1); b = random_elements(torch, n, 2)

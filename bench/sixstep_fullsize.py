@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(ctx, log_n, world, log_chunks, verbose=True):
+def run(ctx, log_n, world, log_chunks, verbose=True, check=None, seed=0x484F444F52):
     import torch
 
     from hodor_amd.sixstep import HipBackend, split_logs
@@ -28,12 +28,14 @@ def run(ctx, log_n, world, log_chunks, verbose=True):
     K = 1 << log_chunks
     omega = ctx.domain(n)[2]
     x = torch.empty((n, 4), dtype=torch.int64, device="cuda")
-    ctx.gen_elements_dev(x, 0, n, 0x484F444F52)
+    ctx.gen_elements_dev(x, 0, n, seed)
     y = torch.empty_like(x)
     t0 = time.perf_counter()
     ctx.poly_fft_dev(x, y, log_n)
     ctx.synchronize()
     t_direct = time.perf_counter() - t0
+    if check is not None:      # e.g. output points of the single-device transform by direct evaluation on the CPU oracle
+        check(x, y, omega)
     xm, ym = x.view(n1, n2, 4), y.view(n2, n1, 4)          # x[n1*N2 + n2];  X[k1 + N1*k2] = ym[k2][k1]
 
     def exchange(send, t):

@@ -3,7 +3,7 @@ Catches intermittent races (the fused kernels hand data between phases through L
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hodor_amd
-from bench import random_elements
+from inputs import random_elements
 ctx = hodor_amd.Context(device=0)
 bad = 0
 for log_code in (4, 6, 9, 10, 11, 12, 13, 16, 19, 20, 21):

@@ -2,7 +2,7 @@
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hodor_amd
-from bench import random_elements
+from inputs import random_elements
 ctx = hodor_amd.Context(device=0)
 bad = 0
 for log_code in (22, 24, 26):

@@ -47,7 +47,9 @@ EXPORTS = [
     "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
-    "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_prototype",
+    "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_proof_strict", "hodor_fri_verify_prototype",
+    "hodor_exchange_available", "hodor_exchange_unique_id", "hodor_exchange_create", "hodor_exchange_adopt",
+    "hodor_exchange_destroy", "hodor_sixstep_exchange_dev", "hodor_sixstep_exchange_wait_dev",
 ]
 
 
@@ -109,6 +111,7 @@ def lib():
         _lib.hodor_transcript_free.restype = None
         _lib.hodor_ctx_destroy.restype = None
         _lib.hodor_fri_free.restype = None
+        _lib.hodor_exchange_destroy.restype = None
     return _lib
 
 
@@ -265,6 +268,61 @@ class Transcript:
             if self.h:
                 self.ctx.L.hodor_transcript_free(self.h)
                 self.h = None
+        except Exception:
+            pass
+
+
+class Exchange:
+    """hodor_exchange: the all-to-all of the 4-step transform on a communicator and a communication stream the
+    library owns (csrc/abi_exchange.hip: grouped ncclSend/ncclRecv, RCCL bound at run time).  The unique id has to
+    reach every rank by a channel of the caller's: `Exchange.over_process_group` uses torch.distributed for that one
+    broadcast and nothing else."""
+
+    def __init__(self, ctx, unique_id, n_ranks, rank):
+        self.ctx, self.n_ranks, self.rank = ctx, n_ranks, rank
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        ctx._chk(ctx.L.hodor_exchange_create(ctx.h, buf, C.c_uint32(n_ranks), C.c_uint32(rank), C.byref(self.h)))
+
+    @staticmethod
+    def available():
+        return bool(lib().hodor_exchange_available())
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = lib().hodor_exchange_unique_id(buf)
+        if rc != OK:
+            raise HodorError(rc, "hodor_exchange_unique_id (librccl not available?)")
+        return bytes(buf)
+
+    @classmethod
+    def over_process_group(cls, ctx, rank, world, group=None):
+        """Rank 0 draws the id, torch.distributed carries the 128 bytes to the others, every rank joins."""
+        import torch.distributed as dist
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(ctx, box[0], world, rank)
+
+    def exchange(self, send, recv, log_chunks=0, chunk=0, stream=None):
+        """Chunk `chunk` of 2^log_chunks of the (n_local, 4) buffers goes on the wire behind everything enqueued on
+        `stream` so far; `stream` does not wait (see wait)."""
+        self.ctx._chk(self.ctx.L.hodor_sixstep_exchange_dev(self.h, C.c_void_p(stream), _dptr(send), _dptr(recv),
+                                                            C.c_size_t(send.shape[0]), C.c_uint32(log_chunks),
+                                                            C.c_uint32(chunk)))
+
+    def wait(self, stream=None):
+        self.ctx._chk(self.ctx.L.hodor_sixstep_exchange_wait_dev(self.h, C.c_void_p(stream)))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.hodor_exchange_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
@@ -517,6 +575,15 @@ class Context:
         ev, ok = _fr(expected_value), C.c_int(0)
         self._chk(self.L.hodor_fri_verify_proof(self.h, buf, C.c_size_t(len(raw)), C.c_size_t(natural_index),
                                                 C.byref(ev), C.byref(ok)))
+        return bool(ok.value)
+
+    def fri_verify_proof_strict(self, raw, domain_size, natural_index, expected_value):
+        """hodor_fri_verify_proof_strict: the verifier above, refusing (False) every proof whose round / query /
+        final-coefficient counts or path lengths are not those of a proof over `domain_size` points."""
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        ev, ok = _fr(expected_value), C.c_int(0)
+        self._chk(self.L.hodor_fri_verify_proof_strict(self.h, buf, C.c_size_t(len(raw)), C.c_size_t(domain_size),
+                                                       C.c_size_t(natural_index), C.byref(ev), C.byref(ok)))
         return bool(ok.value)
 
     def poly_binary_dev(self, a, b, n, op, stream=None):

@@ -192,20 +192,14 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
     return hipSuccess;
 }
 
-// Caller holds ctx->mu.  `user`: the stream whose work is about to use the pool.  The previous user's work
-// was enqueued completely (under the same mutex) on its own stream; if that is a different stream, the new
-// one is made to wait for it, so calls on different streams are ordered on the pool instead of racing for it.
+// Caller holds ctx->mu.  `user`: the stream whose work is about to use the pool.  Every call that uses the pool
+// ends by recording ctx->scratch_ev on its own stream (ScratchUse below) — while that stream is certainly alive —
+// and the next user, if it runs on a different stream, waits for that event: calls on different streams are
+// ordered on the pool instead of racing for it, and no stream handle is ever touched after its call returned.
 int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes, hipStream_t user)
 {
-    if (ctx->scratch_owned && ctx->scratch_owner != user) {
-        if (!ctx->scratch_ev) HIPCHK(hipEventCreateWithFlags(&ctx->scratch_ev, hipEventDisableTiming));
-        if (hipEventRecord(ctx->scratch_ev, ctx->scratch_owner) == hipSuccess) {
-            HIPCHK(hipStreamWaitEvent(user, ctx->scratch_ev, 0));
-        } else {                       // the previous user's stream no longer exists: nothing finer to wait on
-            (void)hipGetLastError();
-            HIPCHK(hipDeviceSynchronize());
-        }
-    }
+    if (ctx->scratch_owned && ctx->scratch_owner != user && ctx->scratch_ev_recorded)
+        HIPCHK(hipStreamWaitEvent(user, ctx->scratch_ev, 0));
     ctx->scratch_owner = user;
     ctx->scratch_owned = true;
     if (ctx->scratch_bytes[which] >= bytes) return HODOR_OK;
@@ -274,11 +268,13 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
     // ping-pong buffers: the last pass writes dst; a pass never runs in place unless it is the only
     // one (a single tile is fully staged in LDS before anything is written back).
     std::vector<uint4 *> outs(passes);
+    ScratchUse pool;
     if (passes == 1) {
         outs[0] = dst;
     } else {
         bool in_place = (src == dst);
         if ((rc = ensure_scratch(ctx, 0, bytes, stream))) return rc;
+        pool.arm(ctx, stream);
         uint4 *s0 = (uint4 *)ctx->scratch[0], *s1 = nullptr;
         // walk backwards: pass P-1 -> dst, P-2 -> s0, P-3 -> dst (or s1 if that would clobber src)...
         for (size_t i = 0; i < passes; i++) {
@@ -492,7 +488,16 @@ extern "C" int hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out)
     return HODOR_OK;
 }
 
-extern "C" const char *hodor_last_error(const hodor_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+// The message is copied under the error mutex into a per-thread buffer: another thread's failing call may
+// reassign ctx->err at any time, so a pointer into it could dangle.  Valid until this thread's next call here.
+extern "C" const char *hodor_last_error(const hodor_ctx *ctx)
+{
+    if (!ctx) return "";
+    static thread_local std::string snapshot;
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    snapshot = ctx->err;
+    return snapshot.c_str();
+}
 
 extern "C" int hodor_ctx_synchronize(hodor_ctx *ctx)
 {
@@ -760,6 +765,8 @@ extern "C" int hodor_gen_elements_dev(hodor_ctx *ctx, void *stream, hodor_fr *ds
 {
     NEED_DEVICE();
     if (!dst && count) return HODOR_ERR_INVALID;
+    // the top limb's mask; contexts are only created for 240 <= NUM_BITS <= 255 (hodor_ctx_create), guarded anyway
+    if (ctx->F.num_bits <= 192) return HODOR_ERR_INVALID;
     const uint64_t top_mask = ctx->F.num_bits >= 256 ? ~0ull : ((1ull << (ctx->F.num_bits - 192)) - 1);
     HIPCHK(gen_elements_launch(pick_stream(ctx, stream), (uint4 *)dst, first_index, count, seed, top_mask,
                                to_dev(ctx->F.r2), ctx->P));
@@ -794,6 +801,8 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     }
     int rc = ensure_scratch(ctx, 0, off + 256, stream);
     if (rc) return rc;
+    ScratchUse pool;
+    pool.arm(ctx, stream);
     uint8_t *base = (uint8_t *)ctx->scratch[0];
     uint32_t *flag = (uint32_t *)(base + off);
     HIPCHK(hipMemsetAsync(flag, 0, 4, stream));
@@ -843,6 +852,8 @@ extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const h
     const size_t blocks = table ? evaluate_at_table_blocks(log_n) : 256;
     int rc = ensure_scratch(ctx, 0, 32 * (blocks + 2) + 64, stream);
     if (rc) return rc;
+    ScratchUse pool;
+    pool.arm(ctx, stream);
     uint4 *partials = (uint4 *)ctx->scratch[0];
     uint4 *res = partials + 2 * blocks;
     uint32_t *ticket = (uint32_t *)(res + 2);

@@ -1,0 +1,227 @@
+// abi_exchange.hip — the exchange step of the 4-step / 6-step transform behind the C ABI.
+//
+// hodor_sixstep_columns_dev / hodor_sixstep_rows_dev (abi_sixstep.hip) do a rank's local arithmetic; between
+// them sits ONE all-to-all of P equal contiguous slabs — the distributed-memory form of the un-shuffle at
+// /root/reference/src/fft/fft.rs:111-123.  A Python caller can run it through torch.distributed
+// (hodor_amd/sixstep.py); a caller without a collective library of its own — the Rust prover — uses the entry
+// points below and needs nothing but this repository's .so: RCCL is bound at run time (dlopen of librccl.so.1,
+// the copy already in the process if there is one), there is no link-time dependency and a box without RCCL
+// still loads the library (the exchange entry points then return HODOR_ERR_DEVICE).
+//
+// Ordering.  The exchange of a chunk runs on a communication stream the hodor_exchange owns:
+//     hodor_sixstep_exchange_dev(x, stream, ...)   records an event on `stream` (everything enqueued there so far —
+//                                                  the kernels that wrote the chunk — must finish first), makes the
+//                                                  communication stream wait for it and enqueues the grouped
+//                                                  ncclSend / ncclRecv of the P slabs there: `stream` itself does NOT
+//                                                  wait, so the arithmetic of the next chunk overlaps the wire time;
+//     hodor_sixstep_exchange_wait_dev(x, stream)   makes `stream` wait for every exchange issued so far (before the
+//                                                  consuming rows / columns call reads the receive buffer).
+// The caller keeps send and receive buffers alive and untouched from the exchange call to the wait.
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: every function is resolved with dlsym
+
+#include "ctx.hpp"
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    std::string why;
+    bool ok = false;
+};
+
+const Rccl &rccl()
+{
+    static const Rccl R = [] {
+        Rccl r;
+        // the copy that is already mapped (PyTorch-ROCm brings its own) before any other: one RCCL per process
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) {
+            const char *e = dlerror();
+            r.why = std::string("librccl.so.1 not found: ") + (e ? e : "?");
+            return r;
+        }
+#define BIND(field, sym)                                                          \
+        r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, #sym));            \
+        if (!r.field) { r.why = "librccl lacks " #sym; return r; }
+        BIND(GetUniqueId, ncclGetUniqueId)
+        BIND(CommInitRank, ncclCommInitRank)
+        BIND(CommDestroy, ncclCommDestroy)
+        BIND(GetErrorString, ncclGetErrorString)
+        BIND(GroupStart, ncclGroupStart)
+        BIND(GroupEnd, ncclGroupEnd)
+        BIND(Send, ncclSend)
+        BIND(Recv, ncclRecv)
+#undef BIND
+        r.ok = true;
+        return r;
+    }();
+    return R;
+}
+
+}  // namespace
+
+struct hodor_exchange {
+    hodor_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owns_comm = false;
+    uint32_t n_ranks = 1, rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ready = nullptr;     // recorded on the caller's stream: the chunk has been produced
+    hipEvent_t done = nullptr;      // recorded on comm_stream after the latest exchange
+    bool issued = false;
+    std::mutex mu;
+};
+
+static_assert(HODOR_EXCHANGE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the unique id travels as opaque bytes");
+
+#define NCCLCHK(expr)                                                                         \
+    do {                                                                                      \
+        ncclResult_t r__ = (expr);                                                            \
+        if (r__ != ncclSuccess) {                                                             \
+            set_err(ctx, std::string(#expr) + ": " + rccl().GetErrorString(r__));             \
+            return HODOR_ERR_DEVICE;                                                          \
+        }                                                                                     \
+    } while (0)
+
+extern "C" int hodor_exchange_available(void) { return rccl().ok ? 1 : 0; }
+
+extern "C" int hodor_exchange_unique_id(uint8_t id[HODOR_EXCHANGE_ID_BYTES])
+{
+    if (!id) return HODOR_ERR_INVALID;
+    if (!rccl().ok) return HODOR_ERR_DEVICE;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return HODOR_ERR_DEVICE;
+    memcpy(id, u.internal, HODOR_EXCHANGE_ID_BYTES);
+    return HODOR_OK;
+}
+
+static int exchange_finish(hodor_ctx *ctx, hodor_exchange *x, hodor_exchange **out)
+{
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&x->ready, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&x->done, hipEventDisableTiming)) != hipSuccess) {
+        set_err(ctx, std::string("exchange: ") + hipGetErrorString(e));
+        hodor_exchange_destroy(x);
+        return HODOR_ERR_DEVICE;
+    }
+    *out = x;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_exchange_create(hodor_ctx *ctx, const uint8_t id[HODOR_EXCHANGE_ID_BYTES], uint32_t n_ranks,
+                                     uint32_t rank, hodor_exchange **out)
+{
+    NEED_DEVICE();
+    if (!id || !out) return HODOR_ERR_INVALID;
+    if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || rank >= n_ranks) {
+        set_err(ctx, "exchange: the number of ranks must be a power of two and rank < n_ranks");
+        return HODOR_ERR_SIZE;
+    }
+    if (!rccl().ok) { set_err(ctx, rccl().why); return HODOR_ERR_DEVICE; }
+    hodor_exchange *x = new (std::nothrow) hodor_exchange();
+    if (!x) return HODOR_ERR_INVALID;
+    x->ctx = ctx;
+    x->n_ranks = n_ranks;
+    x->rank = rank;
+    ncclUniqueId u;
+    memcpy(u.internal, id, HODOR_EXCHANGE_ID_BYTES);
+    ncclResult_t r = rccl().CommInitRank(&x->comm, (int)n_ranks, u, (int)rank);   // collective over the ranks
+    if (r != ncclSuccess) {
+        set_err(ctx, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+        delete x;
+        return HODOR_ERR_DEVICE;
+    }
+    x->owns_comm = true;
+    return exchange_finish(ctx, x, out);
+}
+
+extern "C" int hodor_exchange_adopt(hodor_ctx *ctx, void *nccl_comm, uint32_t n_ranks, uint32_t rank,
+                                    hodor_exchange **out)
+{
+    NEED_DEVICE();
+    if (!nccl_comm || !out) return HODOR_ERR_INVALID;
+    if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || rank >= n_ranks) return HODOR_ERR_SIZE;
+    if (!rccl().ok) { set_err(ctx, rccl().why); return HODOR_ERR_DEVICE; }
+    hodor_exchange *x = new (std::nothrow) hodor_exchange();
+    if (!x) return HODOR_ERR_INVALID;
+    x->ctx = ctx;
+    x->comm = (ncclComm_t)nccl_comm;
+    x->n_ranks = n_ranks;
+    x->rank = rank;
+    return exchange_finish(ctx, x, out);
+}
+
+extern "C" void hodor_exchange_destroy(hodor_exchange *x)
+{
+    if (!x) return;
+    if (x->ctx && x->ctx->device >= 0) (void)hipSetDevice(x->ctx->device);
+    if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+    if (x->owns_comm && x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
+    if (x->ready) (void)hipEventDestroy(x->ready);
+    if (x->done) (void)hipEventDestroy(x->done);
+    if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+    delete x;
+}
+
+// Chunk `chunk` of 2^log_chunks: elements [chunk * n_local / K, (chunk + 1) * n_local / K) of both buffers, seen as
+// n_ranks equal slabs; slab t of the send piece goes to rank t, slab s of the receive piece comes from rank s —
+// exactly the buffers hodor_sixstep_columns_dev / _rows_dev write and gather from.
+extern "C" int hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const hodor_fr *send, hodor_fr *recv,
+                                          size_t n_local, uint32_t log_chunks, uint32_t chunk)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    if (!send || !recv || send == recv) return HODOR_ERR_INVALID;
+    if (log_chunks > 20 || chunk >= (1u << log_chunks) || n_local == 0 ||
+        n_local % ((size_t)x->n_ranks << log_chunks) != 0) {
+        set_err(ctx, "exchange: n_local must be a multiple of n_ranks * chunks, chunk < chunks");
+        return HODOR_ERR_SIZE;
+    }
+    const size_t piece = n_local >> log_chunks, slab = piece / x->n_ranks;
+    const uint8_t *s = (const uint8_t *)(send + (size_t)chunk * piece);
+    uint8_t *r = (uint8_t *)(recv + (size_t)chunk * piece);
+    std::lock_guard<std::mutex> lk(x->mu);
+    HIPCHK(hipEventRecord(x->ready, (hipStream_t)stream));
+    HIPCHK(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
+    const Rccl &R = rccl();
+    NCCLCHK(R.GroupStart());
+    for (uint32_t peer = 0; peer < x->n_ranks; peer++) {
+        ncclResult_t a = R.Send(s + (size_t)peer * slab * 32, slab * 32, ncclInt8, (int)peer, x->comm, x->comm_stream);
+        ncclResult_t b = R.Recv(r + (size_t)peer * slab * 32, slab * 32, ncclInt8, (int)peer, x->comm, x->comm_stream);
+        if (a != ncclSuccess || b != ncclSuccess) {
+            (void)R.GroupEnd();
+            set_err(ctx, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(a != ncclSuccess ? a : b));
+            return HODOR_ERR_DEVICE;
+        }
+    }
+    NCCLCHK(R.GroupEnd());
+    HIPCHK(hipEventRecord(x->done, x->comm_stream));
+    x->issued = true;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->issued) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, x->done, 0));
+    return HODOR_OK;
+}

@@ -398,6 +398,58 @@ extern "C" int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof
     return HODOR_OK;
 }
 
+// hodor_fri_verify_proof with the shape of the proof bound to the claimed domain FIRST.  The reference's
+// verify_proof_queries (src/fri/verifier.rs:131-289) walks zip(roots, queries.chunks_exact(2)) and therefore
+// accepts a proof whose tail of rounds has been cut off, or whose final polynomial has any length; this
+// variant refuses (HODOR_OK with *valid = 0) every buffer whose counts differ from what
+// FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53) writes for the parameters the proof
+// itself carries AND the caller expects:
+//     lde_factor, initial_degree_plus_one, out_deg powers of two, out_deg <= initial_degree_plus_one,
+//     initial_degree_plus_one * lde_factor == expected_domain_size,
+//     n_roots == log2(initial_degree_plus_one / out_deg) + 1, n_queries == 2 * n_roots, n_final == out_deg,
+//     path_len of round k == log2(expected_domain_size >> k), both queries of a round.
+// A well-formed proof is then handed to hodor_fri_verify_proof unchanged.
+extern "C" int hodor_fri_verify_proof_strict(const hodor_ctx *ctx, const uint8_t *proof, size_t len,
+                                             size_t expected_domain_size, size_t natural_element_index,
+                                             const hodor_fr *expected_value_from_oracle, int *valid)
+{
+    if (!ctx || !proof || !expected_value_from_oracle || !valid) return HODOR_ERR_INVALID;
+    *valid = 0;
+    if (!is_pow2(expected_domain_size) || natural_element_index >= expected_domain_size) return HODOR_ERR_SIZE;
+    size_t o = 0;
+    auto get64 = [&](uint64_t *v) -> bool {
+        if (o > len || len - o < 8) return false;
+        memcpy(v, proof + o, 8);
+        o += 8;
+        return true;
+    };
+    auto skip = [&](uint64_t count) -> bool {   // count 32-byte entries
+        if (count > (len - o) / 32) return false;
+        o += (size_t)count * 32;
+        return true;
+    };
+    uint64_t nq = 0;
+    if (!get64(&nq) || nq > len / 48) return HODOR_ERR_INVALID;
+    std::vector<uint64_t> path_lens((size_t)nq);
+    for (auto &pl : path_lens) {
+        uint64_t index;
+        if (!get64(&index) || !skip(1) || !get64(&pl) || !skip(pl)) return HODOR_ERR_INVALID;
+    }
+    uint64_t n_roots = 0, n_final = 0, deg = 0, out_deg = 0, factor = 0;
+    if (!get64(&n_roots) || !skip(n_roots) || !get64(&n_final) || !skip(n_final) || !get64(&deg) ||
+        !get64(&out_deg) || !get64(&factor) || o != len)
+        return HODOR_ERR_INVALID;
+    if (!is_pow2((size_t)deg) || !is_pow2((size_t)out_deg) || !is_pow2((size_t)factor) || out_deg > deg) return HODOR_OK;
+    if (factor > expected_domain_size || deg != expected_domain_size / factor) return HODOR_OK;
+    const uint64_t rounds = log2u((size_t)deg) - log2u((size_t)out_deg) + 1;
+    if (n_roots != rounds || nq != 2 * rounds || n_final != out_deg) return HODOR_OK;
+    for (uint64_t r = 0; r < rounds; r++) {
+        const uint64_t want = log2u(expected_domain_size >> r);
+        if (path_lens[2 * r] != want || path_lens[2 * r + 1] != want) return HODOR_OK;
+    }
+    return hodor_fri_verify_proof(ctx, proof, len, natural_element_index, expected_value_from_oracle, valid);
+}
+
 // NaiveFriIop::verify_prototype (src/fri/verifier.rs:10-129): the same folding walk against the
 // prover's own (device-resident) vectors instead of Merkle queries — two elements per round are
 // fetched from the device.  `lde_values_dev` is the codeword the prototype was committed from.

@@ -138,6 +138,7 @@ struct hodor_ctx {
     hipStream_t scratch_owner = nullptr;
     bool scratch_owned = false;
     hipEvent_t scratch_ev = nullptr;
+    bool scratch_ev_recorded = false;   // set by ScratchUse at the end of the first call that used the pool
     // slice API staging: IO_LANES independent (copy stream, in/out device buffers) sets, so that
     // concurrent callers (src/arp/per_register/mod.rs:43-49 calls best_fft from several scoped threads)
     // overlap one caller's upload with another's kernels and a third's download; see with_device_copy
@@ -160,7 +161,7 @@ struct hodor_ctx {
     uint32_t tw_hi_max_log = 17;   // largest `hi` half (log2 entries) for which the second pass gets a hi-only
                                    // twiddle split (one product instead of two, for a table that outgrows L2)
     std::string err;           // written through set_err() only (entry points run concurrently)
-    std::mutex err_mu;
+    mutable std::mutex err_mu;
 };
 
 static inline void set_err(hodor_ctx *ctx, const std::string &msg)
@@ -234,6 +235,29 @@ int trim_table_cache(hodor_ctx *ctx);
 int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
                   uint32_t lo_bits = 0xffffffffu, const HFr *hi_mult_p = nullptr);
 int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes, hipStream_t user);
+// Armed right after a successful ensure_scratch (caller holds ctx->mu): when the call leaves — normally or on an
+// error path — everything it enqueued on `stream` that touches the pool is behind ctx->scratch_ev.
+struct ScratchUse {
+    hodor_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    void arm(hodor_ctx *c, hipStream_t s) { ctx = c; stream = s; }
+    ~ScratchUse()
+    {
+        if (!ctx) return;
+        if (!ctx->scratch_ev && hipEventCreateWithFlags(&ctx->scratch_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->scratch_ev = nullptr;
+            ctx->scratch_ev_recorded = false;
+            return;
+        }
+        if (hipEventRecord(ctx->scratch_ev, stream) == hipSuccess) {
+            ctx->scratch_ev_recorded = true;
+        } else {   // could not mark the end of this call: fall back to a full wait so that nobody races it
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(stream);
+        }
+    }
+};
 struct NttLayout {
     bool col_mode = false;           // transform along the slow axis of a [2^log_n][2^log_width] array
     uint32_t log_width = 0;          // columns transformed (and the width of the intermediate arrays)

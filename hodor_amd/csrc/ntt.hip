@@ -151,7 +151,7 @@ __device__ unsigned long long hodor_ablate_stamps[1024 * 16];
 #define STAMP(slot)                                                                                   \
     do {                                                                                              \
         if ((A.dbg & 16) && ((A.dbg >> 8) & 3) == (A.log_l >> 3) && threadIdx.x == 0 &&               \
-            (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 1024)                    \
+            (blockIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 6) < 1024)                    \
             hodor_ablate_stamps[(blockIdx.x >> 6) * 16 + (slot)] = __builtin_readcyclecounter();      \
     } while (0)
 #else
@@ -206,12 +206,14 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         T[e] = A.rtw[7 * (ent << tw_sub) + q];
     }
 
-    // batched transforms: blockIdx.y selects one of `batch` independent size-n arrays
-    const uint4 *src_b = A.src + 2ull * blockIdx.y * A.src_batch_stride;   // first LDE pass: n/f apart
-    uint4 *dst_b = A.dst + ((2ull * blockIdx.y) << A.log_n);
+    // batched transforms: grid.y (continued in grid.z beyond 65535, see ntt_launch_pass) selects one of `batch`
+    // independent size-n arrays — or, in column mode, the tile's first array column
+    const uint32_t by = blockIdx.z * gridDim.y + blockIdx.y;
+    const uint4 *src_b = A.src + 2ull * by * A.src_batch_stride;   // first LDE pass: n/f apart
+    uint4 *dst_b = A.dst + ((2ull * by) << A.log_n);
     const uint64_t n_over_r = 1ull << (A.log_n - log_r);
     const bool colm = MODE == 1 && A.col_mode;
-    const uint64_t colbase = colm ? ((uint64_t)blockIdx.y << log_c) : 0;   // first array column of this tile
+    const uint64_t colbase = colm ? ((uint64_t)by << log_c) : 0;   // first array column of this tile
     const uint64_t Lmask = (1ull << A.log_l) - 1;
     const uint32_t tw_shift = A.log_n - A.log_l - log_r;   // exponent scale N / (L*R)
     const uint32_t tile = R << log_c;
@@ -238,7 +240,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 x = fr9_unpack(fr_load(A.src + 2 * ((srow << A.src_log_width) + A.src_col_off + colbase + c)));
                 if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
             } else if (MODE == 1 && A.src_split.on) {
-                x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, blockIdx.y)));
+                x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, by)));
             } else {
                 x = fr9_unpack(fr_load(src_b + 2 * g));
             }
@@ -369,7 +371,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         // streaming stores: the output crosses the chip once and should not push the twiddle tables out of L2
         // (-1 % on the 2^24 step; streaming LOADS of the data measured +0.8 %)
         if (MODE == 1 && colm) fr_store_nt(A.dst + 2 * ((o << A.dst_log_width) + A.dst_col_off + colbase + c), y);
-        else if (MODE == 1 && A.dst_split.on) fr_store_nt(A.dst + 2 * split_index(A.dst_split, o, blockIdx.y), y);
+        else if (MODE == 1 && A.dst_split.on) fr_store_nt(A.dst + 2 * split_index(A.dst_split, o, by), y);
         else fr_store_nt(dst_b + 2 * o, y);
     }
     STAMP(11);
@@ -398,7 +400,16 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     const bool general = A.col_mode || A.src_split.on || A.dst_split.on;
     // column mode: one sub-transform position per workgroup, grid.y walks the array's columns C at a time
     uint64_t grid = A.col_mode ? n >> A.log_r : n >> (A.log_r + A.log_c);
-    unsigned grid_y = A.col_mode ? (1u << (A.log_width - A.log_c)) : (A.batch ? A.batch : 1);
+    // grid.y is limited to 65535: a larger count (2^16 tile-column groups of a wide column-mode array, 2^16+ rows of
+    // a 4-step row block) continues in grid.z — the kernel reads blockIdx.z * gridDim.y + blockIdx.y
+    uint64_t grid_y = A.col_mode ? (1ull << (A.log_width - A.log_c)) : (A.batch ? A.batch : 1);
+    unsigned grid_z = 1;
+    while (grid_y > 65535) {
+        if ((grid_y & 1) || grid_z >= 32768) return hipErrorInvalidValue;
+        grid_y >>= 1;
+        grid_z <<= 1;
+    }
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     Fr9 s = {};
     if (scale) s = *scale;
     // sub-sampled LDS twiddle table when it raises the number of resident workgroups: every step but the
@@ -440,10 +451,10 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
 #endif
     if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
     if (general)
-        hipLaunchKernelGGL(k_ntt_pass<1>, dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
+        hipLaunchKernelGGL(k_ntt_pass<1>, dim3((unsigned)grid, (unsigned)grid_y, grid_z), dim3(threads), lds, stream, B, s,
                            scale ? 1u : 0u, Q);
     else
-        hipLaunchKernelGGL(k_ntt_pass<0>, dim3((unsigned)grid, grid_y), dim3(threads), lds, stream, B, s,
+        hipLaunchKernelGGL(k_ntt_pass<0>, dim3((unsigned)grid, (unsigned)grid_y, grid_z), dim3(threads), lds, stream, B, s,
                            scale ? 1u : 0u, Q);
     return hipGetLastError();
 }

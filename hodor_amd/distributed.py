@@ -13,14 +13,14 @@ commit — BASELINE config[2]'s shape across a node.
 
 `lde_by_cosets_distributed`: the reference's own LDE schedule (`lde_using_multiple_cosets`,
 src/polynomials/mod.rs:418-482: coset i of `factor` is an independent size-n transform of
-coeffs * (W^i)^j) with the cosets dealt round-robin to the ranks — no communication until the
+coeffs * (W^i)^j) with the cosets dealt in contiguous blocks to the ranks — no communication until the
 interleave `out[idx] = res[idx % f][idx / f]` (:466-479), which is ONE all-to-all (the natural-order transform route
 needs three).  The coefficients (n elements, 1/f of the output) are replicated on every rank.
 """
 import torch
 import torch.distributed as dist
 
-from .sixstep import sixstep_ntt
+from .sixstep import _all_to_all, sixstep_ntt
 
 
 class HipTreeBackend:
@@ -48,8 +48,12 @@ def merkle_commit_distributed(backend, leafs_local, rank, world, group=None):
     if world == 1:
         roots = [bytes(my_root.cpu().numpy())]
     else:
-        gathered = torch.empty((world, 32), dtype=torch.uint8, device=my_root.device)
-        dist.all_gather_into_tensor(gathered, my_root.view(1, 32), group=group)
+        if my_root.is_cuda and dist.get_backend(group) == "gloo":      # testing aid: ranks sharing one GPU (see sixstep._all_to_all)
+            gathered = torch.empty((world, 32), dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, my_root.cpu().view(1, 32), group=group)
+        else:
+            gathered = torch.empty((world, 32), dtype=torch.uint8, device=my_root.device)
+            dist.all_gather_into_tensor(gathered, my_root.view(1, 32), group=group)
         roots = [bytes(r) for r in gathered.cpu().numpy()]
     top = {world + r: roots[r] for r in range(world)}
     w = world // 2
@@ -81,31 +85,42 @@ def lde_by_cosets_distributed(backend, coeffs, log_n, factor, omega_big, rank, w
     """`coeffs`: all n = 1 << log_n coefficients (replicated on every rank), shape (n, 4).  `omega_big`:
     generator W of the size n*factor domain.  `coset_shift`: g for coset_lde (values at g * W^idx), None
     for lde.  Needs world | factor and world | n.  Returns this rank's natural block of the n*factor
-    values, shape (n*factor/world, 4) — what `merkle_commit_distributed` takes."""
+    values, shape (n*factor/world, 4) — what `merkle_commit_distributed` takes.
+
+    Rank r transforms the f/P cosets i = r*f/P + t (any assignment is the reference's schedule: its cosets are
+    independent work items, src/polynomials/mod.rs:446-460); every local step is a C-ABI call:
+        coset i      hodor_poly_coset_fft_for_generator_dev(gen = g W^i)   distribute_powers fused into the first pass
+        send slabs   hodor_sixstep_pack_dev([f/P][n] -> [P][f/P][n/P])     (nothing to do when f == P)
+        exchange     ONE all-to-all of P slabs
+        interleave   hodor_transpose_dev([f][n/P] -> [n/P][f])             out[(k - k0)*f + i]  (:466-479)"""
     n, f, P = 1 << log_n, factor, world
     assert f % P == 0 and n % P == 0, "world size must divide the LDE factor and the polynomial size"
     fp, kb = f // P, n // P
+    log_fp, log_p = fp.bit_length() - 1, P.bit_length() - 1
     omega = backend.pow(omega_big, f)                    # generator of the size-n domain
     res = []
     for t in range(fp):
-        i = rank + t * P                                 # my cosets: i = rank, rank + P, ...
+        i = rank * fp + t
         gen = backend.pow(omega_big, i)
         if coset_shift is not None:
             gen = backend.mul(gen, coset_shift)
-        buf = coeffs.clone()
-        if i != 0 or coset_shift is not None:
-            backend.distribute_powers(buf, gen)          # c_j * (g W^i)^j
-        res.append(backend.batched_ntt(buf, 1, log_n, omega))   # res[t][k] = out[k*f + i]
-    a = torch.stack(res)                                 # (fp, n, 4)
+        if hasattr(backend, "coset_ntt"):
+            res.append(backend.coset_ntt(coeffs, log_n, gen if (i != 0 or coset_shift is not None) else None, omega))
+        else:
+            buf = coeffs.clone()
+            if i != 0 or coset_shift is not None:
+                backend.distribute_powers(buf, gen)      # c_j * (g W^i)^j
+            res.append(backend.batched_ntt(buf, 1, log_n, omega))   # res[t][k] = out[k*f + i]
+    a = res[0] if fp == 1 else torch.cat(res)            # [fp][n]
     # rank d owns idx in [d*n*f/P, ...) = k in [d*kb, (d+1)*kb), every coset: slab d = my cosets on that k range
-    send = a.view(fp, P, kb, 4).permute(1, 0, 2, 3).contiguous().view(P, fp * kb, 4)
+    send = backend.pack(a, log_fp, log_n, log_p) if (fp > 1 and P > 1) else a
     if P == 1:
         recv = send
     else:
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
-    # slab s came from rank s and holds cosets i = s + t*P: out_local[(k - k0)*f + t*P + s]
-    return recv.view(P, fp, kb, 4).permute(2, 1, 0, 3).contiguous().view(kb * f, 4)
+        _all_to_all(recv, send, group)
+    # slab s came from rank s and holds cosets i = s*fp + t: recv is [f][kb] in coset order -> [kb][f]
+    return backend.transpose(recv, f, kb)
 
 
 def lde_commit_by_cosets_distributed(ntt_backend, tree_backend, coeffs, log_n, factor, omega_big, rank, world,

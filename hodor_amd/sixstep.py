@@ -30,8 +30,10 @@ import torch.distributed as dist
 class HipBackend:
     """Local steps on the MI355X through the C ABI (device tensors of shape (m, 4), int64)."""
 
-    def __init__(self, ctx, stream=None):
-        self.ctx, self.stream = ctx, stream
+    def __init__(self, ctx, stream=None, exchange=None):
+        # exchange: a hodor_amd.Exchange — the all-to-alls then run through the C ABI (hodor_sixstep_exchange_dev,
+        # grouped ncclSend/ncclRecv on the library's communication stream) instead of torch.distributed
+        self.ctx, self.stream, self.exchange = ctx, stream, exchange
 
     # ---- 4-step building blocks
     def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
@@ -74,6 +76,16 @@ class HipBackend:
     def distribute_powers(self, buf, g):
         self.ctx.distribute_powers_dev(buf, buf.shape[0], g, stream=self.stream)
         return buf
+
+    def coset_ntt(self, coeffs, log_len, gen, omega):
+        """values of sum_j coeffs[j] (gen x)^j on the size-2^log_len domain: the coset scale runs inside the first
+        pass of the transform (coset_fft_for_generator, src/polynomials/mod.rs:633-638); gen None = plain fft."""
+        out = torch.empty_like(coeffs)
+        if gen is None:
+            self.ctx.poly_fft_dev(coeffs, out, log_len, stream=self.stream)
+        else:
+            self.ctx.poly_coset_fft_for_generator_dev(coeffs, out, log_len, gen, stream=self.stream)
+        return out
 
     def pow(self, a, e):
         return self.ctx.pow(a, e)
@@ -137,7 +149,7 @@ def _log_p(world):
     return log_p
 
 
-def _exchange_begin(produce, m, world, group, log_chunks):
+def _exchange_begin(produce, m, world, group, log_chunks, native=None, stream=None):
     """Runs produce(k, send_chunk_k) for k = 0 .. K-1 and puts each chunk on the wire as soon as it has been
     enqueued: the all-to-all of chunk k (asynchronous, on the communicator's own stream, ordered after the
     kernels that wrote the chunk) overlaps the arithmetic of chunk k+1 — and whatever the caller enqueues next.
@@ -153,9 +165,25 @@ def _exchange_begin(produce, m, world, group, log_chunks):
     step = m // K
     for k in range(K):
         produce(k, send[k * step:(k + 1) * step])
-        if collective:
+        if collective and native is not None:
+            native.exchange(send, recv, log_chunks, k, stream=stream)
+        elif collective:
             works.append(_all_to_all(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step], group, async_op=True))
+    if collective and native is not None:
+        # the communication stream reads `send` after this function has returned: the handle keeps it alive until
+        # the compute stream has been made to wait for the exchange (the allocator reuses memory in stream order)
+        works.append(_NativeWait(native, stream, send))
     return recv, works
+
+
+class _NativeWait:
+    def __init__(self, native, stream, keep):
+        self.native, self.stream, self.keep = native, stream, keep
+
+    def wait(self):
+        self.native.wait(stream=self.stream)
+        self.keep = None
+        return True
 
 
 def _exchange_end(works):
@@ -175,7 +203,8 @@ def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log
             return a
         backend.columns(a, log_n1, log_n2, log_p, rank, omega, False, log_chunks, k, out=out)
 
-    recv, works = _exchange_begin(produce, a.shape[0], world, group, log_chunks)
+    recv, works = _exchange_begin(produce, a.shape[0], world, group, log_chunks, getattr(backend, "exchange", None),
+                                  getattr(backend, "stream", None))
     return {"recv": recv, "works": works, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
 
@@ -201,7 +230,8 @@ def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log
             return b
         backend.rows(b, log_n1, log_n2, log_p, rank, omega, True, log_chunks, k, out=out)
 
-    recv, works = _exchange_begin(produce, b.shape[0], world, group, log_chunks)
+    recv, works = _exchange_begin(produce, b.shape[0], world, group, log_chunks, getattr(backend, "exchange", None),
+                                  getattr(backend, "stream", None))
     return {"recv": recv, "works": works, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
 

@@ -277,6 +277,35 @@ int hodor_sixstep_rows_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, ho
 int hodor_sixstep_pack_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, uint32_t log_rows,
                            uint32_t log_cols, uint32_t log_p);
 int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst, size_t rows, size_t cols);
+/* ---- the exchange between the two calls, for a caller without a collective library of its own (the Rust prover):
+ * ONE all-to-all of P equal contiguous slabs per transform = the un-shuffle of parallel_fft, src/fft/fft.rs:111-123,
+ * across devices.  RCCL is bound at run time (dlopen); nothing but this library has to be linked.
+ *   hodor_exchange_available   1 when librccl could be bound in this process
+ *   hodor_exchange_unique_id   ncclGetUniqueId: ONE rank calls it and hands the 128 opaque bytes to its peers by any
+ *                              channel it has (a file, a socket, MPI)
+ *   hodor_exchange_create      ncclCommInitRank on the context's device — collective: every rank calls it with the same
+ *                              id; n_ranks a power of two.  The handle owns the communicator, a communication stream
+ *                              and two events.  hodor_exchange_adopt wraps a communicator (ncclComm_t) the caller owns.
+ *   hodor_sixstep_exchange_dev chunk `chunk` of 2^log_chunks (elements [chunk*n_local/K, (chunk+1)*n_local/K) of both
+ *                              buffers, P slabs each: slab t of the send piece -> rank t, slab s of the receive piece
+ *                              <- rank s) as grouped ncclSend/ncclRecv on the handle's communication stream, ordered
+ *                              AFTER everything enqueued on `stream` so far; `stream` does not wait, so the next chunk's
+ *                              arithmetic overlaps the wire time
+ *   hodor_sixstep_exchange_wait_dev  `stream` waits for every exchange issued so far (call it before the consuming
+ *                              hodor_sixstep_rows_dev / _columns_dev); send and receive buffers must stay alive and
+ *                              untouched between the two calls.
+ * Destroy the handle before its context. */
+typedef struct hodor_exchange hodor_exchange;
+#define HODOR_EXCHANGE_ID_BYTES 128
+int  hodor_exchange_available(void);
+int  hodor_exchange_unique_id(uint8_t id[HODOR_EXCHANGE_ID_BYTES]);
+int  hodor_exchange_create(hodor_ctx *ctx, const uint8_t id[HODOR_EXCHANGE_ID_BYTES], uint32_t n_ranks, uint32_t rank,
+                           hodor_exchange **out);
+int  hodor_exchange_adopt(hodor_ctx *ctx, void *nccl_comm, uint32_t n_ranks, uint32_t rank, hodor_exchange **out);
+void hodor_exchange_destroy(hodor_exchange *x);
+int  hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const hodor_fr *send, hodor_fr *recv, size_t n_local,
+                                uint32_t log_chunks, uint32_t chunk);
+int  hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream);
 /* Synthetic input for tests and benchmarks: dst[r] = element first_index + r of the
  * index-addressable SplitMix64 stream `seed` — uniform canonical residues (rejection-sampled < p)
  * in Montgomery form, i.e. what the reference's tests draw with Fr::rand (src/fft/mod.rs:71-77), but
@@ -307,6 +336,14 @@ size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_de
  * output_coeffs_at_degree_plus_one == 1 round-trip through produce_proof -> verify_proof. */
 int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t natural_element_index,
                            const hodor_fr *expected_value_from_oracle, int *valid);
+/* The same verifier with the proof's SHAPE bound to the domain the caller expects before any hash is checked —
+ * what the caveats above ask an integrator to do by hand.  *valid = 0 (HODOR_OK) unless
+ * initial_degree_plus_one * lde_factor == expected_domain_size, n_roots == log2(initial_degree_plus_one /
+ * out_deg) + 1, n_queries == 2 * n_roots, n_final == out_deg and every path has the length of its round's tree;
+ * a truncated proof, which the reference's walk (and hodor_fri_verify_proof) accepts, is refused here. */
+int hodor_fri_verify_proof_strict(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t expected_domain_size,
+                                  size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
+                                  int *valid);
 /* NaiveFriIop::verify_prototype — src/fri/verifier.rs:10-129: the folding walk against the prover's own
  * device-resident vectors (two elements fetched per round).  *valid as above. */
 int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_dev, size_t natural_element_index,

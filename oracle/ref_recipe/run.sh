@@ -3,11 +3,12 @@
 # Needs cargo + crates.io access; cannot run in the build image (see README.md).
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)
-OUT=$HERE/../_ref
+OUT=${TMPDIR:-/tmp}/hodor_ref_recipe   # scratch OUTSIDE the repository: the crate's sources must never sit under a path gpurun ships
 command -v cargo >/dev/null || { echo "no cargo: the reference is unbuildable here (expected in the build image)"; exit 3; }
 rm -rf "$OUT/hodor" && mkdir -p "$OUT" && cp -r /root/reference "$OUT/hodor"
 cp "$HERE/gen_fixtures.rs" "$OUT/hodor/src/gen_fixtures.rs"
 printf '\n#[cfg(test)]\nmod gen_fixtures;\n' >> "$OUT/hodor/src/lib.rs"
-(cd "$OUT/hodor" && HODOR_FIXTURES_OUT="$OUT/fullsize_digests_rust.json" \
+mkdir -p "$HERE/../_ref"
+(cd "$OUT/hodor" && HODOR_FIXTURES_OUT="$HERE/../_ref/fullsize_digests_rust.json" \
     cargo test --release gen_fixtures -- --nocapture --ignored)
-python3 "$HERE/compare.py" "$OUT/fullsize_digests_rust.json" "$HERE/../../tests/golden/fullsize_digests.json"
+python3 "$HERE/compare.py" "$HERE/../_ref/fullsize_digests_rust.json" "$HERE/../../tests/golden/fullsize_digests.json"

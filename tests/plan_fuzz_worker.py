@@ -44,6 +44,17 @@ def main():
                 big = torch.empty((n * f, 4), dtype=torch.int64, device="cuda")
                 ctx.poly_lde_dev(dev(a), big, lg, f, coset=(f == 8)); ctx.synchronize()
                 assert np.array_equal(host(big), O.poly_lde(a, f, coset=(f == 8))), ("lde", lg, f)
+    # 4-step path under the same knobs (argv[2]: "log_n:world:log_chunks,..."): with a small radix cap the column
+    # transforms (k_ntt_pass<1>, column mode) and the row transforms both take several passes — compact
+    # intermediate widths, 2D twiddle on the first / last pass only, chunked split addressing — and every rank's
+    # row block must equal the single-device transform checked above, the inverse must return the input
+    if len(sys.argv) > 2 and sys.argv[2]:
+        sys.path.insert(0, os.path.join(ROOT, "bench"))
+        import sixstep_fullsize
+        for spec in sys.argv[2].split(","):
+            lg, world, log_chunks = (int(v) for v in spec.split(":"))
+            assert lg in logs, "the sixstep sizes must be among the sizes compared with the oracle"
+            assert sixstep_fullsize.run(ctx, lg, world, log_chunks, verbose=False, seed=4000 + lg), spec
     print("PLAN-FUZZ-OK", os.environ.get("HODOR_MAX_LOG_R"), os.environ.get("HODOR_TILE_LOG"), os.environ.get("HODOR_MIN_LOG_C"))
 
 

@@ -167,6 +167,65 @@ def test_fri_verifier_on_host_matches_restated_verifier():
     ctx.close()
 
 
+def test_strict_fri_verifier_refuses_truncated_and_reshaped_proofs():
+    """The reference's verify_proof_queries walks zip(roots, queries.chunks_exact(2)) (src/fri/verifier.rs:131-289):
+    a proof with its last rounds cut off still verifies.  hodor_fri_verify_proof mirrors that (documented caveat);
+    hodor_fri_verify_proof_strict binds the counts and path lengths to the claimed domain first."""
+    F = P.BN256
+    ctx = hodor_amd.Context(F.p, F.g, device=-1)
+    log_deg, f = 4, 4
+    coeffs = [pow(7, 31 + i, F.p) for i in range(1 << log_deg)]
+    lde = P.poly_lde(F, coeffs, f)
+    n = len(lde)
+    proto = P.fri_commit(F, lde, f, 1)
+    index = n // 2 + 5
+    proof = P.fri_produce_proof(F, proto, lde, index, f, 1)
+    raw = P.fri_proof_to_bytes(proof)
+    expected = F.to_mont(lde[index])
+    assert ctx.fri_verify_proof(raw, index, expected) is True
+    assert ctx.fri_verify_proof_strict(raw, n, index, expected) is True
+    assert ctx.fri_verify_proof_strict(raw, n, index, expected ^ 1) is False
+    assert ctx.fri_verify_proof_strict(raw, 2 * n, index, expected) is False       # not the domain the caller expects
+    assert ctx.fri_verify_proof_strict(raw, n // 2, index % (n // 2), expected) is False
+
+    def variant(mut):
+        bad = dict(proof, queries=list(proof["queries"]), roots=list(proof["roots"]),
+                   final_coeffs=list(proof["final_coeffs"]))
+        mut(bad)
+        return P.fri_proof_to_bytes(bad)
+
+    # 1. the forgery the reference's walk admits: keep only the first two rounds and declare the value the second
+    # fold arrives at (= the honest round-2 query at the halved index) to be the constant "final polynomial"
+    idx1 = index if index < n // 2 else index - n // 2
+    idx2 = idx1 if idx1 < n // 4 else idx1 - n // 4
+    folded = [v for (i, v, _p) in proof["queries"][4:6] if i == idx2]
+    assert len(folded) == 1
+
+    def keep_two_rounds(b):
+        b["queries"] = b["queries"][:4]
+        b["roots"] = b["roots"][:2]
+        b["final_coeffs"] = folded
+    cut = variant(keep_two_rounds)
+    assert P.fri_verify_proof_queries(F, dict(proof, queries=proof["queries"][:4], roots=proof["roots"][:2],
+                                              final_coeffs=folded), index, expected) is True
+    assert ctx.fri_verify_proof(cut, index, expected) is True                       # reference-faithful: accepted
+    assert ctx.fri_verify_proof_strict(cut, n, index, expected) is False            # strict: refused
+    # 2. the pure shape attacks: fewer rounds, extra final coefficients, a shortened path
+    def drop_last_round(b):
+        b["queries"] = b["queries"][:-2]
+        b["roots"] = b["roots"][:-1]
+    def extra_final(b): b["final_coeffs"] = b["final_coeffs"] + [0]
+    def short_path(b): q = b["queries"][0]; b["queries"][0] = (q[0], q[1], list(q[2][:-1]))
+    for mut in (drop_last_round, extra_final, short_path):
+        assert ctx.fri_verify_proof_strict(variant(mut), n, index, expected) is False
+    for cutlen in (0, 9, len(raw) - 1):
+        with pytest.raises(_lib.HodorError):
+            ctx.fri_verify_proof_strict(raw[:cutlen] if cutlen else b"\x00", n, index, expected)
+    with pytest.raises(_lib.HodorError):
+        ctx.fri_verify_proof_strict(raw, n, n, expected)                              # index outside the domain
+    ctx.close()
+
+
 def test_knobs_are_reported_and_bench_refuses_them():
     """hodor_knobs_set() echoes the tuning variables the library saw; bench.py refuses to run with any of
     them set (and --skip-checks without --allow-knobs) before it touches a GPU."""

@@ -252,7 +252,7 @@ def test_iop_tree_large_matches_oracle(gpu_ctxs, oracles, log_n):
     """The schedules of merkle.hip by size: latency only (<= 2^19), one throughput launch then latency
     (2^20, 2^21) — every node against the CPU oracle."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     n = 1 << log_n
     d_l = random_elements(torch, n, 77 + log_n)
@@ -270,7 +270,7 @@ def test_iop_tree_benchmark_sizes_are_made_of_their_subtrees(gpu_ctxs, oracles, 
     aligned blocks of 2^log_sub leaves (built by the smaller-size schedules, which the oracle pins), and
     its top is the hash chain over the block roots."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     n, s = 1 << log_n, 1 << log_sub
     blocks = n // s
@@ -368,7 +368,7 @@ def test_fri_commit_benchmark_size_is_accepted_by_the_verifiers(gpu_ctxs, oracle
     library's verifier and in the Python restatement of verify_proof_queries (:131-289), challenges are
     interpret_hash of the roots, and the constant the chain ends in is the fold of the coefficients."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O, F = gpu_ctxs["bn256"], oracles["bn256"], P.BN256
     f, log_deg = 8, log_code - 3
     n = 1 << log_code
@@ -406,7 +406,7 @@ def test_repeated_commits_are_identical(gpu_ctxs, oracles, log_code):
     """The fused kernels hand data between phases through LDS and global memory inside one workgroup; a
     missing barrier would show as run-to-run differences (bench/soak.py is the long version)."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx = gpu_ctxs["bn256"]
     f, log_deg = 8, log_code - 3
     n = 1 << log_code
@@ -861,7 +861,7 @@ def test_ntt_2_24_output_points_against_cpu_oracle(gpu_ctxs, oracles):
     exercised on the same points too, but it is NOT an independent witness (above 2^16 coefficients it
     runs on fr9_mul and the k_pow_table tables, like the NTT)."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     log_n = 24
     n = 1 << log_n
@@ -886,7 +886,7 @@ def test_ntt_2_24_output_points_against_cpu_oracle(gpu_ctxs, oracles):
 def test_large_transforms_roundtrip_and_points(gpu_ctxs, oracles, log_n):
     """Sizes beyond the benchmark (FRI works on 2^26): 3- and 4-pass plans, 64-bit indexing."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     n = 1 << log_n
     a = random_elements(torch, n, 5 + log_n)
@@ -908,7 +908,7 @@ def test_lde_benchmark_size_points_and_subgrid(gpu_ctxs, oracles, coset):
     on the CPU oracle, and the sub-grid idx = 8k is the plain (coset) transform of the coefficients
     (src/polynomials/mod.rs:466-479 interleave)."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     log_n, f = 22, 8
     n = 1 << log_n
@@ -938,7 +938,7 @@ def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
     scratch.  Checks a 4-pass plan with > 2^31-byte offsets: output points by direct evaluation on the
     CPU oracle (coefficients downloaded 1 GiB at a time) and the inverse round trip."""
     import torch
-    from bench import random_elements
+    from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     n = 1 << log_n
     free, _ = torch.cuda.mem_get_info()

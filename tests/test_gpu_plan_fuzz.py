@@ -1,6 +1,7 @@
 """The planner under every shape its knobs can produce: radix caps 2^2 .. 2^11, tiles of 2^6 .. 2^11 elements,
-0 .. 16 tile columns, both LDS twiddle-table forms and fixed workgroup sizes — transforms, in-place transforms
-and (coset) LDEs of 2^1 .. 2^17 points must stay bit-identical to the CPU oracle whatever the plan (the knobs
+0 .. 16 tile columns, both LDS twiddle-table forms and fixed workgroup sizes — transforms, in-place transforms,
+(coset) LDEs and the 4-step building blocks (several passes down the columns and along the rows, chunked, 1-8
+ranks) of 2^1 .. 2^17 points must stay bit-identical to the CPU oracle whatever the plan (the knobs
 are tuning aids read once per process, so each setting runs in its own process: tests/plan_fuzz_worker.py)."""
 import os
 import subprocess
@@ -13,11 +14,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 SETTINGS = [
-    ({"HODOR_MAX_LOG_R": "2", "HODOR_TILE_LOG": "6"}, "1,2,3,7,8,11"),
-    ({"HODOR_MAX_LOG_R": "3", "HODOR_TILE_LOG": "6", "HODOR_MIN_LOG_C": "0"}, "4,6,9,10,13"),
-    ({"HODOR_MAX_LOG_R": "5", "HODOR_TILE_LOG": "7", "HODOR_MIN_LOG_C": "4"}, "5,8,12,15"),
+    ({"HODOR_MAX_LOG_R": "2", "HODOR_TILE_LOG": "6"}, "1,2,3,7,8,11", "8:2:1,11:4:0"),
+    ({"HODOR_MAX_LOG_R": "3", "HODOR_TILE_LOG": "6", "HODOR_MIN_LOG_C": "0"}, "4,6,9,10,13", "10:1:2,13:2:2,13:8:1"),
+    ({"HODOR_MAX_LOG_R": "5", "HODOR_TILE_LOG": "7", "HODOR_MIN_LOG_C": "4"}, "5,8,12,15", "12:4:1,15:2:3"),
     ({"HODOR_MAX_LOG_R": "6", "HODOR_TILE_LOG": "11", "HODOR_NTT_TW_SUB": "0"}, "6,11,13,17"),
-    ({"HODOR_MAX_LOG_R": "7", "HODOR_TILE_LOG": "9", "HODOR_MIN_LOG_C": "3"}, "7,9,14,16"),
+    ({"HODOR_MAX_LOG_R": "7", "HODOR_TILE_LOG": "9", "HODOR_MIN_LOG_C": "3"}, "7,9,14,16", "16:4:2"),
     ({"HODOR_MAX_LOG_R": "8", "HODOR_TILE_LOG": "8", "HODOR_MIN_LOG_C": "1", "HODOR_NTT_THREADS": "64"}, "8,10,16"),
     ({"HODOR_MAX_LOG_R": "9", "HODOR_TILE_LOG": "11", "HODOR_NTT_THREADS": "512"}, "9,12,17"),
     ({"HODOR_MAX_LOG_R": "10", "HODOR_TILE_LOG": "10", "HODOR_MIN_LOG_C": "0", "HODOR_TW_HI_MAX_LOG": "0"}, "10,13,15"),
@@ -28,10 +29,11 @@ SETTINGS = [
 
 @pytest.mark.parametrize("idx", range(len(SETTINGS)))
 def test_transforms_are_plan_independent(idx):
-    knobs, logs = SETTINGS[idx]
+    knobs, logs = SETTINGS[idx][:2]
+    six = SETTINGS[idx][2] if len(SETTINGS[idx]) > 2 else ""      # 4-step cases "log_n:world:log_chunks" (multi-pass column mode)
     env = dict(os.environ)
     env.update(knobs)
-    out = subprocess.run([sys.executable, os.path.join(HERE, "plan_fuzz_worker.py"), logs], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(HERE, "plan_fuzz_worker.py"), logs, six], capture_output=True,
                          text=True, timeout=900, env=env)
     assert out.returncode == 0 and "PLAN-FUZZ-OK" in out.stdout, (knobs, out.stdout[-1500:], out.stderr[-3000:])
 

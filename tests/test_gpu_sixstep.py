@@ -213,6 +213,144 @@ def test_ranks_played_on_one_gpu_equal_single_device_transform(gpu_ctxs, world, 
     assert sixstep_fullsize.run(gpu_ctxs["bn256"], log_n, world, log_chunks, verbose=False)
 
 
+def test_config4_2_30_points_over_8_ranks_at_full_size(gpu_ctxs, oracles):
+    """BASELINE config[4] itself: ONE 2^30-point transform split 2^15 x 2^15 over 8 ranks with 8 chunks per exchange,
+    the ranks played one after the other on the single device and the all-to-all done by hand (everything of
+    config[4] except the RCCL transport).  Every row block of the forward transform must equal the single-device
+    2^30 transform element for element, the inverse must return the input — and the single-device transform it is
+    compared with is itself anchored outside the library: output points by direct evaluation on the CPU oracle
+    (the reference's chunked evaluate_at over the coefficients downloaded 1 GiB at a time).  132 GiB of HBM."""
+    import sys
+    import torch
+    from test_gpu_parity import cpu_point
+    from oracle.oracle import array_to_ints
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
+    import sixstep_fullsize
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n = 30
+    n = 1 << log_n
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4.4 * n * 32:
+        pytest.skip("not enough free HBM for config[4] on one device (needs ~140 GiB)")
+    checked = []
+
+    def check(x, y, omega):
+        _, _, w = O.domain(n)
+        assert omega == w
+        for k in (3, (n // 7) * 4 + 1):
+            got = array_to_ints(y[k:k + 1].cpu().numpy().view(np.uint64))[0]
+            assert got == cpu_point(O, x, O.pow(w, k)), k
+            checked.append(k)
+
+    assert sixstep_fullsize.run(ctx, log_n, 8, 3, verbose=False, check=check)
+    assert len(checked) == 2
+    torch.cuda.empty_cache()
+
+
+def test_four_step_at_world_1_with_2_16_tile_column_groups(gpu_ctxs):
+    """2^27 points on one rank split 2^9 x 2^18: the column transforms walk 2^18 array columns 4 at a time, 2^16 groups
+    — more than grid.y holds, so the launch continues in grid.z (ntt_launch_pass).  B transposed back is the
+    natural-order transform: equal to the direct single-device transform (whose digest at 2^27 is pinned to the CPU
+    oracle in test_gpu_fullsize.py), and the inverse returns the input."""
+    import torch
+    from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse, split_logs
+    ctx = gpu_ctxs["bn256"]
+    log_n = 27
+    n = 1 << log_n
+    free, _ = torch.cuda.mem_get_info()
+    if free < 5.5 * n * 32:
+        pytest.skip("not enough free HBM")
+    a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a, 0, n, FULL["ntt"]["27"]["seed"])
+    w = ctx.domain(n)[2]
+    hip = HipBackend(ctx)
+    log_n1, log_n2 = split_logs(log_n)
+    assert (log_n1, log_n2) == (9, 18)
+    b = sixstep_forward(hip, a, log_n, w, 0, 1)
+    nat = hip.transpose(b, 1 << log_n1, 1 << log_n2)
+    direct = torch.empty_like(a)
+    ctx.poly_fft_dev(a, direct, log_n)
+    ctx.synchronize()
+    assert torch.equal(nat, direct)
+    assert hashlib.blake2s(memoryview(nat.cpu().numpy()).cast("B"), digest_size=32).hexdigest() == FULL["ntt"]["27"]["fft"]
+    del nat, direct
+    back = sixstep_inverse(hip, b, log_n, w, 0, 1)
+    ctx.synchronize()
+    assert torch.equal(back, a)
+    del a, b, back
+    torch.cuda.empty_cache()
+
+
+def test_native_exchange_over_rccl_at_world_1(gpu_ctxs):
+    """hodor_sixstep_exchange_dev on a REAL RCCL communicator (ncclCommInitRank with one rank): every chunk's grouped
+    ncclSend/ncclRecv — a self-exchange at world 1 — must deliver what the hand exchange delivers (the send piece),
+    in stream order behind the producer, and the 4-step schedule run through it must give the transform and its
+    inverse.  The same entry points carry the data between devices when there are several."""
+    import torch
+    import hodor_amd
+    import hodor_amd.sixstep as six
+    from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse, split_logs
+    ctx = gpu_ctxs["bn256"]
+    assert hodor_amd.Exchange.available(), "librccl could not be bound on the GPU box"
+    x = hodor_amd.Exchange(ctx, hodor_amd.Exchange.unique_id(), 1, 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        n = 1 << 20
+        send = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        recv = torch.zeros_like(send)
+        for k in range(4):       # producer on `side`, chunk k on the wire right behind it
+            ctx.gen_elements_dev(send[k * (n // 4):(k + 1) * (n // 4)], k * (n // 4), n // 4, 99, stream=side.cuda_stream)
+            x.exchange(send, recv, 2, k, stream=side.cuda_stream)
+        x.wait(stream=side.cuda_stream)
+        got = recv.clone()       # on `side`, behind the wait
+    side.synchronize()
+    assert torch.equal(got, send)
+    # the whole schedule through the native exchange, 4 chunks, world 1 with the collectives forced
+    log_n = 22
+    e = FULL["ntt"][str(log_n)]
+    a = torch.empty((1 << log_n, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a, 0, 1 << log_n, e["seed"])
+    ctx.synchronize()
+    w = ctx.domain(1 << log_n)[2]
+    six.FORCE_COLLECTIVES = True
+    try:
+        be = HipBackend(ctx, exchange=x)
+        b = sixstep_forward(be, a, log_n, w, 0, 1, log_chunks=2)
+        back = sixstep_inverse(be, b, log_n, w, 0, 1, log_chunks=2)
+        l1, l2 = split_logs(log_n)
+        nat = be.transpose(b, 1 << l1, 1 << l2)
+        ctx.synchronize()
+    finally:
+        six.FORCE_COLLECTIVES = False
+    assert hashlib.blake2s(memoryview(nat.cpu().numpy()).cast("B"), digest_size=32).hexdigest() == e["fft"]
+    assert torch.equal(back, a)
+    x.close()
+
+
+@pytest.mark.parametrize("exchange", ["native", "torch"])
+def test_bench_four_step_on_real_rccl_at_world_1(exchange):
+    """bench.py's multi-GPU schedule on a real RCCL communicator with one rank (torchrun, --force-collectives): chunked,
+    pipelined exchanges through the library's own exchange (C ABI) and through torch.distributed; the forward output
+    must hash to the CPU oracle's digest."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577" if exchange == "native" else "29578",
+                          os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "sixstep", "--force-collectives",
+                          "--exchange", exchange, "--exchange-chunks", "4", "--steps", "3", "--warmup", "1",
+                          "--log-n", "22", "--strict-steps", "2", "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "fallback" not in line, line.get("fallback")
+    assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
+    assert line["collective_on_data_path"] is True and line["pipelined_across_steps"] is True
+    assert ("C ABI" in line["exchange"]["transport"]) == (exchange == "native")
+
+
 def test_rccl_exchange_when_two_devices_are_visible():
     """world = 2 over RCCL (one process per GPU); skipped on the single-GPU test box."""
     import torch
@@ -228,6 +366,36 @@ def test_rccl_exchange_when_two_devices_are_visible():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["checks"]["roundtrip"] is True
+
+
+@pytest.mark.parametrize("world,log_n,big", [(2, 19, 22), (8, 17, 23)])
+def test_bench_multi_rank_extras_with_ranks_sharing_the_gpu(world, log_n, big):
+    """Both halves of BASELINE's metric and config[4] out of ONE `bench.py --gpus N` line: the NTT + iNTT steps
+    (pipelined AND strict), `extra.lde_commit` = LDE x8 of 2^22 + commit across the ranks gated on the CPU oracle's
+    committed root, `extra.config4` = one strict-order transform of 2^big points over the ranks gated on its round
+    trip, direct evaluation of output points and the CPU oracle's committed digest.  Ranks share the GPU, exchanges
+    staged through the host (gloo) — the schedule, the gates and the JSON are what a real multi-GPU run produces."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29560 + world),
+                          os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "2",
+                          "--warmup", "1", "--log-n", str(log_n), "--big-log-n", str(big), "--strict-steps", "2",
+                          "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["checks"]["roundtrip"] is True
+    assert line["scaling"] == "weak" and line["mode"] == "sixstep" and line["collective_on_data_path"] is True
+    assert line["pipelined_across_steps"] is True and line["ms_per_step_strict"] > 0
+    lde = line["extra"]["lde_commit"]
+    assert lde.get("root_equals_cpu_oracle") is True and lde["root"] == FULL["lde"]["22"]["root"], lde
+    c4 = line["extra"]["config4"]
+    assert c4["checks"]["roundtrip"] is True and c4["checks"]["output_points_vs_direct_evaluation"] == 2, c4
+    assert c4["checks"].get("fft_digest_vs_cpu_oracle") is True
+    assert c4["exchange"]["xgmi_peak_gb_per_s_per_rank"] == 7 * 153.0
 
 
 @pytest.mark.parametrize("world,log_n,chunks", [(2, 21, 4), (4, 20, 8), (2, 19, 1)])
