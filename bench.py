@@ -56,7 +56,7 @@ WARM_MS = 150.0           # clocks settle after ~100 ms of load: warm up by time
 # regenerates the same SplitMix64 inputs on the device and refuses to print a number unless its
 # outputs hash to them.
 FIXTURES = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
-KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_MIN_LOG_C", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TW_SUB",
+KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_MIN_LOG_C", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TW_SUB", "HODOR_NTT_W9",
              "HODOR_MERKLE_TAIL_LOG", "HODOR_MERKLE_LAT_LOG", "HODOR_FRI_TAIL", "HODOR_FRI_FUSE_FOLD",
              "HODOR_BATCHINV_SEQ", "HODOR_DBG", "HODOR_LIB")
 
@@ -205,14 +205,31 @@ def main():
         dist.all_reduce(t, op=op, group=ctl["group"])
         return float(t.item())
 
-    if world > 1 or "RANK" in os.environ:
-        # RCCL prints banner lines ("Hostname : ...", "Librccl path : ...") on STDOUT when the first
-        # communicator is created; keep stdout to the single JSON line by parking fd 1 meanwhile.
+    import contextlib
+
+    @contextlib.contextmanager
+    def quiet_stdout():
+        """RCCL prints banner lines ("Hostname : ...", "Librccl path : ...") on STDOUT when a communicator is created;
+        stdout must stay the single JSON line, so fd 1 is parked meanwhile (and the C library's buffer pushed out
+        while it is)."""
         sys.stdout.flush()
         saved = os.dup(1)
         devnull = os.open(os.devnull, os.O_WRONLY)
         os.dup2(devnull, 1)
         try:
+            yield
+        finally:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:   # noqa: BLE001
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
+            os.close(devnull)
+
+    if world > 1 or "RANK" in os.environ:
+        with quiet_stdout():
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:
@@ -234,15 +251,6 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # every rank or none
                 if flag.item() > 0.5:
                     ctl["dev"], ctl["group"] = "cpu", g
-        finally:
-            try:   # the banner may still sit in the C library's buffer: push it out while fd 1 is parked
-                import ctypes
-                ctypes.CDLL(None).fflush(None)
-            except Exception:   # noqa: BLE001
-                pass
-            os.dup2(saved, 1)
-            os.close(saved)
-            os.close(devnull)
 
     ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=local_rank)
     log_n = args.log_n
@@ -282,7 +290,9 @@ def main():
         if args.exchange == "native" and (world > 1 or args.force_collectives):
             if args.backend != "nccl":
                 raise SystemExit("--exchange native needs one GPU per rank (RCCL); the gloo aid shares one device")
-            native = hodor_amd.Exchange.over_process_group(ctx, rank, world, group=ctl["group"])
+            with quiet_stdout():
+                native = hodor_amd.Exchange.over_process_group(ctx, rank, world, group=ctl["group"])
+                torch.cuda.synchronize()
         be = HipBackend(ctx, stream=stream, exchange=native)
         if world > 1:
             # the generator's natural block -> this rank's column block (layout A): pack + one exchange, untimed

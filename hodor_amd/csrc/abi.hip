@@ -31,16 +31,23 @@ static void make_params9(const HostField &F, Fr9Params *Q)
         if (i > 0) c -= 1;
         Q->c4p[i] = c;
     }
-    // 5p = 4p + p, spread the same way
-    uint32_t carry = 0;
-    for (int i = 0; i < 9; i++) {
-        uint32_t v = q[i] + Q->p[i] + carry;
-        carry = i < 8 ? v >> 29 : 0;
-        if (i < 8) v &= 0x1fffffffu;
-        if (i < 8) v += 1u << 29;
-        if (i > 0) v -= 1;
-        Q->c5p[i] = v;
-    }
+    // 5p = 4p + p and 11p = 5p + 5p + p, spread the same way
+    auto spread_sum = [&](const uint32_t *a, const uint32_t *b, uint32_t *plain, uint32_t *out) {
+        uint32_t carry = 0;
+        for (int i = 0; i < 9; i++) {
+            uint32_t v = a[i] + b[i] + carry;
+            carry = i < 8 ? v >> 29 : 0;
+            if (i < 8) v &= 0x1fffffffu;
+            plain[i] = v;
+            if (i < 8) v += 1u << 29;
+            if (i > 0) v -= 1;
+            out[i] = v;
+        }
+    };
+    uint32_t p5[9], p10[9], p11[9], scratch9[9];
+    spread_sum(q, Q->p, p5, Q->c5p);
+    spread_sum(p5, p5, p10, scratch9);
+    spread_sum(p10, Q->p, p11, Q->c11p);
     // mu = floor(2^(red_bit + 16) / p), red_bit = NUM_BITS - 5, by binary long division (~12-bit quotient)
     const int red_bit = (int)F.num_bits - 5;
     Q->red_shift = (uint32_t)(red_bit - 232);
@@ -83,7 +90,7 @@ static int free_tables(hodor_ctx *ctx)
 {
     HIPCHK(hipDeviceSynchronize());
     for (auto &t : ctx->pow_tables) { (void)hipFree(t.lo); (void)hipFree(t.hi); }
-    for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
+    for (auto &t : ctx->radix_tables) { (void)hipFree(t.rtw); if (t.rtw9) (void)hipFree(t.rtw9); }
     ctx->pow_tables.clear();
     ctx->radix_tables.clear();
     return HODOR_OK;
@@ -136,11 +143,12 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
 
 // omega_R^e = omega^(e << (log_n - log_r)), e < R/2
 static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uint32_t log_r,
-                           const uint4 **out)
+                           const uint4 **out, const uint32_t **out9)
 {
     for (auto &t : ctx->radix_tables)
         if (t.log_n == log_n && t.log_r == log_r && t.omega == omega) {
             *out = t.rtw;
+            *out9 = t.rtw9;
             return HODOR_OK;
         }
     RadixTable t;
@@ -151,9 +159,15 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     HIPCHK(hipMalloc((void **)&t.rtw, cnt * 112));
     HIPCHK(pow_table_w3_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt,
                                ctx->K3, ctx->P));
+    t.rtw9 = nullptr;
+    if (log_r >= 6) {   // the 16 powers omega_R^(e R/32) = omega^(e << (log_n - 5)) the wave-uniform steps use
+        HIPCHK(hipMalloc((void **)&t.rtw9, 16 * W9_WORDS * sizeof(uint32_t)));
+        HIPCHK(pow_table_w9_launch(ctx->stream, t.rtw9, to_dev(omega), log_n - 5, 16, ctx->K9, ctx->P));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->radix_tables.push_back(t);
     *out = t.rtw;
+    *out9 = t.rtw9;
     return HODOR_OK;
 }
 
@@ -298,7 +312,7 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         PassArgs A = {};
         A.src = cur;
         A.dst = outs[i];
-        if ((rc = get_radix_table(ctx, omega, log_n, log_r, &A.rtw))) return rc;
+        if ((rc = get_radix_table(ctx, omega, log_n, log_r, &A.rtw, &A.rtw9))) return rc;
         A.tw = (i + 1 == passes) ? tw_last : tw;
         A.tw_always = (fold_scale && i + 1 == passes) ? 1 : 0;
         A.pre = (i == 0) ? pre_t : TwoLevel{nullptr, nullptr, 0};
@@ -427,6 +441,11 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
             ctx->F.into_repr(ctx->F.pow(two, 87 * (uint64_t)(c + 1)), plain.l);
             ctx->K3.k[c] = to_dev(plain);
         }
+        for (int c = 0; c < 9; c++) {
+            HFr plain;
+            ctx->F.into_repr(ctx->F.pow(two, 29 * (uint64_t)(c + 1)), plain.l);
+            ctx->K9.k[c] = to_dev(plain);
+        }
     }
     // BASE_BLAKE2S_PARAMS, src/iop/blake2s_trivial_iop.rs:8-16
     HostBlake2s::keyed_midstate(ctx->mid.h, (const uint8_t *)"Squeamish Ossifrage", 19,
@@ -458,7 +477,7 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
         for (auto &t : ctx->pow_tables) { (void)hipFree(t.lo); (void)hipFree(t.hi); }
-        for (auto &t : ctx->radix_tables) (void)hipFree(t.rtw);
+        for (auto &t : ctx->radix_tables) { (void)hipFree(t.rtw); if (t.rtw9) (void)hipFree(t.rtw9); }
         for (int i = 0; i < 2; i++)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
         if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);

@@ -29,6 +29,8 @@ hipError_t degree_one_launch(hipStream_t s, uint4 *out, uint64_t n, const TwoLev
                              const Fr9Params &Q);
 hipError_t pow_table_w3_launch(hipStream_t, uint4 *out, const Fr &base, const Fr &mult,
                                uint32_t log_stride, uint64_t count, const W3Consts &, const FrParams &);
+hipError_t pow_table_w9_launch(hipStream_t, uint32_t *out, const Fr &base, uint32_t log_stride, uint32_t count,
+                               const W9Consts &, const FrParams &);
 hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const TwoLevel &t, const Fr9Params &);
 hipError_t distribute_powers_small_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
 hipError_t gen_elements_launch(hipStream_t, uint4 *out, uint64_t first, uint64_t count, uint64_t seed,
@@ -114,6 +116,7 @@ struct RadixTable {
     HFr omega;
     uint32_t log_n, log_r;
     uint4 *rtw;
+    uint32_t *rtw9;        // omega_R^(e R/32), e < 16, W9 entries (null for R < 64)
 };
 
 }  // namespace hodor
@@ -126,6 +129,7 @@ struct hodor_ctx {
     FrParams P;
     Fr9Params Q;
     W3Consts K3;               // 2^87, 2^174, 2^261 mod p (plain integers) for the W3 table generator
+    W9Consts K9;               // 2^(29 (c + 1)) mod p, c = 0 .. 8, for the W9 table generator
     B2Mid mid;
     hipStream_t stream = nullptr;
     std::mutex mu;

@@ -34,6 +34,7 @@ struct Fr9Params {      // kernel argument -> SGPRs
     uint32_t pinv;      // -p^-1 mod 2^29
     uint32_t c4p[9];    // 4p with limbs 0..7 in [2^29, 2^30): subtraction offset (subtrahend < 2.1p)
     uint32_t c5p[9];    // 5p spread the same way: subtraction offset of k_ntt_pass (subtrahend < 4p)
+    uint32_t c11p[9];   // 11p spread the same way: offset for subtrahends < 10p (W9 products, fr9w3.cuh)
     uint32_t mu;        // floor(2^(red_bit + 16) / p): quotient estimate for the partial reduction
     uint32_t red_shift; // red_bit - 232 with red_bit = NUM_BITS - 5: the estimate reads x >> red_bit from limb 8
 };

@@ -64,6 +64,68 @@ __device__ __forceinline__ Fr9 fr9_mul3(const Fr9 &a, const Fr9W3 &W, const Fr9P
     return t;
 }
 
+// ---- W9: the same idea with one-limb groups, for WAVE-UNIFORM constants ------------------------------------
+//     V_c = w * 2^(29 (c + 1)) mod p,  c = 0 .. 8;     T = sum_c x_c V_c  ==  x w 2^29 (mod p),  9 columns
+//     r = (T + m p) / 2^29  ==  x w (mod p),           m = -T p^-1 mod 2^29
+// ONE Montgomery step: 81 + 9 v_mad_u64_u32 and 1 v_mul_lo against the 108 + 3 of fr9_mul3.  The entry is 81
+// limbs — far too much to fetch per lane, but a constant shared by the whole wave is read with scalar loads and
+// enters the multiplier as an SGPR operand (free, like the modulus): the twiddles of the first radix-4 steps of
+// a pass, which take only a handful of values (k_ntt_pass).  Table layout: column-major, V[k][c] = limb k of
+// V_c, 9 words per column padded to 12 (so that a column is three aligned dwordx4), 108 words per entry.
+// Bounds: x normalized and < 2^261 (every limb < 2^29) => T < 9 * 2^29 p, r < 10 p, normalized.
+typedef const __attribute__((address_space(4))) uint32_t *W9Ptr;
+
+__device__ __forceinline__ Fr9 fr9_mul9(const Fr9 &a, W9Ptr V, const Fr9Params &P)
+{
+    Fr9 t;
+    uint64_t acc = 0;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) FR9_MAD(acc, a.v[c], V[12 * k + c]);
+        if (k == 0) m = ((uint32_t)acc * P.pinv) & HODOR_M29;
+        FR9_MAD(acc, m, P.p[k]);
+        if (k > 0) t.v[k - 1] = (uint32_t)acc & HODOR_M29;
+        acc >>= 29;
+    }
+    t.v[8] = (uint32_t)acc;
+    return t;
+}
+
+// two products by the same constant, column by column: the scalar operands of a column are loaded once
+__device__ __forceinline__ void fr9_mul9x2(Fr9 &a, Fr9 &b, W9Ptr V, const Fr9Params &P)
+{
+    Fr9 ta, tb;
+    uint64_t acca = 0, accb = 0;
+    uint32_t ma = 0, mb = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            const uint32_t v = V[12 * k + c];
+            FR9_MAD(acca, a.v[c], v);
+            FR9_MAD(accb, b.v[c], v);
+        }
+        if (k == 0) {
+            ma = ((uint32_t)acca * P.pinv) & HODOR_M29;
+            mb = ((uint32_t)accb * P.pinv) & HODOR_M29;
+        }
+        FR9_MAD(acca, ma, P.p[k]);
+        FR9_MAD(accb, mb, P.p[k]);
+        if (k > 0) {
+            ta.v[k - 1] = (uint32_t)acca & HODOR_M29;
+            tb.v[k - 1] = (uint32_t)accb & HODOR_M29;
+        }
+        acca >>= 29;
+        accb >>= 29;
+    }
+    ta.v[8] = (uint32_t)acca;
+    tb.v[8] = (uint32_t)accb;
+    a = ta;
+    b = tb;
+}
+
 // 27 limbs stored as 7 x 16 bytes (28 words, the last one unused)
 __device__ __forceinline__ Fr9W3 fr9w3_load(const void *ptr)
 {

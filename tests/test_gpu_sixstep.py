@@ -368,7 +368,7 @@ def test_rccl_exchange_when_two_devices_are_visible():
     assert line["n_gpus"] == 2 and line["checks"]["roundtrip"] is True
 
 
-@pytest.mark.parametrize("world,log_n,big", [(2, 19, 22), (8, 17, 23)])
+@pytest.mark.parametrize("world,log_n,big", [(2, 19, 22), (8, 17, 24)])
 def test_bench_multi_rank_extras_with_ranks_sharing_the_gpu(world, log_n, big):
     """Both halves of BASELINE's metric and config[4] out of ONE `bench.py --gpus N` line: the NTT + iNTT steps
     (pipelined AND strict), `extra.lde_commit` = LDE x8 of 2^22 + commit across the ranks gated on the CPU oracle's
