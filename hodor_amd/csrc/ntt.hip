@@ -171,7 +171,8 @@ constexpr int NTT_MAX_THREADS = 512;
 // switches used to apportion the kernel's time; the shipped library is compiled without them.
 #ifdef HODOR_ABLATE
 #define ABL(bit) (A.dbg & (bit))
-// HODOR_DBG bit 16: wave 0 of every 64th workgroup stamps the shader clock at its phase boundaries into
+// HODOR_DBG bit 32: intermediates cross HBM without reduction / pack / unpack (the arithmetic a lazy 48-byte
+// record format would save, at unchanged traffic: an upper bound for that design).  HODOR_DBG bit 16: wave 0 of every 64th workgroup stamps the shader clock at its phase boundaries into
 // hodor_ablate_stamps (read back by bench/phase_timeline.py); bits 8-9 select the pass (log_l / 8)
 __device__ unsigned long long hodor_ablate_stamps[1024 * 16];
 #define STAMP(slot)                                                                                   \
@@ -270,6 +271,11 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
             } else if (MODE == 1 && A.src_split.on) {
                 x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, by)));
+            } else if (ABL(32) && A.apply_tw) {   // upper bound of "lazy intermediates": the words as they are, no unpack
+                Fr raw = fr_load(src_b + 2 * g);
+#pragma unroll
+                for (int k = 0; k < 8; k++) x.v[k] = raw.v[k] & HODOR_M29;
+                x.v[8] = 0;
             } else {
                 x = fr9_unpack(fr_load(src_b + 2 * g));
             }
@@ -451,7 +457,13 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         if (MODE == 1 && colm && A.tw2d.lo != nullptr && !A.tw2d_on_load)
             x = mul_two_level(x, A.tw2d, o * (A.col0 + colbase + c), false, Q);
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
-        Fr y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
+        Fr y;
+        if (ABL(32) && !last) {                   // ... and no reduction / pack on the way out
+#pragma unroll
+            for (int k = 0; k < 8; k++) y.v[k] = x.v[k];
+        } else {
+            y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
+        }
         if (ABL(8) && y.v[0] != 0x12345u) continue;
         // streaming stores: the output crosses the chip once and should not push the twiddle tables out of L2
         // (-1 % on the 2^24 step; streaming LOADS of the data measured +0.8 %)
