@@ -623,6 +623,7 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
                               "kernel": "k_ntt_pass", "avg_launch_ms": avg_launch_ms,
+                              "avg_launch_ms_includes_exchange_waits": bool(args.mode == "sixstep" and (world > 1 or args.force_collectives)),
                               "rocprofv3_avg_launch_ms": profiled_ms,
                               "launches_per_transform": passes,
                               "alg_bytes_per_launch": alg_bytes_per_launch,

@@ -307,13 +307,16 @@ class Exchange:
 
     def exchange(self, send, recv, log_chunks=0, chunk=0, stream=None):
         """Chunk `chunk` of 2^log_chunks of the (n_local, 4) buffers goes on the wire behind everything enqueued on
-        `stream` so far; `stream` does not wait (see wait)."""
+        `stream` so far; `stream` does not wait (see wait).  Returns the exchange's ticket."""
+        ticket = C.c_uint64(0)
         self.ctx._chk(self.ctx.L.hodor_sixstep_exchange_dev(self.h, C.c_void_p(stream), _dptr(send), _dptr(recv),
                                                             C.c_size_t(send.shape[0]), C.c_uint32(log_chunks),
-                                                            C.c_uint32(chunk)))
+                                                            C.c_uint32(chunk), C.byref(ticket)))
+        return int(ticket.value)
 
-    def wait(self, stream=None):
-        self.ctx._chk(self.ctx.L.hodor_sixstep_exchange_wait_dev(self.h, C.c_void_p(stream)))
+    def wait(self, stream=None, ticket=0):
+        """`stream` waits for the exchange `ticket` (as returned by exchange) and all earlier ones; 0 = all so far."""
+        self.ctx._chk(self.ctx.L.hodor_sixstep_exchange_wait_dev(self.h, C.c_void_p(stream), C.c_uint64(ticket)))
 
     def close(self):
         if self.h:

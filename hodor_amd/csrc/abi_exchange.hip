@@ -14,8 +14,9 @@
 //                                                  communication stream wait for it and enqueues the grouped
 //                                                  ncclSend / ncclRecv of the P slabs there: `stream` itself does NOT
 //                                                  wait, so the arithmetic of the next chunk overlaps the wire time;
-//     hodor_sixstep_exchange_wait_dev(x, stream)   makes `stream` wait for every exchange issued so far (before the
-//                                                  consuming rows / columns call reads the receive buffer).
+//     hodor_sixstep_exchange_wait_dev(x, stream, t) makes `stream` wait for the exchange with ticket t and all earlier ones
+//                                                  (0: every exchange issued so far) before the consuming rows / columns
+//                                                  call reads the receive buffer.
 // The caller keeps send and receive buffers alive and untouched from the exchange call to the wait.
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: every function is resolved with dlsym
@@ -81,8 +82,9 @@ struct hodor_exchange {
     uint32_t n_ranks = 1, rank = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ready = nullptr;     // recorded on the caller's stream: the chunk has been produced
-    hipEvent_t done = nullptr;      // recorded on comm_stream after the latest exchange
-    bool issued = false;
+    static constexpr uint64_t RING = 64;
+    hipEvent_t done[RING] = {};     // done[t % RING]: recorded on comm_stream after exchange number t (tickets start at 1)
+    uint64_t issued = 0;            // number of exchanges enqueued so far = the latest ticket
     std::mutex mu;
 };
 
@@ -113,12 +115,17 @@ static int exchange_finish(hodor_ctx *ctx, hodor_exchange *x, hodor_exchange **o
 {
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&x->ready, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&x->done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&x->ready, hipEventDisableTiming)) != hipSuccess) {
         set_err(ctx, std::string("exchange: ") + hipGetErrorString(e));
         hodor_exchange_destroy(x);
         return HODOR_ERR_DEVICE;
     }
+    for (uint64_t i = 0; i < hodor_exchange::RING; i++)
+        if ((e = hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming)) != hipSuccess) {
+            set_err(ctx, std::string("exchange: ") + hipGetErrorString(e));
+            hodor_exchange_destroy(x);
+            return HODOR_ERR_DEVICE;
+        }
     *out = x;
     return HODOR_OK;
 }
@@ -173,7 +180,8 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
     if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
     if (x->owns_comm && x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);
-    if (x->done) (void)hipEventDestroy(x->done);
+    for (uint64_t i = 0; i < hodor_exchange::RING; i++)
+        if (x->done[i]) (void)hipEventDestroy(x->done[i]);
     if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
     delete x;
 }
@@ -182,7 +190,7 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
 // n_ranks equal slabs; slab t of the send piece goes to rank t, slab s of the receive piece comes from rank s —
 // exactly the buffers hodor_sixstep_columns_dev / _rows_dev write and gather from.
 extern "C" int hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const hodor_fr *send, hodor_fr *recv,
-                                          size_t n_local, uint32_t log_chunks, uint32_t chunk)
+                                          size_t n_local, uint32_t log_chunks, uint32_t chunk, uint64_t *ticket)
 {
     if (!x || !x->ctx) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = x->ctx;
@@ -211,17 +219,25 @@ extern "C" int hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const
         }
     }
     NCCLCHK(R.GroupEnd());
-    HIPCHK(hipEventRecord(x->done, x->comm_stream));
-    x->issued = true;
+    x->issued += 1;
+    HIPCHK(hipEventRecord(x->done[x->issued % hodor_exchange::RING], x->comm_stream));
+    if (ticket) *ticket = x->issued;
     return HODOR_OK;
 }
 
-extern "C" int hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream)
+// `ticket`: what hodor_sixstep_exchange_dev handed out for the LAST chunk the consumer needs (the communication stream
+// runs in order, so every earlier exchange is then complete too); 0 = everything issued so far.  Two transforms in
+// flight on one handle (the forward of one step interleaved with the inverse of another) therefore wait for their own
+// exchanges only.  A ticket more than 64 exchanges old has been overtaken: the wait then covers everything.
+extern "C" int hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream, uint64_t ticket)
 {
     if (!x || !x->ctx) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = x->ctx;
     NEED_DEVICE();
     std::lock_guard<std::mutex> lk(x->mu);
-    if (x->issued) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, x->done, 0));
+    if (x->issued == 0) return HODOR_OK;
+    if (ticket > x->issued) { set_err(ctx, "exchange: ticket from the future"); return HODOR_ERR_INVALID; }
+    if (ticket == 0 || x->issued - ticket >= hodor_exchange::RING) ticket = x->issued;
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, x->done[ticket % hodor_exchange::RING], 0));
     return HODOR_OK;
 }

@@ -166,22 +166,22 @@ def _exchange_begin(produce, m, world, group, log_chunks, native=None, stream=No
     for k in range(K):
         produce(k, send[k * step:(k + 1) * step])
         if collective and native is not None:
-            native.exchange(send, recv, log_chunks, k, stream=stream)
+            ticket = native.exchange(send, recv, log_chunks, k, stream=stream)
         elif collective:
             works.append(_all_to_all(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step], group, async_op=True))
     if collective and native is not None:
         # the communication stream reads `send` after this function has returned: the handle keeps it alive until
         # the compute stream has been made to wait for the exchange (the allocator reuses memory in stream order)
-        works.append(_NativeWait(native, stream, send))
+        works.append(_NativeWait(native, stream, send, ticket))
     return recv, works
 
 
 class _NativeWait:
-    def __init__(self, native, stream, keep):
-        self.native, self.stream, self.keep = native, stream, keep
+    def __init__(self, native, stream, keep, ticket):
+        self.native, self.stream, self.keep, self.ticket = native, stream, keep, ticket
 
     def wait(self):
-        self.native.wait(stream=self.stream)
+        self.native.wait(stream=self.stream, ticket=self.ticket)    # this transform's last chunk, not another's
         self.keep = None
         return True
 

@@ -290,10 +290,12 @@ int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor
  *                              buffers, P slabs each: slab t of the send piece -> rank t, slab s of the receive piece
  *                              <- rank s) as grouped ncclSend/ncclRecv on the handle's communication stream, ordered
  *                              AFTER everything enqueued on `stream` so far; `stream` does not wait, so the next chunk's
- *                              arithmetic overlaps the wire time
- *   hodor_sixstep_exchange_wait_dev  `stream` waits for every exchange issued so far (call it before the consuming
- *                              hodor_sixstep_rows_dev / _columns_dev); send and receive buffers must stay alive and
- *                              untouched between the two calls.
+ *                              arithmetic overlaps the wire time; *ticket (may be NULL) numbers the exchange
+ *   hodor_sixstep_exchange_wait_dev  `stream` waits for the exchange with that ticket and every earlier one (0: all
+ *                              issued so far) — call it with the LAST chunk's ticket before the consuming
+ *                              hodor_sixstep_rows_dev / _columns_dev; two transforms in flight on one handle wait for
+ *                              their own exchanges only.  Send and receive buffers must stay alive and untouched
+ *                              between the two calls.
  * Destroy the handle before its context. */
 typedef struct hodor_exchange hodor_exchange;
 #define HODOR_EXCHANGE_ID_BYTES 128
@@ -304,8 +306,8 @@ int  hodor_exchange_create(hodor_ctx *ctx, const uint8_t id[HODOR_EXCHANGE_ID_BY
 int  hodor_exchange_adopt(hodor_ctx *ctx, void *nccl_comm, uint32_t n_ranks, uint32_t rank, hodor_exchange **out);
 void hodor_exchange_destroy(hodor_exchange *x);
 int  hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const hodor_fr *send, hodor_fr *recv, size_t n_local,
-                                uint32_t log_chunks, uint32_t chunk);
-int  hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream);
+                                uint32_t log_chunks, uint32_t chunk, uint64_t *ticket);
+int  hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream, uint64_t ticket);
 /* Synthetic input for tests and benchmarks: dst[r] = element first_index + r of the
  * index-addressable SplitMix64 stream `seed` — uniform canonical residues (rejection-sampled < p)
  * in Montgomery form, i.e. what the reference's tests draw with Fr::rand (src/fft/mod.rs:71-77), but

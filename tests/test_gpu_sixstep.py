@@ -301,8 +301,9 @@ def test_native_exchange_over_rccl_at_world_1(gpu_ctxs):
         recv = torch.zeros_like(send)
         for k in range(4):       # producer on `side`, chunk k on the wire right behind it
             ctx.gen_elements_dev(send[k * (n // 4):(k + 1) * (n // 4)], k * (n // 4), n // 4, 99, stream=side.cuda_stream)
-            x.exchange(send, recv, 2, k, stream=side.cuda_stream)
-        x.wait(stream=side.cuda_stream)
+            t = x.exchange(send, recv, 2, k, stream=side.cuda_stream)
+            assert t == k + 1
+        x.wait(stream=side.cuda_stream, ticket=t)
         got = recv.clone()       # on `side`, behind the wait
     side.synchronize()
     assert torch.equal(got, send)
