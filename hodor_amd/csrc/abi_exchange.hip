@@ -11,8 +11,9 @@
 // Ordering.  The exchange of a chunk runs on a communication stream the hodor_exchange owns:
 //     hodor_sixstep_exchange_dev(x, stream, ...)   records an event on `stream` (everything enqueued there so far —
 //                                                  the kernels that wrote the chunk — must finish first), makes the
-//                                                  communication stream wait for it and enqueues the grouped
-//                                                  ncclSend / ncclRecv of the P slabs there: `stream` itself does NOT
+//                                                  communication stream wait for it and enqueues RCCL's
+//                                                  all-to-all of the P slabs (ncclAllToAll; grouped ncclSend / ncclRecv where
+//                                                  the library lacks it) there: `stream` itself does NOT
 //                                                  wait, so the arithmetic of the next chunk overlaps the wire time;
 //     hodor_sixstep_exchange_wait_dev(x, stream, t) makes `stream` wait for the exchange with ticket t and all earlier ones
 //                                                  (0: every exchange issued so far) before the consuming rows / columns
@@ -35,6 +36,7 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllToAll) AllToAll = nullptr;   // RCCL's own entry point (absent from NCCL proper): optional
     std::string why;
     bool ok = false;
 };
@@ -67,6 +69,7 @@ const Rccl &rccl()
         BIND(Send, ncclSend)
         BIND(Recv, ncclRecv)
 #undef BIND
+        r.AllToAll = reinterpret_cast<decltype(r.AllToAll)>(dlsym(r.lib, "ncclAllToAll"));
         r.ok = true;
         return r;
     }();
@@ -114,7 +117,11 @@ extern "C" int hodor_exchange_unique_id(uint8_t id[HODOR_EXCHANGE_ID_BYTES])
 static int exchange_finish(hodor_ctx *ctx, hodor_exchange *x, hodor_exchange **out)
 {
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking)) != hipSuccess ||
+    // highest priority: a chunk's exchange must not queue behind the workgroups of the next chunk's arithmetic, which
+    // is what it is supposed to overlap (and what the consuming call finally waits for)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if ((e = hipStreamCreateWithPriority(&x->comm_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&x->ready, hipEventDisableTiming)) != hipSuccess) {
         set_err(ctx, std::string("exchange: ") + hipGetErrorString(e));
         hodor_exchange_destroy(x);
@@ -208,17 +215,23 @@ extern "C" int hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const
     HIPCHK(hipEventRecord(x->ready, (hipStream_t)stream));
     HIPCHK(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
     const Rccl &R = rccl();
-    NCCLCHK(R.GroupStart());
-    for (uint32_t peer = 0; peer < x->n_ranks; peer++) {
-        ncclResult_t a = R.Send(s + (size_t)peer * slab * 32, slab * 32, ncclInt8, (int)peer, x->comm, x->comm_stream);
-        ncclResult_t b = R.Recv(r + (size_t)peer * slab * 32, slab * 32, ncclInt8, (int)peer, x->comm, x->comm_stream);
-        if (a != ncclSuccess || b != ncclSuccess) {
-            (void)R.GroupEnd();
-            set_err(ctx, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(a != ncclSuccess ? a : b));
-            return HODOR_ERR_DEVICE;
+    if (R.AllToAll) {
+        // RCCL's all-to-all of equal pieces: the same P sends and P receives, issued by the library that knows the
+        // topology (and a plain device copy on a one-rank communicator)
+        NCCLCHK(R.AllToAll(s, r, slab * 32, ncclInt8, x->comm, x->comm_stream));
+    } else {
+        NCCLCHK(R.GroupStart());
+        for (uint32_t peer = 0; peer < x->n_ranks; peer++) {
+            ncclResult_t a = R.Send(s + (size_t)peer * slab * 32, slab * 32, ncclInt8, (int)peer, x->comm, x->comm_stream);
+            ncclResult_t b = R.Recv(r + (size_t)peer * slab * 32, slab * 32, ncclInt8, (int)peer, x->comm, x->comm_stream);
+            if (a != ncclSuccess || b != ncclSuccess) {
+                (void)R.GroupEnd();
+                set_err(ctx, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(a != ncclSuccess ? a : b));
+                return HODOR_ERR_DEVICE;
+            }
         }
+        NCCLCHK(R.GroupEnd());
     }
-    NCCLCHK(R.GroupEnd());
     x->issued += 1;
     HIPCHK(hipEventRecord(x->done[x->issued % hodor_exchange::RING], x->comm_stream));
     if (ticket) *ticket = x->issued;
