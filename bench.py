@@ -228,6 +228,9 @@ def main():
             os.close(saved)
             os.close(devnull)
 
+    # a process group exists: every control all-reduce, barrier and distributed extra below runs — also at world 1
+    # under --force-collectives (a one-rank RCCL communicator), which is how those paths are exercised on a 1-GPU box
+    multi = world > 1 or (args.force_collectives and "RANK" in os.environ)
     if world > 1 or "RANK" in os.environ:
         with quiet_stdout():
             if args.backend == "nccl":
@@ -237,7 +240,7 @@ def main():
             warm = torch.zeros(1, device=ctl["dev"])
             dist.all_reduce(warm)
             torch.cuda.synchronize()
-            if args.backend == "nccl" and world > 1:
+            if args.backend == "nccl" and multi:
                 # verdicts and retreat decisions travel on a host-side (gloo) group of their own: they must still get
                 # through when the RCCL communicator is what failed, and must not queue behind its pending exchanges
                 g, have = None, 1.0
@@ -365,7 +368,7 @@ def main():
         drain()
         torch.cuda.synchronize()
         spent = (time.perf_counter() - t_warm) * 1e3
-        if world > 1:
+        if multi:
             spent = all_reduce_scalar(spent, dist.ReduceOp.MAX)
         per_step = spent / max(args.warmup, 1)
         extra = 0 if spent >= WARM_MS else int((WARM_MS - spent) / max(per_step, 1e-3)) + 1
@@ -385,7 +388,7 @@ def main():
         except Exception as exc:   # noqa: BLE001
             err = "%s: %s" % (type(exc).__name__, str(exc)[:160])
         failed = 1.0 if err else 0.0
-        if world > 1:
+        if multi:
             failed = all_reduce_scalar(failed, dist.ReduceOp.MAX)
         if failed > 0.5 and err is None:
             err = "failed on another rank"
@@ -420,7 +423,7 @@ def main():
     # correctness gates (outside the timed region): the round trip, and — where the CPU oracle's answer
     # for this exact input is committed — every element of the forward transform through its digest
     ok = True if args.skip_checks else bool(torch.equal(a, c))
-    if world > 1:      # every rank must reach the same verdict (a lone SystemExit would hang the others)
+    if multi:      # every rank must reach the same verdict (a lone SystemExit would hang the others)
         ok = all_reduce_scalar(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
     checks = {"skipped": True} if args.skip_checks else {"roundtrip": ok}
     if not ok:
@@ -437,7 +440,7 @@ def main():
         checks["fft_digest_vs_cpu_oracle"] = True
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     barrier()
@@ -453,7 +456,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
-    if world > 1:
+    if multi:
         dt = all_reduce_scalar(dt, dist.ReduceOp.MAX)
 
     def timed(step, drain, steps):
@@ -467,7 +470,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         d = time.perf_counter() - t
-        if world > 1:
+        if multi:
             d = all_reduce_scalar(d, dist.ReduceOp.MAX)
         return d / steps * 1e3
 
@@ -503,7 +506,7 @@ def main():
                     "all_to_all_ms_unoverlapped": ms, "gb_per_s_per_rank": (sent / (ms * 1e-3) / 1e9) if world > 1 else None,
                     "share_of_step": 2 * ms / (dt / args.steps * 1e3) if world > 1 else 0.0}
 
-    if world > 1 and args.mode == "sixstep" and not args.skip_checks:
+    if multi and args.mode == "sixstep" and not args.skip_checks:
         # After the measurement (so that nothing it needs can disturb the timed region): the whole forward transform
         # against the CPU oracle's committed digest of the 2^log_total-point transform of the same generator stream —
         # layout B -> natural blocks (one more exchange), gathered on rank 0.  A mismatch withholds the line; a
@@ -642,11 +645,11 @@ def main():
             "frac": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12 / MAD_PEAK_TOPS,
             "mad_floor_ms_per_transform": mad_floor_ms,
             "ms_per_transform": avg_launch_ms * passes}
-        if not args.no_extra and world == 1:
+        if not args.no_extra and not multi:
             result["extra"] = extra_lde_commit(ctx, torch, stream)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
-    if world > 1 and not args.no_extra:
+    if multi and not args.no_extra:
         # the other half of BASELINE's metric and config[4], every rank takes part (collectives inside)
         del b, c
         holder.clear()

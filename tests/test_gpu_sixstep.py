@@ -331,18 +331,21 @@ def test_native_exchange_over_rccl_at_world_1(gpu_ctxs):
 
 @pytest.mark.parametrize("exchange", ["native", "torch"])
 def test_bench_four_step_on_real_rccl_at_world_1(exchange):
-    """bench.py's multi-GPU schedule on a real RCCL communicator with one rank (torchrun, --force-collectives): chunked,
-    pipelined exchanges through the library's own exchange (C ABI) and through torch.distributed; the forward output
-    must hash to the CPU oracle's digest."""
+    """bench.py's multi-GPU code paths on a real RCCL communicator with one rank (torchrun, --force-collectives): the
+    chunked, pipelined exchanges through the library's own exchange (C ABI) and through torch.distributed, the host-side
+    control group next to the RCCL one, the agreed verdicts, and — with the torch transport — both distributed extras
+    (LDE x8 + commit by cosets, the config[4]-shaped strict transform with its gather-and-digest gate).  Everything a
+    multi-GPU run executes except more than one device."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    extras = ["--big-log-n", "24"] if exchange == "torch" else ["--no-extra"]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29577" if exchange == "native" else "29578",
                           os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "sixstep", "--force-collectives",
                           "--exchange", exchange, "--exchange-chunks", "4", "--steps", "3", "--warmup", "1",
-                          "--log-n", "22", "--strict-steps", "2", "--no-cpu-baseline", "--no-extra"],
+                          "--log-n", "22", "--strict-steps", "2", "--no-cpu-baseline"] + extras,
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -350,6 +353,10 @@ def test_bench_four_step_on_real_rccl_at_world_1(exchange):
     assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
     assert line["collective_on_data_path"] is True and line["pipelined_across_steps"] is True
     assert ("C ABI" in line["exchange"]["transport"]) == (exchange == "native")
+    if exchange == "torch":
+        assert line["extra"]["lde_commit"]["root"] == FULL["lde"]["22"]["root"], line["extra"]["lde_commit"]
+        c4 = line["extra"]["config4"]
+        assert c4["checks"] == {"roundtrip": True, "output_points_vs_direct_evaluation": 2, "fft_digest_vs_cpu_oracle": True}, c4
 
 
 def test_rccl_exchange_when_two_devices_are_visible():
