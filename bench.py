@@ -614,14 +614,41 @@ def main():
             pass
         # the resource that actually binds: v_mad_u64_u32 issue.  Products per element and transform =
         # butterflies (0.5 per stage, minus the trivial twiddles of each pass's first two stages) +
-        # inter-pass twiddles (1 for the second pass, 2 from the third on); every product is
-        # data x W3 table constant = 108 mads (fr9w3.cuh); 9 more per element where a pass reduces its
-        # output.  Peak = bench/microbench.hip on this part.
+        # inter-pass twiddles (1 for the second pass, 2 from the third on); a product is data x W3 table constant =
+        # 108 mads (fr9w3.cuh), or data x wave-uniform W9 constant = 90 mads in the first radix-4 steps of a pass
+        # (k_ntt_pass; the launcher's choice of those steps is restated in pass_mads); 9 more per element where a
+        # pass reduces its output.  Peak = bench/microbench.hip on this part.
         base, rem = divmod(log_n, passes)
         radices = [base + (1 if i < rem else 0) for i in range(passes)]
         products = sum(0.5 * r - (0.75 if r % 2 == 0 else 0.5) for r in radices) + sum(min(i, 2) for i in range(passes))
-        mads_per_launch = n * (products * 108 + 9 * passes) / passes
-        mad_floor_ms = n * (products * 108 + 9 * passes) / (MAD_PEAK_TOPS * 1e12) * 1e3
+
+        def pass_mads(log_r):
+            """multiplier instructions per element of one un-padded pass of radix 2^log_r (butterfly steps only)"""
+            log_c = max(10 - log_r, 2)
+            lm0, bound0 = (1, 9) if log_r & 1 else (0, 4)
+            limit = 0
+            for T in (3, 2, 1, 0):                      # ntt_launch_pass: the largest T within the 63p bound
+                bound, any_, ok = bound0, False, True
+                for lm in range(lm0, log_r, 2):
+                    w9 = lm <= T
+                    any_ |= w9
+                    ok &= not (w9 and log_r - 2 + log_c < 6 + lm)
+                    bound = (20 if w9 else 14) if lm == 0 else bound + (22 if w9 else 10)
+                if any_ and ok and bound <= 63 and log_r >= 6:
+                    limit = T + 1
+                    break
+            per_item = 0.0                                 # (a leading radix-2 stage has half-size 1: twiddles 1, no product)
+            for lm in range(lm0, log_r, 2):
+                m = 1 << lm
+                if lm < limit:                          # W9: jp = 0 multiplies once and reduces three subtrahends (9 mads each)
+                    per_item += 90.0 if m == 1 else ((90 + 27) + (m - 1) * 4 * 90) / m
+                else:
+                    per_item += 108.0 if m == 1 else 4 * 108.0
+            return per_item / 4
+
+        mads_per_element = sum(pass_mads(r) for r in radices) + 108.0 * sum(min(i, 2) for i in range(passes)) + 9 * passes
+        mads_per_launch = n * mads_per_element / passes
+        mad_floor_ms = n * mads_per_element / (MAD_PEAK_TOPS * 1e12) * 1e3
         hbm_target_ms = 2.0 * n * 32 / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
@@ -633,14 +660,15 @@ def main():
                               "note": "integer-ALU-bound kernel (v_mad_u64_u32); HBM fraction reported as required. "
                                       "The north-star target of 40 %% of HBM peak (%.3f ms per 2^%d transform) is "
                                       "arithmetically out of reach for 255-bit modular products on 32-bit "
-                                      "multipliers: %.2f products x 108 mads per element at the measured %.0f Tmad/s "
+                                      "multipliers: %.2f products of 90-108 mads per element at the measured %.0f Tmad/s "
                                       "issue ceiling is already %.2f ms per transform (%.1fx the target) before any "
                                       "addition, carry or memory instruction"
                                       % (hbm_target_ms, log_n, products, MAD_PEAK_TOPS, mad_floor_ms,
                                          mad_floor_ms / hbm_target_ms)}
         if args.mode == "replicas":
           result["roofline"]["valu"] = {
-            "bound": "v_mad_u64_u32 issue", "products_per_element": products, "mads_per_product": 108,
+            "bound": "v_mad_u64_u32 issue", "products_per_element": products, "mads_per_product": "108 (W3) / 90 (wave-uniform W9)",
+            "mads_per_element": mads_per_element,
             "achieved": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
             "frac": mads_per_launch / (avg_launch_ms * 1e-3) / 1e12 / MAD_PEAK_TOPS,
             "mad_floor_ms_per_transform": mad_floor_ms,
