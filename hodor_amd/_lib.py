@@ -283,6 +283,7 @@ class Exchange:
         self.h = C.c_void_p()
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         ctx._chk(ctx.L.hodor_exchange_create(ctx.h, buf, C.c_uint32(n_ranks), C.c_uint32(rank), C.byref(self.h)))
+        ctx._exchanges.add(self)         # closed with (before) the context: the handle's calls report through it
 
     @staticmethod
     def available():
@@ -337,6 +338,7 @@ class Context:
         self.L = lib()
         self.h = C.c_void_p()
         self._protos = weakref.WeakSet()
+        self._exchanges = weakref.WeakSet()
         mod = (C.c_uint64 * 4)(*_limbs(modulus))
         rc = self.L.hodor_ctx_create(mod, C.c_uint64(generator), C.c_int(device), C.byref(self.h))
         if rc != OK:
@@ -353,6 +355,8 @@ class Context:
         if self.h:
             for proto in list(self._protos):
                 proto.free()
+            for x in list(self._exchanges):
+                x.close()
             self.L.hodor_ctx_destroy(self.h)
             self.h = None
 

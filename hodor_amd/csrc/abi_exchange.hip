@@ -80,6 +80,7 @@ const Rccl &rccl()
 
 struct hodor_exchange {
     hodor_ctx *ctx = nullptr;
+    int device = -1;                // copied at creation: destroy must not depend on the context still being alive
     ncclComm_t comm = nullptr;
     bool owns_comm = false;
     uint32_t n_ranks = 1, rank = 0;
@@ -150,6 +151,7 @@ extern "C" int hodor_exchange_create(hodor_ctx *ctx, const uint8_t id[HODOR_EXCH
     hodor_exchange *x = new (std::nothrow) hodor_exchange();
     if (!x) return HODOR_ERR_INVALID;
     x->ctx = ctx;
+    x->device = ctx->device;
     x->n_ranks = n_ranks;
     x->rank = rank;
     ncclUniqueId u;
@@ -174,6 +176,7 @@ extern "C" int hodor_exchange_adopt(hodor_ctx *ctx, void *nccl_comm, uint32_t n_
     hodor_exchange *x = new (std::nothrow) hodor_exchange();
     if (!x) return HODOR_ERR_INVALID;
     x->ctx = ctx;
+    x->device = ctx->device;
     x->comm = (ncclComm_t)nccl_comm;
     x->n_ranks = n_ranks;
     x->rank = rank;
@@ -183,7 +186,7 @@ extern "C" int hodor_exchange_adopt(hodor_ctx *ctx, void *nccl_comm, uint32_t n_
 extern "C" void hodor_exchange_destroy(hodor_exchange *x)
 {
     if (!x) return;
-    if (x->ctx && x->ctx->device >= 0) (void)hipSetDevice(x->ctx->device);
+    if (x->device >= 0) (void)hipSetDevice(x->device);
     if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
     if (x->owns_comm && x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);

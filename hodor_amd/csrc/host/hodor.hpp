@@ -459,6 +459,18 @@ struct NaiveFriIop {
         return ok != 0;
     }
 
+    // the same verdict with the proof's shape bound to the domain the verifier expects first (hodor_fri_verify_proof_strict):
+    // what a verifier of UNTRUSTED proofs calls — the reference's walk accepts a proof whose last rounds were cut off
+    static bool verify_proof_strict(const Field &F, const FRIProof &proof, size_t expected_domain_size,
+                                    size_t natural_element_index, const Fr &expected_value)
+    {
+        std::vector<uint8_t> raw = proof.to_bytes();
+        int ok = 0;
+        F.check(hodor_fri_verify_proof_strict(F.ctx(), raw.data(), raw.size(), expected_domain_size,
+                                              natural_element_index, &expected_value, &ok), "verify_proof_queries (strict)");
+        return ok != 0;
+    }
+
     static FRIProofPrototype proof_from_lde(const Polynomial<Values> &lde_values, size_t lde_factor,
                                             size_t output_coeffs_at_degree_plus_one)
     {
