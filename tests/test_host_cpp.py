@@ -62,3 +62,6 @@ def test_c_program_on_device(tmp_path):
     out = subprocess.run([_build_c(tmp_path), "0"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+    # a plain C process (no Python, no torch) binds RCCL at run time and runs the 4-step transform through
+    # hodor_sixstep_exchange_dev on a one-rank communicator
+    assert "through the library's exchange (one-rank RCCL) ok" in out.stdout, out.stdout + out.stderr
