@@ -44,7 +44,7 @@ EXPORTS = [
     "hodor_fft_dev", "hodor_fft_batch_dev", "hodor_twiddle_mul_dev", "hodor_poly_fft_dev", "hodor_poly_ifft_dev", "hodor_poly_coset_fft_dev",
     "hodor_poly_icoset_fft_dev", "hodor_poly_coset_fft_for_generator_dev", "hodor_poly_icoset_fft_for_generator_dev",
     "hodor_poly_coset_fft_for_generator", "hodor_poly_icoset_fft_for_generator", "hodor_poly_lde_dev", "hodor_poly_lde_batch_dev", "hodor_iop_create_batch_dev", "hodor_distribute_powers_dev", "hodor_poly_degree_one_on_domain_dev", "hodor_precomputed_omegas_dev",
-    "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev",
+    "hodor_poly_binary_dev", "hodor_poly_add_scaled_dev", "hodor_poly_unary_dev", "hodor_poly_quotient_term_dev",
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_proof_strict", "hodor_fri_verify_prototype",
@@ -643,6 +643,14 @@ class Context:
         """dst[r] = element first_index + r of the SplitMix64 input stream `seed`."""
         self._chk(self.L.hodor_gen_elements_dev(self.h, C.c_void_p(stream), _dptr(dst), C.c_uint64(first_index),
                                                 C.c_size_t(count), C.c_uint64(seed)))
+
+    def poly_quotient_term_dev(self, acc, f, divisor_inv, n, value, alpha=None, accumulate=True, stream=None):
+        """acc[i] (+)= alpha * (f[i] - value) * divisor_inv[i] in one pass (calculate_deep's quotient term)."""
+        v = _fr(value)
+        al = _fr(alpha) if alpha is not None else None
+        self._chk(self.L.hodor_poly_quotient_term_dev(self.h, C.c_void_p(stream), _dptr(acc), _dptr(f), _dptr(divisor_inv),
+                                                      C.c_size_t(n), C.byref(v), C.byref(al) if al is not None else None,
+                                                      C.c_int(1 if accumulate else 0)))
 
     def poly_batch_inversion_dev(self, a, n, stream=None):
         self._chk(self.L.hodor_poly_batch_inversion_dev(self.h, C.c_void_p(stream), _dptr(a), C.c_size_t(n)))

@@ -779,6 +779,19 @@ extern "C" int hodor_poly_unary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, s
     return HODOR_OK;
 }
 
+extern "C" int hodor_poly_quotient_term_dev(hodor_ctx *ctx, void *stream, hodor_fr *acc, const hodor_fr *f,
+                                            const hodor_fr *divisor_inv, size_t n, const hodor_fr *value,
+                                            const hodor_fr *alpha, int accumulate)
+{
+    NEED_DEVICE();
+    if (!acc || !f || !divisor_inv || !value) return HODOR_ERR_INVALID;
+    Fr a = {};
+    if (alpha) a = to_dev(to_h(alpha));
+    HIPCHK(quotient_term_launch(pick_stream(ctx, stream), (uint4 *)acc, (const uint4 *)f, (const uint4 *)divisor_inv, n,
+                                to_dev(to_h(value)), alpha ? &a : nullptr, accumulate != 0, ctx->P));
+    return HODOR_OK;
+}
+
 extern "C" int hodor_gen_elements_dev(hodor_ctx *ctx, void *stream, hodor_fr *dst, uint64_t first_index,
                                       size_t count, uint64_t seed)
 {

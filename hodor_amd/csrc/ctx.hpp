@@ -39,6 +39,8 @@ hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const Fr
 hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
 hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
 hipError_t unary_launch(hipStream_t, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &);
+hipError_t quotient_term_launch(hipStream_t, uint4 *acc, const uint4 *f, const uint4 *dinv, uint64_t n, const Fr &value,
+                                const Fr *alpha, bool accumulate, const FrParams &);
 hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod,
                                    uint32_t *zero_flag, const FrParams &);
 hipError_t batchinv_backward_launch(hipStream_t, uint4 *a, uint64_t n, uint64_t T, const uint4 *prefix,

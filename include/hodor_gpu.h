@@ -234,6 +234,13 @@ int hodor_poly_add_scaled_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, const h
 /* negate / square / pow(e) / scale(c) / add_constant(c) / sub_constant(c) */
 int hodor_poly_unary_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, int op, const hodor_fr *c,
                          uint64_t e);
+/* One DEEP quotient term in a single pass over the data: acc[i] = (accumulate ? acc[i] : 0) + alpha * (f[i] - value) *
+ * divisor_inv[i] (alpha NULL = 1) — the sequence clone / add_constant(-value) / scale(alpha) / mul_assign(divisor^-1) /
+ * add_assign of calculate_deep (src/ali/per_register/deep.rs:74-84 for every h1 term, :139-144 for h2), same canonical
+ * result, a fifth of the memory traffic.  acc may alias neither f nor divisor_inv. */
+int hodor_poly_quotient_term_dev(hodor_ctx *ctx, void *stream, hodor_fr *acc, const hodor_fr *f,
+                                 const hodor_fr *divisor_inv, size_t n, const hodor_fr *value, const hodor_fr *alpha,
+                                 int accumulate);
 /* batch_inversion: a[i] = a[i]^-1; HODOR_ERR_INVALID (data untouched) if any element is zero
  * (SynthesisError::Error, src/polynomials/mod.rs:909).  Synchronises the stream. */
 int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n);

@@ -33,17 +33,24 @@ def calculate_deep(ops, f_polys, f_ldes, g_poly, g_lde, scalars):
             q = ops.degree_one_on_domain(f_size, ops.F.one(), ops.F.neg(root), f_ldes[0])   # q(x) = x - root
             ops.batch_inversion(q)
             divisors[mi] = q
-        t = ops.clone(f_ldes[reg])
-        ops.add_constant(t, ops.F.neg(value))
-        ops.scale(t, scalars["alphas"][k])
-        ops.mul_assign(t, divisors[mi])
-        ops.add_assign(h1, t)
+        if hasattr(ops, "quotient_term"):                # the five passes below as one (hodor_poly_quotient_term_dev)
+            ops.quotient_term(h1, f_ldes[reg], divisors[mi], value, scalars["alphas"][k], True)
+        else:
+            t = ops.clone(f_ldes[reg])
+            ops.add_constant(t, ops.F.neg(value))
+            ops.scale(t, scalars["alphas"][k])
+            ops.mul_assign(t, divisors[mi])
+            ops.add_assign(h1, t)
     inv = ops.degree_one_on_domain(g_size, ops.F.one(), ops.F.neg(z), g_lde)
     ops.batch_inversion(inv)
     g_at_z = ops.evaluate_at(g_poly, z)
-    h2 = ops.clone(g_lde)
-    ops.add_constant(h2, ops.F.neg(g_at_z))
-    ops.mul_assign(h2, inv)
+    if hasattr(ops, "quotient_term"):
+        h2 = ops.empty(g_size, g_lde)
+        ops.quotient_term(h2, g_lde, inv, g_at_z, None, False)
+    else:
+        h2 = ops.clone(g_lde)
+        ops.add_constant(h2, ops.F.neg(g_at_z))
+        ops.mul_assign(h2, inv)
     return h1, h2, f_at_z_m, g_at_z
 
 
@@ -139,6 +146,18 @@ class DeviceOps:
 
     def add_assign(self, a, b):
         self.ctx.poly_binary_dev(a, b, a.shape[0], "add", stream=self.stream)
+
+
+class FusedDeviceOps(DeviceOps):
+    """DeviceOps with every quotient term — clone / add_constant / scale / mul_assign / add_assign — as ONE pass
+    (hodor_poly_quotient_term_dev): what a device-resident prover calls; same canonical results."""
+
+    def empty(self, n, like):
+        import torch
+        return torch.empty((n, 4), dtype=torch.int64, device=like.device)
+
+    def quotient_term(self, acc, f, divisor_inv, value, alpha, accumulate):
+        self.ctx.poly_quotient_term_dev(acc, f, divisor_inv, acc.shape[0], value, alpha, accumulate, stream=self.stream)
 
 
 def make_inputs(O, log_n, factor, g_factor, seed=0x44454550):

@@ -218,7 +218,7 @@ class DeviceProver:
         self.host_round_trips = 0
         prover = self
 
-        class CountingDeep(deep.DeviceOps):     # the two calls of calculate_deep that return to the host
+        class CountingDeep(deep.FusedDeviceOps):     # the two calls of calculate_deep that return to the host
             def evaluate_at(self, coeffs, x):
                 prover.host_round_trips += 1
                 return super().evaluate_at(coeffs, x)

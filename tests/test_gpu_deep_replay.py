@@ -9,10 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("log_n,factor,g_factor", [(5, 2, 2), (10, 4, 8), (15, 8, 16), (17, 8, 8)])
-def test_calculate_deep_sequence_device_resident_matches_oracle(gpu_ctxs, oracles, field_name, log_n, factor, g_factor):
+def test_calculate_deep_sequence_device_resident_matches_oracle(gpu_ctxs, oracles, field_name, log_n, factor, g_factor, fused):
+    """fused: every quotient term as ONE pass (hodor_poly_quotient_term_dev) instead of the reference's five
+    value-form operations — the oracle always runs the five."""
     import torch
-    from deep_replay_ref import DeviceOps, OracleOps, calculate_deep, make_inputs
+    from deep_replay_ref import DeviceOps, FusedDeviceOps, OracleOps, calculate_deep, make_inputs
     if field_name != "bn256" and log_n > 10:
         pytest.skip("large cases on the bn256.rs field only")
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
@@ -22,7 +25,7 @@ def test_calculate_deep_sequence_device_resident_matches_oracle(gpu_ctxs, oracle
     def dev(x):
         return torch.from_numpy(x.view(np.int64).copy()).cuda()
 
-    h1, h2, fz, gz = calculate_deep(DeviceOps(O, ctx), [dev(p) for p in f_polys], [dev(p) for p in f_ldes], dev(g_poly),
+    h1, h2, fz, gz = calculate_deep((FusedDeviceOps if fused else DeviceOps)(O, ctx), [dev(p) for p in f_polys], [dev(p) for p in f_ldes], dev(g_poly),
                                     dev(g_lde), scalars)
     ctx.synchronize()
     assert fz == e_fz and gz == e_gz
