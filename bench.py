@@ -234,7 +234,17 @@ def main():
     if world > 1 or "RANK" in os.environ:
         with quiet_stdout():
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                # the exchanges are meant to run BEHIND arithmetic that keeps every CU busy: on a default-priority
+                # stream their kernels queue behind the next chunk's workgroups (measured with the library's own
+                # exchange, profiles/r03/sixstep_world1_rccl.txt), so the communicator's streams get high priority
+                kw = {}
+                try:
+                    opts = dist.ProcessGroupNCCL.Options()
+                    opts.is_high_priority_stream = True
+                    kw["pg_options"] = opts
+                except Exception:   # noqa: BLE001 — an older torch: default streams
+                    pass
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
             else:
                 dist.init_process_group("gloo")
             warm = torch.zeros(1, device=ctl["dev"])
