@@ -8,6 +8,11 @@ anything written in this repository:
  * BLAKE2s: RFC 7693 Appendix B ("abc") and the first keyed vectors of the BLAKE2 reference
    implementation's `testvectors/blake2s-kat.txt` (key = 00 01 .. 1f, input = 00 01 .. n-1).
 
+ * the third modulus the tests drive the library with, the BN254 scalar field (not a field of the reference: it keeps
+   "the modulus is a run-time parameter" honest): its multiplicative generator 5, two-adicity 28 and 2^28-th root of
+   unity as published in arkworks `ark-bn254` (FrConfig::TWO_ADIC_ROOT_OF_UNITY; the same number is snarkjs's
+   `Fr.nqr^t` root) — canonical residue; the derive rule root_of_unity = generator^t reproduces it.
+
 They were typed from the published sources, not produced by code in this repository."""
 import ctypes as C
 
@@ -36,6 +41,32 @@ BLAKE2S_KEYED_KAT = [   # blake2s-kat.txt, key = 000102..1f
     (2, "6bb71300644cd3991b26ccd4d274acd1adeab8b1d7914546c1198bbe9fc9d803"),
 ]
 BLAKE2S_ABC = "508c5e8c327c14e2e1a72ba34eeb452f37458b209ed63a294d999b4c86675982"   # RFC 7693 App. B
+
+
+BN254_FR = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BN254_FR_ROOT_OF_UNITY = 19103219067921713944291392827692070036145651957329286315305642004821462161904   # canonical, order 2^28
+
+
+def test_bn254_scalar_field_constants(oracles):
+    """A second, unrelated published field through the same generic code paths (ofield_init / HostField::init)."""
+    O = oracles["bn254"]
+    assert O.f.s == 28
+    assert O.to_canonical(O.const("root_of_unity")) == BN254_FR_ROOT_OF_UNITY
+    hodor_amd.build()
+    ctx = hodor_amd.Context(BN254_FR, 5, device=-1)
+    assert ctx.S == 28 and ctx.num_bits == 254
+    assert ctx.into_repr(ctx.root_of_unity) == BN254_FR_ROOT_OF_UNITY
+    assert ctx.into_repr(ctx.domain(1 << 28)[2]) == BN254_FR_ROOT_OF_UNITY
+    ctx.close()
+
+
+def test_experiments_field_is_the_stark_prime():
+    """src/experiments/mod.rs:18-21 spells the modulus in decimal: it is StarkWare's published field prime
+    2^251 + 17 * 2^192 + 1 (two-adicity 192, generator 3 as in the Cairo field), which fixes S and the limb count."""
+    assert P.EXPERIMENTS.p == 2**251 + 17 * 2**192 + 1 == hodor_amd.EXPERIMENTS_FR_MODULUS
+    assert P.EXPERIMENTS.g == 3 == hodor_amd.EXPERIMENTS_FR_GENERATOR
+    t = (P.EXPERIMENTS.p - 1) >> 192
+    assert t == 2**59 + 17 and t % 2 == 1
 
 
 def test_reference_modulus_is_the_published_one():
