@@ -1,0 +1,74 @@
+"""An independent THIRD-PARTY implementation of the transform pins the oracle (and, on the GPU box, the library):
+sympy's `ntt` / `intt` (sympy.discrete.transforms) compute A[k] = sum_i a[i] w^(ik) mod p over canonical residues with
+w = g^((p - 1) / n), g the SMALLEST primitive root of p.  For both 4-limb fields of the reference that g is the field's
+`multiplicative_generator` (7 for src/bn256.rs, 3 for src/experiments/mod.rs — sympy finds it by factoring p - 1), and
+ff_ce's derive rule root_of_unity = g^t makes the domain generator of `Domain::new_for_size`
+(/root/reference/src/domains/mod.rs:21-44) exactly that w.  So `Polynomial::fft` / `ifft`
+(src/polynomials/mod.rs:611-624, :773-798) of canonical residues must equal sympy's output element for element —
+code written by neither this repository nor the reference.  (It is a pin of the mathematics and of the root
+convention, not a run of the Rust crate: DESIGN.md §4 keeps "parity unpinned" for that.)"""
+import numpy as np
+import pytest
+
+sympy = pytest.importorskip("sympy")
+from sympy.discrete.transforms import intt, ntt  # noqa: E402
+
+from oracle import pyref as P  # noqa: E402
+from oracle.oracle import array_to_ints, ints_to_array  # noqa: E402
+
+FIELDS = {"bn256": P.BN256, "experiments": P.EXPERIMENTS}
+
+
+def _canon(O, arr):
+    return [O.to_canonical(x) for x in array_to_ints(arr)]
+
+
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+def test_smallest_primitive_root_is_the_reference_generator(name):
+    F = FIELDS[name]
+    assert sympy.primitive_root(F.p) == F.g
+
+
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 10])
+def test_oracle_fft_and_ifft_equal_sympy(oracles, name, log_n):
+    O, F = oracles[name], FIELDS[name]
+    n = 1 << log_n
+    a = O.gen_elements(0, n, 0x53594D + log_n)
+    can = _canon(O, a)
+    want = [int(x) for x in ntt(can, F.p)]
+    b = a.copy()
+    O.poly_fft(b)                                  # the C restatement of Polynomial::fft (best_fft underneath)
+    assert _canon(O, b) == want
+    for variant in ("serial_fft", "serial_fft_radix_4"):
+        if variant == "serial_fft_radix_4" and log_n % 2:
+            continue
+        c = a.copy()
+        _, k, w = O.domain(n)
+        getattr(O, variant)(c, w, k)
+        assert _canon(O, c) == want, variant
+    assert P.poly_fft(F, can) == want             # the Python big-int twin
+    assert P.poly_ifft(F, want) == can
+    # inverse: Polynomial::ifft = omega^-1 and the n^-1 scale
+    back = a.copy()
+    O.poly_fft(back)
+    O.poly_ifft(back)
+    assert np.array_equal(back, a)
+    d = ints_to_array([O.from_canonical(v) for v in want])
+    O.poly_ifft(d)
+    assert _canon(O, d) == [int(x) for x in intt(want, F.p)] == can
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+@pytest.mark.parametrize("log_n", [4, 9, 11])
+def test_gpu_fft_equals_sympy(gpu_ctxs, oracles, name, log_n):
+    """The HIP path itself against the third-party transform (no oracle arithmetic in between: canonical residues are
+    converted with the library's own from_repr / into_repr)."""
+    ctx, O, F = gpu_ctxs[name], oracles[name], FIELDS[name]
+    n = 1 << log_n
+    can = _canon(O, O.gen_elements(0, n, 0x475055 + log_n))
+    a = np.array([[(ctx.from_repr(v) >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in can], dtype=np.uint64)
+    ctx.poly_fft(a)
+    got = [ctx.into_repr(sum(int(a[j][i]) << (64 * i) for i in range(4))) for j in range(n)]
+    assert got == [int(x) for x in ntt(can, F.p)]
