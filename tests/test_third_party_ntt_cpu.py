@@ -59,6 +59,25 @@ def test_oracle_fft_and_ifft_equal_sympy(oracles, name, log_n):
     assert _canon(O, d) == [int(x) for x in intt(want, F.p)] == can
 
 
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+@pytest.mark.parametrize("log_n,factor", [(3, 2), (5, 8), (7, 4)])
+def test_oracle_coset_fft_and_lde_equal_sympy(oracles, name, log_n, factor):
+    """coset_fft = fft of a[i] g^i (src/polynomials/mod.rs:626-631); lde / coset_lde = the transform of the zero-padded
+    (and coset-scaled) coefficients on the n * factor domain (:343-349, asserted by the reference's own tests
+    :1026-1031) — each against sympy's transform of the same list."""
+    O, F = oracles[name], FIELDS[name]
+    n = 1 << log_n
+    a = O.gen_elements(0, n, 0x434F53 + log_n)
+    can = _canon(O, a)
+    scaled = [v * pow(F.g, i, F.p) % F.p for i, v in enumerate(can)]
+    b = a.copy()
+    O.poly_coset_fft(b)
+    assert _canon(O, b) == [int(x) for x in ntt(scaled, F.p)]
+    pad = [0] * (n * factor - n)
+    assert _canon(O, O.poly_lde(a, factor)) == [int(x) for x in ntt(can + pad, F.p)]
+    assert _canon(O, O.poly_lde(a, factor, coset=True)) == [int(x) for x in ntt(scaled + pad, F.p)]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["bn256", "experiments"])
 @pytest.mark.parametrize("log_n", [4, 9, 11])
@@ -72,3 +91,17 @@ def test_gpu_fft_equals_sympy(gpu_ctxs, oracles, name, log_n):
     ctx.poly_fft(a)
     got = [ctx.into_repr(sum(int(a[j][i]) << (64 * i) for i in range(4))) for j in range(n)]
     assert got == [int(x) for x in ntt(can, F.p)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+def test_gpu_lde_equals_sympy(gpu_ctxs, oracles, name):
+    ctx, O, F = gpu_ctxs[name], oracles[name], FIELDS[name]
+    n, factor = 1 << 7, 8
+    can = _canon(O, O.gen_elements(0, n, 0x4C4445))
+    a = np.array([[(ctx.from_repr(v) >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in can], dtype=np.uint64)
+    for coset in (False, True):
+        out = ctx.poly_lde(a, factor, coset=coset)
+        got = [ctx.into_repr(sum(int(out[j][i]) << (64 * i) for i in range(4))) for j in range(n * factor)]
+        src = [v * pow(F.g, i, F.p) % F.p for i, v in enumerate(can)] if coset else can
+        assert got == [int(x) for x in ntt(src + [0] * (n * factor - n), F.p)], coset
