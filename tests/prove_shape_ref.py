@@ -115,6 +115,10 @@ def prove(ops, trace, prep, lde_factor, clock=None):
         out += [fr_bytes(value), u64(len(path))] + [bytes(x) for x in path]
     out += [u64(len(ops.fri_roots(p1)))] + ops.fri_roots(p1) + [u64(len(ops.fri_roots(p2)))] + ops.fri_roots(p2)
     out += [u64(x1), u64(len(proof1)), proof1, u64(x2), u64(len(proof2)), proof2]
+    # what a verifier needs besides the proof bytes: the two FRI proofs and the values the h oracles hold at the queried
+    # points (the verifier recomputes them from the f / g queries and the DEEP equations; here they come from the prover)
+    prove.last = {"fri": [(proof1, ops.size(h1), x1, ops.value_at(h1, x1)), (proof2, ops.size(h2), x2, ops.value_at(h2, x2))],
+                  "queries": [(f_roots[k], x1, f_queries[k]) for k in range(len(f_queries))] + [(g_root, x2, g_query)]}
     marks = {"f_roots": b"".join(f_roots).hex(), "g_root": g_root.hex(),
              "h1_fri": hashlib.blake2s(ops.fri_serialized(p1), digest_size=32).hexdigest(),
              "h2_fri": hashlib.blake2s(ops.fri_serialized(p2), digest_size=32).hexdigest(),
@@ -203,6 +207,10 @@ class OracleProver:
     def query(self, nodes, lde, index):
         from oracle.oracle import array_to_ints
         return array_to_ints(lde[index:index + 1])[0], self.O.iop_path(nodes, lde, index)
+
+    def value_at(self, a, index):
+        from oracle.oracle import array_to_ints
+        return array_to_ints(a[index:index + 1])[0]
 
     def release(self, *protos):
         pass
@@ -302,6 +310,10 @@ class DeviceProver:
     def query(self, nodes, lde, index):
         self.host_round_trips += 1
         return self.ctx.iop_query_dev(lde, nodes, lde.shape[0], index, stream=self.stream)
+
+    def value_at(self, a, index):
+        from oracle.oracle import array_to_ints     # (a verification aid after the run: not one of the prover's round trips)
+        return array_to_ints(a[index:index + 1].cpu().numpy().view(np.uint64))[0]
 
     def release(self, *protos):
         for p in protos:
