@@ -22,6 +22,7 @@ EXPERIMENTS_FR_MODULUS = 3618502788666131213697322783095070105623107215331596699
 EXPERIMENTS_FR_GENERATOR = 3
 
 OK, ERR_SIZE, ERR_INVALID, ERR_DEVICE = 0, 1, 2, 3
+TRIVIAL, COSET2 = 0, 1   # HODOR_COMBINER_*: the tree format (CosetCombiner, src/iop/mod.rs:22-34)
 
 # every symbol include/hodor_gpu.h declares
 EXPORTS = [
@@ -48,6 +49,10 @@ EXPORTS = [
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_proof_strict", "hodor_fri_verify_prototype",
+    "hodor_iop_create_combined", "hodor_hash_leaf_combined", "hodor_iop_path_combined", "hodor_iop_verify_combined",
+    "hodor_iop_create_combined_dev", "hodor_iop_query_combined_dev", "hodor_fri_commit_combined",
+    "hodor_fri_commit_combined_dev", "hodor_fri_combiner", "hodor_fri_verify_proof_combined",
+    "hodor_fri_verify_proof_strict_combined",
     "hodor_exchange_available", "hodor_exchange_unique_id", "hodor_exchange_create", "hodor_exchange_adopt",
     "hodor_exchange_destroy", "hodor_sixstep_exchange_dev", "hodor_sixstep_exchange_wait_dev",
 ]
@@ -151,6 +156,7 @@ class FriPrototype:
         ctx._protos.add(self)            # a prototype must not outlive its context (hodor_fri_free uses it)
         L = ctx.L
         self.num_steps = int(L.hodor_fri_num_steps(handle))
+        self.combiner = int(L.hodor_fri_combiner(handle))
         roots = np.zeros((self.num_steps + 1, 32), dtype=np.uint8)
         ctx._chk(L.hodor_fri_roots(handle, roots.ctypes.data_as(C.c_void_p)))
         self.roots = [bytes(r) for r in roots]
@@ -204,6 +210,9 @@ class FriPrototype:
             idx = u64()
             value = int.from_bytes(raw[o:o + 32], "little")
             o += 32
+            if self.combiner == COSET2:      # both values of the coset in one query
+                value = (value, int.from_bytes(raw[o:o + 32], "little"))
+                o += 32
             plen = u64()
             path = [raw[o + 32 * k:o + 32 * (k + 1)] for k in range(plen)]
             o += 32 * plen
@@ -497,11 +506,44 @@ class Context:
                                           C.c_size_t(len(path)), C.c_size_t(tree_index), C.byref(ok)))
         return bool(ok.value)
 
-    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one):
+    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, combiner=TRIVIAL):
         h = C.c_void_p()
-        self._chk(self.L.hodor_fri_commit(self.h, _hptr(lde_values), C.c_size_t(len(lde_values)),
-                                          C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.byref(h)))
+        self._chk(self.L.hodor_fri_commit_combined(self.h, _hptr(lde_values), C.c_size_t(len(lde_values)),
+                                                   C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one),
+                                                   C.c_int(combiner), C.byref(h)))
         return FriPrototype(self, h)
+
+    # ---- the tree format as a parameter (HODOR_COMBINER_COSET2: leaf k = value[k] || value[k + n/2])
+    def iop_create_combined(self, leafs, combiner):
+        n = len(leafs)
+        nodes = np.zeros((n // 2 if combiner == COSET2 else n, 32), dtype=np.uint8)
+        self._chk(self.L.hodor_iop_create_combined(self.h, _hptr(leafs), C.c_size_t(n), C.c_int(combiner),
+                                                   nodes.ctypes.data_as(C.c_void_p)))
+        return nodes
+
+    def hash_leaf_combined(self, values_mont, combiner):
+        out = (C.c_uint8 * 32)()
+        arr = (_Fr * len(values_mont))(*[_fr(v) for v in values_mont])
+        self._chk(self.L.hodor_hash_leaf_combined(self.h, arr, C.c_int(combiner), out))
+        return bytes(out)
+
+    def iop_path_combined(self, nodes, leafs, combiner, natural_index):
+        n = len(leafs)
+        path = np.zeros((max(1, n.bit_length() - 1), 32), dtype=np.uint8)
+        cnt = C.c_size_t()
+        self._chk(self.L.hodor_iop_path_combined(self.h, nodes.ctypes.data_as(C.c_void_p), _hptr(leafs), C.c_size_t(n),
+                                                 C.c_int(combiner), C.c_size_t(natural_index),
+                                                 path.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return path[:cnt.value]
+
+    def iop_verify_combined(self, root, values_mont, path, natural_index, n, combiner):
+        ok = C.c_int()
+        arr = (_Fr * len(values_mont))(*[_fr(v) for v in values_mont])
+        path = np.ascontiguousarray(path)
+        self._chk(self.L.hodor_iop_verify_combined(self.h, bytes(root), arr, path.ctypes.data_as(C.c_void_p),
+                                                   C.c_size_t(len(path)), C.c_size_t(natural_index), C.c_size_t(n),
+                                                   C.c_int(combiner), C.byref(ok)))
+        return bool(ok.value)
 
     # ---- device API (tensors / raw device pointers)
     def fft_dev(self, src, dst, log_n, omega, stream=None):
@@ -584,13 +626,23 @@ class Context:
                                                 C.byref(ev), C.byref(ok)))
         return bool(ok.value)
 
-    def fri_verify_proof_strict(self, raw, domain_size, natural_index, expected_value):
-        """hodor_fri_verify_proof_strict: the verifier above, refusing (False) every proof whose round / query /
+    def fri_verify_proof_strict(self, raw, domain_size, lde_factor, out_deg_plus_one, natural_index, expected_value,
+                                combiner=TRIVIAL):
+        """hodor_fri_verify_proof_strict(_combined): the verifier above, refusing (False) every proof whose
+        lde_factor / output_coeffs_at_degree_plus_one are not the ones the CALLER expects, or whose round / query /
         final-coefficient counts or path lengths are not those of a proof over `domain_size` points."""
         buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
         ev, ok = _fr(expected_value), C.c_int(0)
-        self._chk(self.L.hodor_fri_verify_proof_strict(self.h, buf, C.c_size_t(len(raw)), C.c_size_t(domain_size),
-                                                       C.c_size_t(natural_index), C.byref(ev), C.byref(ok)))
+        self._chk(self.L.hodor_fri_verify_proof_strict_combined(
+            self.h, buf, C.c_size_t(len(raw)), C.c_int(combiner), C.c_size_t(domain_size), C.c_size_t(lde_factor),
+            C.c_size_t(out_deg_plus_one), C.c_size_t(natural_index), C.byref(ev), C.byref(ok)))
+        return bool(ok.value)
+
+    def fri_verify_proof_combined(self, raw, combiner, natural_index, expected_value):
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        ev, ok = _fr(expected_value), C.c_int(0)
+        self._chk(self.L.hodor_fri_verify_proof_combined(self.h, buf, C.c_size_t(len(raw)), C.c_int(combiner),
+                                                         C.c_size_t(natural_index), C.byref(ev), C.byref(ok)))
         return bool(ok.value)
 
     def poly_binary_dev(self, a, b, n, op, stream=None):
@@ -672,8 +724,22 @@ class Context:
                                              path.ctypes.data_as(C.c_void_p), C.byref(cnt)))
         return _to_int(value.l), path[:cnt.value]
 
-    def fri_commit_dev(self, lde_values, n, lde_factor, out_deg_plus_one, stream=None):
+    def fri_commit_dev(self, lde_values, n, lde_factor, out_deg_plus_one, stream=None, combiner=TRIVIAL):
         h = C.c_void_p()
-        self._chk(self.L.hodor_fri_commit_dev(self.h, C.c_void_p(stream), _dptr(lde_values), C.c_size_t(n),
-                                              C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.byref(h)))
+        self._chk(self.L.hodor_fri_commit_combined_dev(self.h, C.c_void_p(stream), _dptr(lde_values), C.c_size_t(n),
+                                                       C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one),
+                                                       C.c_int(combiner), C.byref(h)))
         return FriPrototype(self, h)
+
+    def iop_create_combined_dev(self, leafs, n, combiner, nodes, stream=None):
+        self._chk(self.L.hodor_iop_create_combined_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n),
+                                                       C.c_int(combiner), _dptr(nodes)))
+
+    def iop_query_combined_dev(self, leafs, nodes, n, combiner, natural_index, stream=None):
+        """-> ([values], path): both values of the coset for COSET2, the queried one for TRIVIAL."""
+        values, cnt = (_Fr * 2)(), C.c_size_t()
+        path = np.zeros((max(1, n.bit_length() - 1), 32), dtype=np.uint8)
+        self._chk(self.L.hodor_iop_query_combined_dev(self.h, C.c_void_p(stream), _dptr(leafs), _dptr(nodes),
+                                                      C.c_size_t(n), C.c_int(combiner), C.c_size_t(natural_index), values,
+                                                      path.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return [_to_int(values[i].l) for i in range(2 if combiner == COSET2 else 1)], path[:cnt.value]

@@ -913,6 +913,20 @@ extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const h
     return HODOR_OK;
 }
 
+// IopTree::create with the tree format chosen by `combiner` (HODOR_COMBINER_*): COSET2 hashes the coset
+// {k, k + n/2} as ONE 64-byte leaf and writes the (n/2)-entry heap array of the tree over those n/2 leaves.
+extern "C" int hodor_iop_create_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, int combiner,
+                                             uint8_t *nodes)
+{
+    if (combiner == HODOR_COMBINER_TRIVIAL) return hodor_iop_create_dev(ctx, stream, leafs, n, nodes);
+    NEED_DEVICE();
+    if (combiner != HODOR_COMBINER_COSET2 || !leafs || !nodes) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 4) { set_err(ctx, "iop_create (COSET2): n must be a power of two >= 4"); return HODOR_ERR_SIZE; }
+    HIPCHK(merkle_build_launch(pick_stream(ctx, stream), (const uint4 *)leafs, (uint4 *)nodes, n, ctx->mid, 1, nullptr,
+                               nullptr, true));
+    return HODOR_OK;
+}
+
 extern "C" int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n,
                                     uint8_t *nodes)
 {
@@ -1045,6 +1059,18 @@ extern "C" int hodor_poly_lde(hodor_ctx *ctx, const hodor_fr *c, size_t n, size_
 { return poly_lde_slice(ctx, c, n, f, out, 0); }
 extern "C" int hodor_poly_coset_lde(hodor_ctx *ctx, const hodor_fr *c, size_t n, size_t f, hodor_fr *out)
 { return poly_lde_slice(ctx, c, n, f, out, 1); }
+
+extern "C" int hodor_iop_create_combined(hodor_ctx *ctx, const hodor_fr *leafs, size_t n, int combiner, uint8_t *nodes)
+{
+    if (combiner == HODOR_COMBINER_TRIVIAL) return hodor_iop_create(ctx, leafs, n, nodes);
+    NEED_DEVICE();
+    if (combiner != HODOR_COMBINER_COSET2 || !leafs || !nodes) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 4) { set_err(ctx, "iop_create (COSET2): n must be a power of two >= 4"); return HODOR_ERR_SIZE; }
+    return with_device_copy(ctx, leafs, n, nodes, n / 2, [&](const uint4 *s, uint4 *d) -> int {
+        HIPCHK(merkle_build_launch(ctx->stream, s, d, n, ctx->mid, 1, nullptr, nullptr, true));
+        return HODOR_OK;
+    }, true);
+}
 
 extern "C" int hodor_iop_create(hodor_ctx *ctx, const hodor_fr *leafs, size_t n, uint8_t *nodes)
 {

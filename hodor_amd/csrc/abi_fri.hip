@@ -29,8 +29,16 @@ extern "C" void hodor_fri_free(hodor_fri_proto *p)
 extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
                                     size_t lde_factor, size_t out_deg, hodor_fri_proto **out)
 {
+    return hodor_fri_commit_combined_dev(ctx, stream_, lde_values, n, lde_factor, out_deg, HODOR_COMBINER_TRIVIAL, out);
+}
+
+extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
+                                             size_t lde_factor, size_t out_deg, int combiner, hodor_fri_proto **out)
+{
     NEED_DEVICE();
     if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (combiner != HODOR_COMBINER_TRIVIAL && combiner != HODOR_COMBINER_COSET2) return HODOR_ERR_INVALID;
+    const bool comb = combiner == HODOR_COMBINER_COSET2;
     if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;
     size_t initial_degree_plus_one = n / lde_factor;
     if (initial_degree_plus_one < 2 * out_deg) {   // num_steps == 0: the reference panics at roots.pop() (:124)
@@ -38,7 +46,11 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
         return HODOR_ERR_SIZE;
     }
     size_t num_steps = log2u(initial_degree_plus_one / out_deg);
-    if ((n >> num_steps) < 2) return HODOR_ERR_SIZE;
+    if ((n >> num_steps) < (comb ? 4u : 2u)) {   // the smallest committed vector: a tree needs two leaves
+        set_err(ctx, comb ? "fri_commit: COSET2 needs lde_factor * out_deg >= 4 (two combined leaves in the last tree)"
+                          : "fri_commit: the last tree needs two leaves");
+        return HODOR_ERR_SIZE;
+    }
     uint32_t log_n = log2u(n);
     HFr omega, omega_inv;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -55,6 +67,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     p->lde_factor = lde_factor;
     p->out_deg = out_deg;
     p->initial_degree_plus_one = initial_degree_plus_one;
+    p->combiner = combiner;
 
 #define FRICHK(expr)                                                                   \
     do {                                                                               \
@@ -109,7 +122,8 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     uint32_t shave = 256 - ctx->F.capacity;
     Fr r2 = to_dev(ctx->F.r2);
 
-    FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid));   // :17
+    FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid, 1, nullptr,
+                               nullptr, comb));                                                         // :17
 
     const uint4 *values = (const uint4 *)lde_values;
     size_t next_size = n / 2;
@@ -135,7 +149,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
             T.first_round = (uint32_t)i;
             T.half0 = (uint32_t)next_size;
             T.shave = shave;
-            FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P));
+            FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P, comb));
             values = (const uint4 *)p->inter_values[num_steps - 1];
             tail_done = true;
             break;
@@ -147,7 +161,7 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
         const bool fused = merkle_fuses_fold(next_size);   // small rounds: fold inside the tree's leaf launch
         if (!fused) FRICHK(fri_fold_launch(stream, fold, ctx->Q));                                        // :70-104
         FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid, 1,
-                                   fused ? &fold : nullptr, &ctx->Q));                                   // :106
+                                   fused ? &fold : nullptr, &ctx->Q, comb));                             // :106
         prev_nodes = (const uint4 *)nodes;
         values = (const uint4 *)next;
         next_size >>= 1;
@@ -176,6 +190,12 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
 extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
                                 size_t out_deg, hodor_fri_proto **out)
 {
+    return hodor_fri_commit_combined(ctx, lde_values, n, lde_factor, out_deg, HODOR_COMBINER_TRIVIAL, out);
+}
+
+extern "C" int hodor_fri_commit_combined(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                                         size_t out_deg, int combiner, hodor_fri_proto **out)
+{
     NEED_DEVICE();
     if (!lde_values || !out) return HODOR_ERR_INVALID;
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
@@ -185,7 +205,8 @@ extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size
     // the context's own compute stream, like every other slice entry point: in-order with the other
     // callers' transforms that share ctx->scratch (hodor_fri_commit_dev holds ctx->mu until it has
     // synchronised), never the legacy NULL stream, which has no ordering with a non-blocking stream
-    return hodor_fri_commit_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor, out_deg, out);
+    return hodor_fri_commit_combined_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor, out_deg,
+                                         combiner, out);
 }
 
 // IOP::query on device-resident leaves and tree (src/iop/blake2s_trivial_iop.rs:324-338)
@@ -211,6 +232,33 @@ extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr
     return HODOR_OK;
 }
 
+// IOP::query on a tree built by `combiner`: COSET2 returns both values of the coset {k, k + n/2}, k = index mod n/2
+// (values[0] at k, values[1] at k + n/2) and the path of the combined leaf (log2(n) - 1 digests); TRIVIAL returns
+// values[0] only and the reference's path.
+extern "C" int hodor_iop_query_combined_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *leafs, const uint8_t *nodes,
+                                            size_t n, int combiner, size_t natural_index, hodor_fr *values,
+                                            uint8_t *path, size_t *path_len)
+{
+    if (combiner == HODOR_COMBINER_TRIVIAL)
+        return hodor_iop_query_dev(ctx, stream_, leafs, nodes, n, natural_index, values, path, path_len);
+    NEED_DEVICE();
+    if (combiner != HODOR_COMBINER_COSET2 || !leafs || !nodes || !values || !path || !path_len) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 4 || natural_index >= n) return HODOR_ERR_SIZE;
+    hipStream_t stream = pick_stream(ctx, stream_);
+    size_t entries = log2u(n) + 1;                 // 2 values + (log2(n) - 1) digests
+    DevBuf stage;
+    HIPCHK(hipMalloc(&stage.p, entries * 32));
+    HIPCHK(iop_query_coset2_launch(stream, (const uint4 *)leafs, (const uint4 *)nodes, n, natural_index,
+                                   (uint4 *)stage.p, ctx->mid));
+    std::vector<uint8_t> host(entries * 32);
+    HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    memcpy(values, host.data(), 64);
+    memcpy(path, host.data() + 64, (entries - 2) * 32);
+    *path_len = entries - 2;
+    return HODOR_OK;
+}
+
 // FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53): for the l0 oracle and every
 // intermediate oracle, the two queries of the coset {idx, idx + size/2} (sorted), idx halving as the
 // domain does (Domain::index_and_size_for_next_domain).  Serialised FRIProof (src/fri/mod.rs:139-147):
@@ -224,11 +272,18 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     hodor_ctx *ctx = p->ctx;
     if (!ctx || ctx->device < 0 || natural_first_element_index >= p->n) return 0;
     const size_t rounds = p->num_steps + 1;
+    const bool comb = p->combiner == HODOR_COMBINER_COSET2;
     size_t need = 8, stage_bytes = 0;
     for (size_t r = 0, sz = p->n; r < rounds; r++, sz >>= 1) {
-        size_t entries = log2u(sz) + 1;
-        need += 2 * (8 + 32 + 8 + (entries - 1) * 32);
-        stage_bytes += 2 * entries * 32;
+        if (comb) {   // ONE query per round: index, both values of the coset, a path of log2(sz) - 1 digests
+            size_t plen = log2u(sz) - 1;
+            need += 8 + 64 + 8 + plen * 32;
+            stage_bytes += (2 + plen) * 32;
+        } else {
+            size_t entries = log2u(sz) + 1;
+            need += 2 * (8 + 32 + 8 + (entries - 1) * 32);
+            stage_bytes += 2 * entries * 32;
+        }
     }
     need += 8 + rounds * 32 + 8 + p->out_deg * 32 + 24;
     if (!buf || cap < need) return need;
@@ -244,7 +299,15 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
         size_t pair = (domain_idx + domain_size / 2) % domain_size;
         size_t coset[2] = {domain_idx < pair ? domain_idx : pair, domain_idx < pair ? pair : domain_idx};
         size_t entries = log2u(domain_size) + 1;
-        for (int k = 0; k < 2; k++) {
+        if (comb) {
+            if (iop_query_coset2_launch(ctx->stream, (const uint4 *)leafs, nodes, domain_size, coset[0],
+                                        (uint4 *)((uint8_t *)stage.p + off), ctx->mid) != hipSuccess)
+                return 0;
+            q_index.push_back(coset[0]);
+            q_entries.push_back(entries);            // 2 values + (log2 - 1) digests = log2 + 1 entries
+            off += entries * 32;
+        }
+        for (int k = 0; k < 2 && !comb; k++) {
             if (iop_query_launch(ctx->stream, (const uint4 *)(leafs + (coset[k] & ~(size_t)1)), nodes, domain_size,
                                  coset[k], (uint4 *)((uint8_t *)stage.p + off), ctx->mid) != hipSuccess)
                 return 0;
@@ -263,11 +326,12 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     size_t o = 0, h = 0;
     auto put64 = [&](uint64_t v) { memcpy(buf + o, &v, 8); o += 8; };
     put64(q_index.size());
+    const size_t vals = comb ? 2 : 1;   // values carried by one query
     for (size_t q = 0; q < q_index.size(); q++) {
         put64(q_index[q]);
-        memcpy(buf + o, host.data() + h, 32); o += 32;
-        put64(q_entries[q] - 1);
-        memcpy(buf + o, host.data() + h + 32, (q_entries[q] - 1) * 32); o += (q_entries[q] - 1) * 32;
+        memcpy(buf + o, host.data() + h, 32 * vals); o += 32 * vals;
+        put64(q_entries[q] - vals);
+        memcpy(buf + o, host.data() + h + 32 * vals, (q_entries[q] - vals) * 32); o += (q_entries[q] - vals) * 32;
         h += q_entries[q] * 32;
     }
     put64(rounds);
@@ -289,8 +353,24 @@ extern "C" int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof
                                       size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
                                       int *valid)
 {
+    return hodor_fri_verify_proof_combined(ctx, proof, len, HODOR_COMBINER_TRIVIAL, natural_element_index,
+                                           expected_value_from_oracle, valid);
+}
+
+// COSET2 proofs (one query per round carrying both values of the coset): the same walk as below with the pair
+// checked against the round's root by ONE path — see verify_coset2_walk.
+static int verify_coset2_walk(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t natural_element_index,
+                              const hodor_fr *expected_value_from_oracle, int *valid);
+
+extern "C" int hodor_fri_verify_proof_combined(const hodor_ctx *ctx, const uint8_t *proof, size_t len, int combiner,
+                                               size_t natural_element_index,
+                                               const hodor_fr *expected_value_from_oracle, int *valid)
+{
     if (!ctx || !proof || !expected_value_from_oracle || !valid) return HODOR_ERR_INVALID;
     *valid = 0;
+    if (combiner == HODOR_COMBINER_COSET2)
+        return verify_coset2_walk(ctx, proof, len, natural_element_index, expected_value_from_oracle, valid);
+    if (combiner != HODOR_COMBINER_TRIVIAL) return HODOR_ERR_INVALID;
     size_t o = 0;
     bool bad = false;
     auto get64 = [&]() -> uint64_t {
@@ -398,24 +478,141 @@ extern "C" int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof
     return HODOR_OK;
 }
 
-// hodor_fri_verify_proof with the shape of the proof bound to the claimed domain FIRST.  The reference's
+// hodor_fri_verify_proof with the proof bound to the parameters the CALLER chose FIRST.  The reference's
 // verify_proof_queries (src/fri/verifier.rs:131-289) walks zip(roots, queries.chunks_exact(2)) and therefore
-// accepts a proof whose tail of rounds has been cut off, or whose final polynomial has any length; this
-// variant refuses (HODOR_OK with *valid = 0) every buffer whose counts differ from what
-// FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53) writes for the parameters the proof
-// itself carries AND the caller expects:
-//     lde_factor, initial_degree_plus_one, out_deg powers of two, out_deg <= initial_degree_plus_one,
-//     initial_degree_plus_one * lde_factor == expected_domain_size,
+// accepts a proof whose tail of rounds has been cut off, or whose final polynomial has any length, and it takes
+// lde_factor / initial_degree_plus_one / output_coeffs_at_degree_plus_one from the proof itself — a prover that
+// re-encodes lde_factor = 1 (rate 1: every function on the domain is "low degree") passes it.  This variant
+// refuses (HODOR_OK with *valid = 0) every buffer whose fields differ from what
+// FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53) writes for the caller's parameters:
+//     lde_factor == expected_lde_factor, output_coeffs_at_degree_plus_one == expected_out_deg,
+//     initial_degree_plus_one == expected_domain_size / expected_lde_factor,
 //     n_roots == log2(initial_degree_plus_one / out_deg) + 1, n_queries == 2 * n_roots, n_final == out_deg,
 //     path_len of round k == log2(expected_domain_size >> k), both queries of a round.
 // A well-formed proof is then handed to hodor_fri_verify_proof unchanged.
 extern "C" int hodor_fri_verify_proof_strict(const hodor_ctx *ctx, const uint8_t *proof, size_t len,
-                                             size_t expected_domain_size, size_t natural_element_index,
+                                             size_t expected_domain_size, size_t expected_lde_factor,
+                                             size_t expected_out_deg, size_t natural_element_index,
                                              const hodor_fr *expected_value_from_oracle, int *valid)
+{
+    return hodor_fri_verify_proof_strict_combined(ctx, proof, len, HODOR_COMBINER_TRIVIAL, expected_domain_size,
+                                                  expected_lde_factor, expected_out_deg, natural_element_index,
+                                                  expected_value_from_oracle, valid);
+}
+
+static int verify_coset2_walk(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t natural_element_index,
+                              const hodor_fr *expected_value_from_oracle, int *valid)
+{
+    size_t o = 0;
+    bool bad = false;
+    auto get64 = [&]() -> uint64_t {
+        uint64_t v = 0;
+        if (o > len || len - o < 8) { bad = true; return 0; }
+        memcpy(&v, proof + o, 8);
+        o += 8;
+        return v;
+    };
+    auto take = [&](uint64_t count) -> const uint8_t * {   // count 32-byte entries
+        if (bad || count > (len - o) / 32) { bad = true; return nullptr; }
+        const uint8_t *r = proof + o;
+        o += (size_t)count * 32;
+        return r;
+    };
+    struct Query { uint64_t index; const uint8_t *values; uint64_t path_len; const uint8_t *path; };
+    uint64_t nq = get64();
+    if (bad || nq > len / 80) return HODOR_ERR_INVALID;
+    std::vector<Query> queries((size_t)nq);
+    for (auto &q : queries) {
+        q.index = get64();
+        q.values = take(2);
+        q.path_len = get64();
+        q.path = take(q.path_len);
+        if (bad) return HODOR_ERR_INVALID;
+    }
+    uint64_t n_roots = get64();
+    const uint8_t *roots = take(n_roots);
+    uint64_t n_final = get64();
+    const uint8_t *final_coeffs = take(n_final);
+    uint64_t initial_degree_plus_one = get64();
+    (void)get64();
+    uint64_t lde_factor = get64();
+    if (bad || o != len) return HODOR_ERR_INVALID;
+
+    const HostField &F = ctx->F;
+    HFr two_inv, omega, omega_inv;
+    if (!F.inverse(F.add(F.one, F.one), &two_inv)) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_size;
+    if (lde_factor && initial_degree_plus_one > ~0ull / lde_factor) return HODOR_ERR_SIZE;
+    if (!F.domain(initial_degree_plus_one * lde_factor, &size, &log_size, &omega)) return HODOR_ERR_SIZE;
+    HFr x = F.pow(omega, natural_element_index);
+    if (!(F.pow(x, size) == F.one) || F.pow(x, size / 2) == F.one) return HODOR_ERR_INVALID;
+    if (!F.inverse(omega, &omega_inv)) return HODOR_ERR_INVALID;
+
+    auto value_of = [&](const uint8_t *b) { hodor_fr v; memcpy(v.l, b, 32); return to_h(&v); };
+    bool have_expected = false;
+    HFr expected = F.one;
+    uint64_t domain_size = size, domain_idx = natural_element_index;
+    const HFr oracle_value = to_h(expected_value_from_oracle);
+    const size_t rounds = std::min<size_t>((size_t)n_roots, queries.size());   // zip(roots, queries)
+    for (size_t rnd = 0; rnd < rounds; rnd++) {
+        if (domain_size < 4) return HODOR_ERR_INVALID;        // no combined tree over fewer than two leaves
+        const Query &q = queries[rnd];
+        const uint8_t *root = roots + 32 * rnd;
+        uint64_t pair = (domain_idx + domain_size / 2) % domain_size;
+        uint64_t coset[2] = {std::min(domain_idx, pair), std::max(domain_idx, pair)};
+        if (q.index != coset[0] && q.index != coset[1]) return HODOR_OK;                      // Ok(false)
+        if (q.index != coset[0]) return HODOR_ERR_INVALID;                                    // "invalid tree index"
+        const HFr f_at_omega = value_of(q.values), f_at_minus_omega = value_of(q.values + 32);
+        const HFr &supplied = domain_idx == coset[0] ? f_at_omega : f_at_minus_omega;
+        if (rnd == 0 && !(supplied == oracle_value)) return HODOR_OK;
+        int ok = 0;
+        hodor_fr pair_values[2];
+        memcpy(pair_values, q.values, 64);
+        if (hodor_iop_verify_combined(ctx, root, pair_values, q.path, (size_t)q.path_len, (size_t)coset[0],
+                                      (size_t)domain_size, HODOR_COMBINER_COSET2, &ok))
+            return HODOR_ERR_INVALID;
+        if (!ok) return HODOR_OK;
+        hodor_fr ch;
+        if (hodor_iop_challenge(ctx, root, &ch)) return HODOR_ERR_INVALID;
+        if (have_expected && !(supplied == expected)) return HODOR_OK;
+        HFr divisor = F.pow(omega_inv, coset[0]);
+        HFr even = F.add(f_at_omega, f_at_minus_omega);
+        HFr odd = F.mul(F.sub(f_at_omega, f_at_minus_omega), divisor);
+        expected = F.mul(F.add(F.mul(odd, to_h(&ch)), even), two_inv);
+        have_expected = true;
+        uint64_t next = domain_size / 2;
+        domain_idx = domain_idx < next ? domain_idx : domain_idx - next;
+        domain_size = next;
+        omega = F.sqr(omega);
+        omega_inv = F.sqr(omega_inv);
+    }
+    if (!have_expected) return HODOR_ERR_INVALID;
+    HFr point = F.pow(omega, domain_idx), acc = F.sub(F.one, F.one), power = F.one;
+    for (uint64_t i = 0; i < n_final; i++) {
+        hodor_fr c;
+        memcpy(c.l, final_coeffs + 32 * i, 32);
+        acc = F.add(acc, F.mul(power, to_h(&c)));
+        power = F.mul(power, point);
+    }
+    *valid = (acc == expected) ? 1 : 0;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_fri_verify_proof_strict_combined(const hodor_ctx *ctx, const uint8_t *proof, size_t len,
+                                                      int combiner, size_t expected_domain_size,
+                                                      size_t expected_lde_factor, size_t expected_out_deg,
+                                                      size_t natural_element_index,
+                                                      const hodor_fr *expected_value_from_oracle, int *valid)
 {
     if (!ctx || !proof || !expected_value_from_oracle || !valid) return HODOR_ERR_INVALID;
     *valid = 0;
+    if (combiner != HODOR_COMBINER_TRIVIAL && combiner != HODOR_COMBINER_COSET2) return HODOR_ERR_INVALID;
+    const bool comb = combiner == HODOR_COMBINER_COSET2;
     if (!is_pow2(expected_domain_size) || natural_element_index >= expected_domain_size) return HODOR_ERR_SIZE;
+    if (!is_pow2(expected_lde_factor) || !is_pow2(expected_out_deg) || expected_lde_factor > expected_domain_size ||
+        expected_out_deg > expected_domain_size / expected_lde_factor)
+        return HODOR_ERR_SIZE;
     size_t o = 0;
     auto get64 = [&](uint64_t *v) -> bool {
         if (o > len || len - o < 8) return false;
@@ -433,21 +630,27 @@ extern "C" int hodor_fri_verify_proof_strict(const hodor_ctx *ctx, const uint8_t
     std::vector<uint64_t> path_lens((size_t)nq);
     for (auto &pl : path_lens) {
         uint64_t index;
-        if (!get64(&index) || !skip(1) || !get64(&pl) || !skip(pl)) return HODOR_ERR_INVALID;
+        if (!get64(&index) || !skip(comb ? 2 : 1) || !get64(&pl) || !skip(pl)) return HODOR_ERR_INVALID;
     }
     uint64_t n_roots = 0, n_final = 0, deg = 0, out_deg = 0, factor = 0;
     if (!get64(&n_roots) || !skip(n_roots) || !get64(&n_final) || !skip(n_final) || !get64(&deg) ||
         !get64(&out_deg) || !get64(&factor) || o != len)
         return HODOR_ERR_INVALID;
-    if (!is_pow2((size_t)deg) || !is_pow2((size_t)out_deg) || !is_pow2((size_t)factor) || out_deg > deg) return HODOR_OK;
-    if (factor > expected_domain_size || deg != expected_domain_size / factor) return HODOR_OK;
+    // the low-degree claim is the CALLER's: rate and degree bound as the verifier chose them, not as the proof says
+    if (factor != expected_lde_factor || out_deg != expected_out_deg ||
+        deg != expected_domain_size / expected_lde_factor)
+        return HODOR_OK;
     const uint64_t rounds = log2u((size_t)deg) - log2u((size_t)out_deg) + 1;
-    if (n_roots != rounds || nq != 2 * rounds || n_final != out_deg) return HODOR_OK;
+    const uint64_t per_round = comb ? 1 : 2;
+    if (n_roots != rounds || nq != per_round * rounds || n_final != out_deg) return HODOR_OK;
+    if (comb && (expected_domain_size >> (rounds - 1)) < 4) return HODOR_OK;
     for (uint64_t r = 0; r < rounds; r++) {
-        const uint64_t want = log2u(expected_domain_size >> r);
-        if (path_lens[2 * r] != want || path_lens[2 * r + 1] != want) return HODOR_OK;
+        const uint64_t want = log2u(expected_domain_size >> r) - (comb ? 1 : 0);
+        for (uint64_t k = 0; k < per_round; k++)
+            if (path_lens[per_round * r + k] != want) return HODOR_OK;
     }
-    return hodor_fri_verify_proof(ctx, proof, len, natural_element_index, expected_value_from_oracle, valid);
+    return hodor_fri_verify_proof_combined(ctx, proof, len, combiner, natural_element_index,
+                                           expected_value_from_oracle, valid);
 }
 
 // NaiveFriIop::verify_prototype (src/fri/verifier.rs:10-129): the same folding walk against the
@@ -521,6 +724,7 @@ extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *ld
 }
 
 extern "C" size_t hodor_fri_num_steps(const hodor_fri_proto *p) { return p ? p->num_steps : 0; }
+extern "C" int hodor_fri_combiner(const hodor_fri_proto *p) { return p ? p->combiner : -1; }
 
 extern "C" int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots)
 {
@@ -559,8 +763,9 @@ extern "C" int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes
     if (!p || !nodes || step < -1 || step >= (int)p->num_steps) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = p->ctx;
     NEED_DEVICE();
-    if (step < 0) HIPCHK(hipMemcpy(nodes, p->l0_nodes, p->n * 32, hipMemcpyDeviceToHost));
-    else HIPCHK(hipMemcpy(nodes, p->inter_nodes[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
+    const size_t shift = p->combiner == HODOR_COMBINER_COSET2 ? 1 : 0;   // a COSET2 tree has half as many entries
+    if (step < 0) HIPCHK(hipMemcpy(nodes, p->l0_nodes, (p->n >> shift) * 32, hipMemcpyDeviceToHost));
+    else HIPCHK(hipMemcpy(nodes, p->inter_nodes[step], (p->inter_sizes[step] >> shift) * 32, hipMemcpyDeviceToHost));
     return HODOR_OK;
 }
 

@@ -141,6 +141,65 @@ extern "C" int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], co
     return HODOR_OK;
 }
 
+// ---- the same three for a tree built by `combiner` (COSET2: leaf k = value[k] || value[k + n/2], see the header) ----
+static void host_hash_pair(const hodor_ctx *ctx, const hodor_fr *lo, const hodor_fr *hi, uint8_t out[32])
+{
+    uint8_t buf[64];
+    memcpy(buf, lo->l, 32);          // encode_leaf: the raw Montgomery limbs, little-endian (host is LE)
+    memcpy(buf + 32, hi->l, 32);
+    HostBlake2s::finish(ctx->mid.h, buf, 64, out);
+}
+
+extern "C" int hodor_hash_leaf_combined(const hodor_ctx *ctx, const hodor_fr *values, int combiner, uint8_t out[32])
+{
+    if (!ctx || !values || !out) return HODOR_ERR_INVALID;
+    if (combiner == HODOR_COMBINER_TRIVIAL) host_hash_leaf(ctx, values, out);
+    else if (combiner == HODOR_COMBINER_COSET2) host_hash_pair(ctx, values, values + 1, out);
+    else return HODOR_ERR_INVALID;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_path_combined(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
+                                       int combiner, size_t natural_index, uint8_t *path, size_t *path_len)
+{
+    if (combiner == HODOR_COMBINER_TRIVIAL) return hodor_iop_path(ctx, nodes, leafs, n, natural_index, path, path_len);
+    if (combiner != HODOR_COMBINER_COSET2 || !ctx || !nodes || !leafs || !path || !path_len) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 4 || natural_index >= n) return HODOR_ERR_SIZE;
+    const size_t leaves = n / 2, k = natural_index % leaves;
+    size_t cnt = 0;
+    host_hash_pair(ctx, &leafs[k ^ 1], &leafs[(k ^ 1) + leaves], path);
+    cnt++;
+    size_t idx = k >> 1;
+    for (size_t w = leaves / 2; w >= 2; w /= 2) {
+        memcpy(path + 32 * cnt, nodes + 32 * (w + (idx ^ 1)), 32);
+        cnt++;
+        idx >>= 1;
+    }
+    *path_len = cnt;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_iop_verify_combined(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *values,
+                                         const uint8_t *path, size_t path_len, size_t natural_index, size_t n,
+                                         int combiner, int *ok)
+{
+    if (combiner == HODOR_COMBINER_TRIVIAL) return hodor_iop_verify(ctx, root, values, path, path_len, natural_index, ok);
+    if (combiner != HODOR_COMBINER_COSET2 || !ctx || !root || !values || (!path && path_len) || !ok)
+        return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 4 || natural_index >= n) return HODOR_ERR_SIZE;
+    uint8_t h[32], t[32];
+    host_hash_pair(ctx, values, values + 1, h);
+    size_t idx = natural_index % (n / 2);
+    for (size_t i = 0; i < path_len; i++) {
+        if ((idx & 1) == 0) host_hash_node(ctx, h, path + 32 * i, t);
+        else host_hash_node(ctx, path + 32 * i, h, t);
+        memcpy(h, t, 32);
+        idx >>= 1;
+    }
+    *ok = memcmp(h, root, 32) == 0;
+    return HODOR_OK;
+}
+
 // ---- Blake2sTranscript (src/transcript/mod.rs:10-80): host-side, sequential, O(#roots) ----
 struct hodor_transcript {
     const hodor_ctx *ctx;
@@ -233,6 +292,7 @@ static Knobs read_knobs()
     k.ntt_threads = get("HODOR_NTT_THREADS", 0, 0, 1024);
     k.ntt_tw_sub = get("HODOR_NTT_TW_SUB", 1, 0, 1);
     k.ntt_w9 = get("HODOR_NTT_W9", 2, 0, 2);
+    k.ntt_p1 = get("HODOR_NTT_P1", 1, 0, 1);
     k.merkle_tail_log = get("HODOR_MERKLE_TAIL_LOG", 6, 0, 30);
     k.merkle_lat_log = get("HODOR_MERKLE_LAT_LOG", 19, 0, 40);
     k.fri_tail = get("HODOR_FRI_TAIL", 1, 0, 1);

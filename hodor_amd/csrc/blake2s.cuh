@@ -66,6 +66,14 @@ __device__ __forceinline__ void b2s_leaf(const B2Mid &mid, const uint4 &lo, cons
     b2s_final(mid, m, 96, out);
 }
 
+// hash of one COSET2 leaf: the 64 bytes of two field elements (one compression, like a node)
+__device__ __forceinline__ void b2s_pair(const B2Mid &mid, const uint4 &a0, const uint4 &a1, const uint4 &b0,
+                                         const uint4 &b1, uint32_t out[8])
+{
+    uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    b2s_final(mid, m, 128, out);
+}
+
 __device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], const uint32_t r[8],
                                          uint32_t out[8])
 {

@@ -53,7 +53,10 @@ hipError_t evaluate_at_launch(hipStream_t, const uint4 *a, uint64_t n, const Fr 
 hipError_t twiddle_mul_launch(hipStream_t, uint4 *a, uint64_t rows, uint64_t cols, uint64_t row0,
                               const TwoLevel &t, uint32_t log_order, const Fr *scale, const FrParams &);
 hipError_t merkle_build_launch(hipStream_t, const uint4 *leafs, uint4 *nodes, uint64_t n, const B2Mid &,
-                               uint32_t batch = 1, const FoldArgs *fold = nullptr, const Fr9Params *Q = nullptr);
+                               uint32_t batch = 1, const FoldArgs *fold = nullptr, const Fr9Params *Q = nullptr,
+                               bool comb = false);
+hipError_t iop_query_coset2_launch(hipStream_t, const uint4 *values, const uint4 *nodes, uint64_t n, uint64_t index,
+                                   uint4 *out, const B2Mid &);
 bool merkle_fuses_fold(uint64_t n);
 hipError_t iop_query_launch(hipStream_t, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &);
@@ -63,7 +66,7 @@ hipError_t fri_round_table_launch(hipStream_t, const uint4 *nodes, uint4 *chal_o
                                   const uint4 *hi, uint4 *hi_out, uint64_t count, const Fr9 &c16, const Fr &r2,
                                   uint32_t shave, const Fr9Params &, const FrParams &);
 hipError_t fri_tail_launch(hipStream_t, const FriTailArgs &, const Fr9 &c16, const Fr &r2, const B2Mid &,
-                           const Fr9Params &, const FrParams &);
+                           const Fr9Params &, const FrParams &, bool comb = false);
 hipError_t fri_fold_launch(hipStream_t, const FoldArgs &, const Fr9Params &);
 
 static inline Fr to_dev(const HFr &a)
@@ -179,6 +182,7 @@ static inline void set_err(hodor_ctx *ctx, const std::string &msg)
 struct hodor_fri_proto {
     hodor_ctx *ctx;
     size_t n, num_steps, lde_factor, out_deg, initial_degree_plus_one;
+    int combiner = 0;                         // HODOR_COMBINER_*: the format of every tree of this prototype
     void *slab = nullptr;                     // one device allocation holding everything below
     size_t slab_bytes = 0;
     void *l0_nodes = nullptr;                 // device, n*32

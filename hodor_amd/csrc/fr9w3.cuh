@@ -34,6 +34,28 @@ struct Fr9W3 {
 #define FR9_MAD(acc, x, y) do { acc += (uint64_t)(x) * (y); } while (0)
 #endif
 
+// P1: the modulus is 1 mod 2^29 (true for both fields of the reference, src/bn256.rs:5 and
+// src/experiments/mod.rs:19: p = 1 mod 2^32 resp. 2^192), so -p^-1 = -1 mod 2^29 and the Montgomery
+// quotient digit is m = -T mod 2^29: a subtraction instead of a (half-rate) v_mul_lo_u32.
+template <bool P1>
+__device__ __forceinline__ uint32_t fr9_mont_digit(uint32_t lo, const Fr9Params &P)
+{
+    return (P1 ? 0u - lo : lo * P.pinv) & HODOR_M29;
+}
+
+// group-wise carry propagation: enough for fr9_mul3, whose bound only needs every 87-bit GROUP below 2^87
+// (limbs 2 and 5 carried into 3 and 6; the top group is bounded by the value itself).  For x with lazy limbs
+// < 2^31.5 and value < 2^261: X_0, X_1 < 2^87 (1 + 2^-26), X_2 < 2^87, column sums of the product
+// <= 9 * 2^31.5 * 2^29 + 3 * 2^58 < 2^64, and the product stays < (4 + 2^-25) p — 6 instructions instead of 24.
+__device__ __forceinline__ void fr9_normalize_groups(Fr9 &a)
+{
+    a.v[3] += a.v[2] >> 29;
+    a.v[2] &= HODOR_M29;
+    a.v[6] += a.v[5] >> 29;
+    a.v[5] &= HODOR_M29;
+}
+
+template <bool P1 = false>
 __device__ __forceinline__ Fr9 fr9_mul3(const Fr9 &a, const Fr9W3 &W, const Fr9Params &P)
 {
     uint32_t m[3];
@@ -53,7 +75,7 @@ __device__ __forceinline__ Fr9 fr9_mul3(const Fr9 &a, const Fr9W3 &W, const Fr9P
             if (j < k && k - j < 9) FR9_MAD(acc, m[j], P.p[k - j]);
         }
         if (k < 3) {
-            m[k] = ((uint32_t)acc * P.pinv) & HODOR_M29;
+            m[k] = fr9_mont_digit<P1>((uint32_t)acc, P);
             FR9_MAD(acc, m[k], P.p[0]);
         } else {
             t.v[k - 3] = (uint32_t)acc & HODOR_M29;
@@ -75,6 +97,7 @@ __device__ __forceinline__ Fr9 fr9_mul3(const Fr9 &a, const Fr9W3 &W, const Fr9P
 // Bounds: x normalized and < 2^261 (every limb < 2^29) => T < 9 * 2^29 p, r < 10 p, normalized.
 typedef const __attribute__((address_space(4))) uint32_t *W9Ptr;
 
+template <bool P1 = false>
 __device__ __forceinline__ Fr9 fr9_mul9(const Fr9 &a, W9Ptr V, const Fr9Params &P)
 {
     Fr9 t;
@@ -84,7 +107,7 @@ __device__ __forceinline__ Fr9 fr9_mul9(const Fr9 &a, W9Ptr V, const Fr9Params &
     for (int k = 0; k < 9; k++) {
 #pragma unroll
         for (int c = 0; c < 9; c++) FR9_MAD(acc, a.v[c], V[12 * k + c]);
-        if (k == 0) m = ((uint32_t)acc * P.pinv) & HODOR_M29;
+        if (k == 0) m = fr9_mont_digit<P1>((uint32_t)acc, P);
         FR9_MAD(acc, m, P.p[k]);
         if (k > 0) t.v[k - 1] = (uint32_t)acc & HODOR_M29;
         acc >>= 29;
@@ -94,6 +117,7 @@ __device__ __forceinline__ Fr9 fr9_mul9(const Fr9 &a, W9Ptr V, const Fr9Params &
 }
 
 // two products by the same constant, column by column: the scalar operands of a column are loaded once
+template <bool P1 = false>
 __device__ __forceinline__ void fr9_mul9x2(Fr9 &a, Fr9 &b, W9Ptr V, const Fr9Params &P)
 {
     Fr9 ta, tb;
@@ -108,8 +132,8 @@ __device__ __forceinline__ void fr9_mul9x2(Fr9 &a, Fr9 &b, W9Ptr V, const Fr9Par
             FR9_MAD(accb, b.v[c], v);
         }
         if (k == 0) {
-            ma = ((uint32_t)acca * P.pinv) & HODOR_M29;
-            mb = ((uint32_t)accb * P.pinv) & HODOR_M29;
+            ma = fr9_mont_digit<P1>((uint32_t)acca, P);
+            mb = fr9_mont_digit<P1>((uint32_t)accb, P);
         }
         FR9_MAD(acca, ma, P.p[k]);
         FR9_MAD(accb, mb, P.p[k]);

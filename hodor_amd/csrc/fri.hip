@@ -68,6 +68,10 @@ k_fri_fold(FoldArgs F, Fr9Params Q)
 // challenge array itself (same workgroup, barrier in between).  Everything the multi-launch path
 // writes (values, trees with nodes[0] = 0, roots, challenges) is written identically.
 // ---------------------------------------------------------------------------------------------
+// COMB: the trees are COSET2 trees (merkle.hip): leaf k of a round with h outputs is y[k] || y[k + h/2] — the two
+// lanes that computed them drop their values into the leaf's 64-byte message block in LDS — and the tree over
+// the h/2 leaves has h/2 heap entries.  Rounds of fewer than 4 outputs do not occur (abi_fri.hip refuses them).
+template <bool COMB>
 __global__ void __launch_bounds__(FRI_TAIL_THREADS)
 k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
 {
@@ -83,7 +87,8 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
     for (uint32_t k = 0; k < A.rounds; k++) {
         const uint32_t h = A.half0 >> k, gi = A.first_round + k;
         uint4 *dst = A.values[k], *nodes = A.nodes[k];
-        const bool quad_leafs = h <= QUADS;
+        const uint32_t leaves = COMB ? h >> 1 : h;
+        const bool quad_leafs = leaves <= QUADS;
         if (tid < h) {
             // fold (fri_on_values.rs:77-100), same arithmetic as k_fri_round_table + k_fri_fold
             Fr9 b16 = fr9_mul(fr9_unpack(fr_load(A.chal + 2 * gi)), c16, Q);
@@ -97,7 +102,12 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
             Fr y = fr9_to_canonical(fr9_add(even, odd), Q);
             fr_store(dst + 2 * tid, y);
             const uint4 y0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]), y1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
-            if (quad_leafs) {
+            if (COMB) {
+                // message block of leaf tid mod h/2, lower or upper 32 bytes; the blocks of a round too wide for
+                // the quad-lane hash (256 leaves) are staged in buf_a, whose hashes then go to buf_b
+                uint4 *blk = (quad_leafs ? buf_m : buf_a) + 4 * (tid & (leaves - 1)) + 2 * (tid >= leaves ? 1 : 0);
+                blk[0] = y0; blk[1] = y1;
+            } else if (quad_leafs) {
                 buf_m[4 * tid] = y0; buf_m[4 * tid + 1] = y1;
                 buf_m[4 * tid + 2] = make_uint4(0, 0, 0, 0); buf_m[4 * tid + 3] = make_uint4(0, 0, 0, 0);
             } else {
@@ -109,16 +119,24 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
         }
         __syncthreads();
         if (quad_leafs) {
-            if (quad < h) {
+            if (quad < leaves) {
                 uint32_t lo, hi;
-                b2q_compress(bq, reinterpret_cast<const uint32_t *>(buf_m + 4 * quad), false, lo, hi);
+                b2q_compress(bq, reinterpret_cast<const uint32_t *>(buf_m + 4 * quad), COMB, lo, hi);
                 uint32_t *o = reinterpret_cast<uint32_t *>(buf_a + 2 * quad);
                 o[j] = lo; o[4 + j] = hi;
             }
             __syncthreads();
+        } else if (COMB) {
+            if (tid < leaves) {
+                uint32_t out[8];
+                b2s_pair(mid, buf_a[4 * tid], buf_a[4 * tid + 1], buf_a[4 * tid + 2], buf_a[4 * tid + 3], out);
+                buf_b[2 * tid] = make_uint4(out[0], out[1], out[2], out[3]);
+                buf_b[2 * tid + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+            }
+            __syncthreads();
         }
-        uint4 *s = buf_a, *d = buf_b;
-        for (uint32_t w = h >> 1; w >= 1; w >>= 1) {             // level of width w at nodes[w .. 2w)
+        uint4 *s = (COMB && !quad_leafs) ? buf_b : buf_a, *d = (COMB && !quad_leafs) ? buf_a : buf_b;
+        for (uint32_t w = leaves >> 1; w >= 1; w >>= 1) {        // level of width w at nodes[w .. 2w)
             if (w <= QUADS) {
                 if (quad < w) {
                     uint32_t lo, hi;
@@ -155,9 +173,10 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
 }
 
 hipError_t fri_tail_launch(hipStream_t s, const FriTailArgs &A, const Fr9 &c16, const Fr &r2, const B2Mid &mid,
-                           const Fr9Params &Q, const FrParams &P)
+                           const Fr9Params &Q, const FrParams &P, bool comb)
 {
-    hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P);
+    if (comb) hipLaunchKernelGGL(k_fri_tail<true>, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P);
+    else hipLaunchKernelGGL(k_fri_tail<false>, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P);
     return hipGetLastError();
 }
 

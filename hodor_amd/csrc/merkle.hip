@@ -51,14 +51,19 @@ constexpr uint32_t MERKLE_LAT_LOG_CH = 8;    // latency: 256 inputs per workgrou
 // FOLD (leaf launch only, either schedule): the leaves do not exist yet — leaf i is the FRI fold of the
 // previous round's values (fri_fold_one), computed here, stored to `fold.dst` and hashed from registers,
 // which saves the separate fold launch and its round trip through memory.
-template <bool LEAF, bool LAT, bool FOLD = false>
+// COMB (leaf launch only): the COSET2 combiner — leaf k of the tree is the 64-byte pair value[k] || value[k + n/2]
+// (the coset FRI opens together, src/fri/query_producer.rs:27-34; CosetCombiner seam src/iop/mod.rs:22-34), hashed
+// with ONE compression; the tree has m = n/2 leaves and its heap array n/2 entries.  With FOLD the two values of a
+// leaf are fold outputs k and k + n/2 of the round.
+template <bool LEAF, bool LAT, bool FOLD = false, bool COMB = false>
 __global__ void __launch_bounds__(256)
 k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint32_t levels, uint64_t n,
                  B2Mid mid, FoldArgs fold = FoldArgs(), Fr9Params Q = Fr9Params())
 {
-    // blockIdx.y selects one of several independent trees over n leaves each (batched commit)
+    // blockIdx.y selects one of several independent trees over n values each (batched commit)
     leafs += 2 * (uint64_t)blockIdx.y * n;
-    nodes += 2 * (uint64_t)blockIdx.y * n;
+    nodes += 2 * (uint64_t)blockIdx.y * (COMB ? n >> 1 : n);
+    const uint64_t half = n >> 1;   // COMB: distance between the two values of a leaf
     // throughput: level 1 (1024 digests) | level 2 (512); latency: the inputs (256 digests) | level 1 (128)
     constexpr uint32_t CAP_A = LAT ? (1u << MERKLE_LAT_LOG_CH) : (1u << (MERKLE_LOG_CH - 1));
     __shared__ uint4 buf_a[2 * CAP_A];
@@ -73,20 +78,28 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
     if (LAT) {
         // one input per lane into LDS: leaf hash (LEAF) or the digest itself
         for (uint32_t p = tid; p < ch; p += nthreads) {
-            uint4 a0, a1;
+            uint4 a0, a1, b0, b1;
             if (FOLD) {
                 const uint64_t i = (chunk << log_ch) + p;
                 Fr y = fri_fold_one(fold, i, Q);
                 fr_store(fold.dst + 2 * i, y);
                 a0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
                 a1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+                if (COMB) {
+                    y = fri_fold_one(fold, i + half, Q);
+                    fr_store(fold.dst + 2 * (i + half), y);
+                    b0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+                    b1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+                }
             } else {
                 a0 = in[2 * p];
                 a1 = in[2 * p + 1];
+                if (COMB) { b0 = in[2 * (p + half)]; b1 = in[2 * (p + half) + 1]; }
             }
             if (LEAF) {
                 uint32_t out[8];
-                b2s_leaf(mid, a0, a1, out);
+                if (COMB) b2s_pair(mid, a0, a1, b0, b1, out);
+                else b2s_leaf(mid, a0, a1, out);
                 a0 = make_uint4(out[0], out[1], out[2], out[3]);
                 a1 = make_uint4(out[4], out[5], out[6], out[7]);
             }
@@ -98,6 +111,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
         uint4 *lvl_out = nodes + 2 * ((m >> 1) + chunk * (ch >> 1));
         for (uint32_t p = tid; p < (ch >> 1); p += nthreads) {
             uint4 a0, a1, b0, b1;
+            uint4 c0, c1, d0, d1;   // COMB: the upper halves of the two leaves (values k + n/2, k + 1 + n/2)
             if (FOLD) {
                 // the two leaves of this lane are FRI fold outputs that do not exist yet: compute them
                 // (two products each), store them as the round's values, hash them from registers
@@ -109,12 +123,26 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
                 a1 = make_uint4(y0.v[4], y0.v[5], y0.v[6], y0.v[7]);
                 b0 = make_uint4(y1.v[0], y1.v[1], y1.v[2], y1.v[3]);
                 b1 = make_uint4(y1.v[4], y1.v[5], y1.v[6], y1.v[7]);
+                if (COMB) {
+                    y0 = fri_fold_one(fold, i + half, Q);
+                    y1 = fri_fold_one(fold, i + half + 1, Q);
+                    fr_store(fold.dst + 2 * (i + half), y0);
+                    fr_store(fold.dst + 2 * (i + half) + 2, y1);
+                    c0 = make_uint4(y0.v[0], y0.v[1], y0.v[2], y0.v[3]);
+                    c1 = make_uint4(y0.v[4], y0.v[5], y0.v[6], y0.v[7]);
+                    d0 = make_uint4(y1.v[0], y1.v[1], y1.v[2], y1.v[3]);
+                    d1 = make_uint4(y1.v[4], y1.v[5], y1.v[6], y1.v[7]);
+                }
             } else {
                 const uint4 *q = in + 4 * p;
                 a0 = q[0]; a1 = q[1]; b0 = q[2]; b1 = q[3];
+                if (COMB) { q += 2 * half; c0 = q[0]; c1 = q[1]; d0 = q[2]; d1 = q[3]; }
             }
             uint32_t l[8], r[8], out[8];
-            if (LEAF) {
+            if (LEAF && COMB) {
+                b2s_pair(mid, a0, a1, c0, c1, l);
+                b2s_pair(mid, b0, b1, d0, d1, r);
+            } else if (LEAF) {
                 b2s_leaf(mid, a0, a1, l);
                 b2s_leaf(mid, b0, b1, r);
             } else {
@@ -214,9 +242,44 @@ __global__ void k_iop_query(const uint4 *leaf_pair, const uint4 *nodes, uint64_t
     }
 }
 
+// The same for a COSET2 tree (n values, n/2 leaves): out[0] = value[k], out[1] = value[k + n/2] for the leaf
+// k = index mod n/2, out[2] = hash of the sibling leaf, out[2 + j] = sibling node at tree level log2(n/2) - 1 - j.
+__global__ void k_iop_query_coset2(const uint4 *values, const uint4 *nodes, uint64_t n, uint64_t index, uint4 *out,
+                                   B2Mid mid)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint64_t leaves = n >> 1, k = index & (leaves - 1);
+    uint32_t levels = 0;
+    for (uint64_t w = leaves >> 1; w >= 2; w >>= 1) levels++;   // log2(leaves) - 1 node levels on the path
+    if (lane == 0) {
+        const uint4 *lo = values + 2 * k, *hi = values + 2 * (k + leaves);
+        out[0] = lo[0]; out[1] = lo[1];
+        out[2] = hi[0]; out[3] = hi[1];
+        const uint4 *slo = values + 2 * (k ^ 1), *shi = values + 2 * ((k ^ 1) + leaves);
+        uint32_t h[8];
+        b2s_pair(mid, slo[0], slo[1], shi[0], shi[1], h);
+        out[4] = make_uint4(h[0], h[1], h[2], h[3]);
+        out[5] = make_uint4(h[4], h[5], h[6], h[7]);
+    } else if (lane <= levels) {
+        uint32_t j = lane - 1;
+        uint64_t width = leaves >> (j + 1);
+        uint64_t idx = (k >> (j + 1)) ^ 1;
+        const uint4 *src = nodes + 2 * (width + idx);
+        out[2 * (lane + 2)] = src[0];
+        out[2 * (lane + 2) + 1] = src[1];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+hipError_t iop_query_coset2_launch(hipStream_t s, const uint4 *values, const uint4 *nodes, uint64_t n,
+                                   uint64_t index, uint4 *out, const B2Mid &mid)
+{
+    hipLaunchKernelGGL(k_iop_query_coset2, dim3(1), dim3(64), 0, s, values, nodes, n, index, out, mid);
+    return hipGetLastError();
+}
+
 hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &mid)
 {
@@ -238,12 +301,12 @@ bool merkle_fuses_fold(uint64_t n)
 }
 
 hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, uint64_t n,
-                               const B2Mid &mid, uint32_t batch, const FoldArgs *fold, const Fr9Params *Q)
+                               const B2Mid &mid, uint32_t batch, const FoldArgs *fold, const Fr9Params *Q, bool comb)
 {
-    // n >= 2, power of two (checked by the caller); `batch` trees back to back
+    // n >= 2 (comb: n >= 4), power of two (checked by the caller); `batch` trees back to back
     merkle_knobs();
     const int tail_log = g_tail_log, lat_log = g_lat_log;
-    uint64_t m = n;
+    uint64_t m = comb ? n >> 1 : n;   // leaves of the tree
     bool first = true;
     while (m > 1) {
         uint32_t log_m = 0;
@@ -263,7 +326,14 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
             if (threads < 64) threads = 64;
         }
         dim3 grid((unsigned)chunks, batch);
-        if (first && lat && fold)
+        if (first && comb) {
+            const FoldArgs fa = fold ? *fold : FoldArgs();
+            const Fr9Params qa = Q ? *Q : Fr9Params();
+            if (lat && fold)  hipLaunchKernelGGL((k_merkle_subtree<true, true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
+            else if (lat)     hipLaunchKernelGGL((k_merkle_subtree<true, true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
+            else if (fold)    hipLaunchKernelGGL((k_merkle_subtree<true, false, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
+            else              hipLaunchKernelGGL((k_merkle_subtree<true, false, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
+        } else if (first && lat && fold)
             hipLaunchKernelGGL((k_merkle_subtree<true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
         else if (first && lat)
             hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());

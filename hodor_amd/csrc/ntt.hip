@@ -146,11 +146,12 @@ __device__ __forceinline__ Fr9 fr9_sub5(const Fr9 &a, const Fr9 &b, const Fr9Par
 // x * base^e through the two-level W3 table: base^e = hi[e >> lo_bits] * lo[e & mask], applied as two
 // successive data x constant products (x normalized on entry, result normalized and < 4p).
 // `always`: hi[0] is not 1 (it carries the folded n^-1 scale), so it is applied even for exponent 0.
+template <bool P1>
 __device__ __forceinline__ Fr9 mul_two_level(Fr9 x, const TwoLevel &t, uint64_t e, bool always, const Fr9Params &Q)
 {
     const uint64_t lo_i = e & ((1ull << t.lo_bits) - 1), hi_i = e >> t.lo_bits;
-    if (hi_i != 0 || always) x = fr9_mul3(x, fr9w3_load(t.hi + 7 * hi_i), Q);
-    if (lo_i != 0) x = fr9_mul3(x, fr9w3_load(t.lo + 7 * lo_i), Q);
+    if (hi_i != 0 || always) x = fr9_mul3<P1>(x, fr9w3_load(t.hi + 7 * hi_i), Q);
+    if (lo_i != 0) x = fr9_mul3<P1>(x, fr9w3_load(t.lo + 7 * lo_i), Q);
     return x;
 }
 
@@ -194,7 +195,8 @@ __device__ __forceinline__ uint64_t split_index(const SplitAddr &S, uint64_t x, 
 
 // MODE 0: plain arrays (every transform of the single-GPU API).  MODE 1: the same pass with the
 // generalized layouts of PassArgs (column mode, 2D twiddle, split addressing) compiled in.
-template <int MODE>
+// P1: modulus = 1 mod 2^29 (fr9_mont_digit): chosen by the launcher from Fr9Params::pinv.
+template <int MODE, bool P1>
 __global__ void __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
 {
@@ -268,7 +270,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 // the row of a column-mode source may itself arrive cut into slabs / chunks (src_split)
                 const uint64_t srow = A.src_split.on ? split_index(A.src_split, g, 0) : g;
                 x = fr9_unpack(fr_load(A.src + 2 * ((srow << A.src_log_width) + A.src_col_off + colbase + c)));
-                if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
+                if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level<P1>(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
             } else if (MODE == 1 && A.src_split.on) {
                 x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, by)));
             } else if (ABL(32) && A.apply_tw) {   // upper bound of "lazy intermediates": the words as they are, no unpack
@@ -279,10 +281,10 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             } else {
                 x = fr9_unpack(fr_load(src_b + 2 * g));
             }
-            if (A.pre.lo != nullptr) x = mul_two_level(x, A.pre, g, false, Q);
+            if (A.pre.lo != nullptr) x = mul_two_level<P1>(x, A.pre, g, false, Q);
             if (A.apply_tw && !ABL(2)) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
-                x = mul_two_level(x, A.tw, ex, A.tw_always != 0, Q);
+                x = mul_two_level<P1>(x, A.tw, ex, A.tw_always != 0, Q);
             }
         } else {
 #pragma unroll
@@ -308,7 +310,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c);
             Fr9 x0 = lds_get(D, s0), x1 = lds_get(D, s1);
             // m == 1: twiddle 1 and x1 is a stored value (normalized, < 4p), a valid subtrahend
-            if (m > 1) x1 = fr9_mul3(x1, fr9w3_load(T + 7 * ((jp << (log_r - log_m - 1)) >> tw_sub)), Q);
+            if (m > 1) x1 = fr9_mul3<P1>(x1, fr9w3_load(T + 7 * ((jp << (log_r - log_m - 1)) >> tw_sub)), Q);
             Fr9 y0 = fr9_add(x0, x1), y1 = fr9_sub5(x0, x1, Q);
             fr9_normalize(y0);
             fr9_normalize(y1);
@@ -347,12 +349,12 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 Fr9 t;
                 const bool ones = jp == 0 && (m == 1 || A.w9_skip_one);   // wa = wb = 1 (wave-uniform branch)
                 if (!ones) {
-                    fr9_mul9x2(x1, x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 1)) >> e_shift), Q);
+                    fr9_mul9x2<P1>(x1, x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 1)) >> e_shift), Q);
                     t = x1; x1 = fr9_sub11(x0, t, Q); x0 = fr9_add(x0, t);
                     t = x3; x3 = fr9_sub11(x2, t, Q); x2 = fr9_add(x2, t);
                     fr9_normalize(x2);
                     fr9_normalize(x3);
-                    t = fr9_mul9(x2, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 2)) >> e_shift), Q);
+                    t = fr9_mul9<P1>(x2, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 2)) >> e_shift), Q);
                     x2 = fr9_sub11(x0, t, Q); x0 = fr9_add(x0, t);
                 } else {
                     // twiddles 1: the subtrahends are stored values, brought under 2p first unless this is the
@@ -365,7 +367,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                     x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                     fr9_normalize(x3);
                 }
-                t = fr9_mul9(x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane(((jp + m) << (log_r - log_m - 2)) >> e_shift), Q);
+                t = fr9_mul9<P1>(x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane(((jp + m) << (log_r - log_m - 2)) >> e_shift), Q);
                 x3 = fr9_sub11(x1, t, Q); x1 = fr9_add(x1, t);
                 fr9_normalize(x0);
                 fr9_normalize(x1);
@@ -402,15 +404,20 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 Fr9 t;
                 if (m > 1) {
                     const Fr9W3 wa = twiddle(jp << (log_r - log_m - 1));
-                    t = fr9_mul3(x1, wa, Q);
+                    t = fr9_mul3<P1>(x1, wa, Q);
                     x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
-                    t = fr9_mul3(x3, wa, Q);
+                    t = fr9_mul3<P1>(x3, wa, Q);
                     x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
-                    // the second stage multiplies the lazy sums: carry-propagate them first so that the
-                    // W3 product sees 87-bit limb groups (its < 4p bound)
+                    // the second stage multiplies the lazy sums (limbs < 2^29 + 2^30): the W3 product only needs
+                    // its three 87-bit limb GROUPS below 2^87 for its (4 + 2^-25) p bound — two carries, not eight
+#ifdef HODOR_EXP_FULLNORM
                     fr9_normalize(x2);
                     fr9_normalize(x3);
-                    t = fr9_mul3(x2, twiddle(jp << (log_r - log_m - 2)), Q);
+#else
+                    fr9_normalize_groups(x2);
+                    fr9_normalize_groups(x3);
+#endif
+                    t = fr9_mul3<P1>(x2, twiddle(jp << (log_r - log_m - 2)), Q);
                     x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                 } else {
                     // twiddles are 1: subtrahends are stored values (normalized, < 4p), except the
@@ -422,7 +429,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                     x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                     fr9_normalize(x3);
                 }
-                t = fr9_mul3(x3, twiddle((jp + m) << (log_r - log_m - 2)), Q);
+                t = fr9_mul3<P1>(x3, twiddle((jp + m) << (log_r - log_m - 2)), Q);
                 x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
                 fr9_normalize(x0);
                 fr9_normalize(x1);
@@ -453,9 +460,9 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << A.log_l);
         Fr9 x = lds_get(D, SLOT(cc, c));
         if (has_scale) x = fr9_mul(x, scale, Q);
-        if (A.post.lo != nullptr) x = mul_two_level(x, A.post, o, false, Q);
+        if (A.post.lo != nullptr) x = mul_two_level<P1>(x, A.post, o, false, Q);
         if (MODE == 1 && colm && A.tw2d.lo != nullptr && !A.tw2d_on_load)
-            x = mul_two_level(x, A.tw2d, o * (A.col0 + colbase + c), false, Q);
+            x = mul_two_level<P1>(x, A.tw2d, o * (A.col0 + colbase + c), false, Q);
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y;
         if (ABL(32) && !last) {                   // ... and no reduction / pack on the way out
@@ -487,12 +494,16 @@ size_t ntt_pass_lds_bytes(uint32_t log_r, uint32_t log_c, uint32_t tw_sub)
 
 hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *scale, const Fr9Params &Q)
 {
-    static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<0>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_rc1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<1>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc0 != hipSuccess) return attr_rc0;
-    if (attr_rc1 != hipSuccess) return attr_rc1;
+    static const hipError_t attr_rc = [] {
+        const void *fns[4] = {reinterpret_cast<const void *>(k_ntt_pass<0, false>), reinterpret_cast<const void *>(k_ntt_pass<0, true>),
+                              reinterpret_cast<const void *>(k_ntt_pass<1, false>), reinterpret_cast<const void *>(k_ntt_pass<1, true>)};
+        for (const void *f : fns) {
+            hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (rc != hipSuccess) return rc;
+        }
+        return hipSuccess;
+    }();
+    if (attr_rc != hipSuccess) return attr_rc;
     uint64_t n = 1ull << A.log_n;
     const bool general = A.col_mode || A.src_split.on || A.dst_split.on;
     // column mode: one sub-transform position per workgroup, grid.y walks the array's columns C at a time
@@ -570,13 +581,16 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
 #ifdef HODOR_TWOPASS
     if (items >= 1024) threads = 1024;
 #endif
-    if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override;
-    if (general)
-        hipLaunchKernelGGL(k_ntt_pass<1>, dim3((unsigned)grid, (unsigned)grid_y, grid_z), dim3(threads), lds, stream, B, s,
-                           scale ? 1u : 0u, Q);
-    else
-        hipLaunchKernelGGL(k_ntt_pass<0>, dim3((unsigned)grid, (unsigned)grid_y, grid_z), dim3(threads), lds, stream, B, s,
-                           scale ? 1u : 0u, Q);
+    // rounded down to whole waves: the wave-uniform steps deal their work per wave (tid >> 6, nthreads >> 6)
+    if (threads_override >= 64 && threads_override <= NTT_MAX_THREADS) threads = (unsigned)threads_override & ~63u;
+    // p = 1 mod 2^29 <=> -p^-1 = -1 mod 2^29 (Fr9Params::pinv all ones): the Montgomery digit is a negation
+    const bool p1 = knobs().ntt_p1 && Q.pinv == HODOR_M29;
+    const dim3 g3((unsigned)grid, (unsigned)grid_y, grid_z);
+    const uint32_t hs = scale ? 1u : 0u;
+    if (general && p1) hipLaunchKernelGGL((k_ntt_pass<1, true>), g3, dim3(threads), lds, stream, B, s, hs, Q);
+    else if (general)  hipLaunchKernelGGL((k_ntt_pass<1, false>), g3, dim3(threads), lds, stream, B, s, hs, Q);
+    else if (p1)       hipLaunchKernelGGL((k_ntt_pass<0, true>), g3, dim3(threads), lds, stream, B, s, hs, Q);
+    else               hipLaunchKernelGGL((k_ntt_pass<0, false>), g3, dim3(threads), lds, stream, B, s, hs, Q);
     return hipGetLastError();
 }
 

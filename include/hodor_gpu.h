@@ -61,7 +61,7 @@ int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
 /* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
- * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_MIN_LOG_C, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TW_SUB, HODOR_NTT_W9,
+ * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_MIN_LOG_C, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TW_SUB, HODOR_NTT_W9, HODOR_NTT_P1,
  * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ.
  * They are read once per process, change schedules only (never results), and a benchmark must echo
  * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
@@ -125,10 +125,41 @@ int hodor_iop_path(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *l
 int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *leaf,
                      const uint8_t *path, size_t path_len, size_t tree_index, int *ok);
 
+/* ---- coset combining: the tree format as a parameter (CosetCombiner, src/iop/mod.rs:22-34) --------------------
+ * The reference's IOP is generic over a CosetCombiner whose only instance is TrivialCombiner
+ * (src/iop/trivial_coset_combiner.rs:17-53: identity index maps, coset {i, i + n/2}); its README lists "Proof size
+ * optimization with coset combining" as not done (README.md:46).  FRI always opens the two members of a coset
+ * together (src/fri/query_producer.rs:27-34), so HODOR_COMBINER_COSET2 — an opt-in format DEFINED BY THIS BUILD —
+ * commits them as ONE leaf:
+ *     natural index i of n values  <->  tree element t = 2 (i mod n/2) + (i div n/2)   (natural_index_into_tree_index)
+ *     leaf k (k < n/2) = the 64 bytes value[k] || value[k + n/2], hashed with ONE keyed BLAKE2s call
+ *     nodes = heap array of the tree over those n/2 leaves: (n/2) x 32 bytes, root = nodes[32..64]
+ *     path  = log2(n) - 1 digests; a query returns both values of the coset
+ * -> n compressions per tree instead of 2n, one path per FRI round instead of two.  n >= 4.  Every entry point
+ * without a `combiner` argument is the TRIVIAL format, byte for byte the reference's. */
+enum { HODOR_COMBINER_TRIVIAL = 0, HODOR_COMBINER_COSET2 = 1 };
+/* IopTree::create (:131-219) in the chosen format; nodes: n x 32 bytes (TRIVIAL) / (n/2) x 32 bytes (COSET2) */
+int hodor_iop_create_combined(hodor_ctx *ctx, const hodor_fr *leafs, size_t n, int combiner, uint8_t *nodes);
+/* hash of one leaf: `values` holds 1 element (TRIVIAL, = hodor_hash_leaf) or the 2 of a coset (COSET2) */
+int hodor_hash_leaf_combined(const hodor_ctx *ctx, const hodor_fr *values, int combiner, uint8_t out[32]);
+/* get_path (:251-279) of the leaf that holds `natural_index` (host) */
+int hodor_iop_path_combined(const hodor_ctx *ctx, const uint8_t *nodes, const hodor_fr *leafs, size_t n,
+                            int combiner, size_t natural_index, uint8_t *path, size_t *path_len);
+/* verify (:236-249): `values` = the queried element (TRIVIAL) or {value[k], value[k + n/2]}, k = natural_index mod n/2
+ * (COSET2); n = the size of the committed vector */
+int hodor_iop_verify_combined(const hodor_ctx *ctx, const uint8_t root[32], const hodor_fr *values,
+                              const uint8_t *path, size_t path_len, size_t natural_index, size_t n, int combiner,
+                              int *ok);
+
 /* FriIop::proof_from_lde (NaiveFriIop::proof_from_lde_by_values) — src/fri/fri_on_values.rs:11-159.
  * The result mirrors FRIProofPrototype field for field (src/fri/mod.rs:106-117). */
 int  hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
                       size_t output_coeffs_at_degree_plus_one, hodor_fri_proto **out);
+/* the same with every oracle (l0 and intermediates) in the chosen format; COSET2 needs lde_factor *
+ * output_coeffs_at_degree_plus_one >= 4 (two combined leaves in the last tree) */
+int  hodor_fri_commit_combined(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                               size_t output_coeffs_at_degree_plus_one, int combiner, hodor_fri_proto **out);
+int  hodor_fri_combiner(const hodor_fri_proto *p);   /* HODOR_COMBINER_* of the prototype's trees */
 void hodor_fri_free(hodor_fri_proto *p);   /* before hodor_ctx_destroy of the context it came from */
 size_t hodor_fri_num_steps(const hodor_fri_proto *p);
 /* roots: l0 root followed by the intermediate roots -> (num_steps + 1) x 32 bytes (get_roots, src/fri/mod.rs:120-128) */
@@ -136,7 +167,8 @@ int hodor_fri_roots(const hodor_fri_proto *p, uint8_t *roots);
 int hodor_fri_final_root(const hodor_fri_proto *p, uint8_t root[32]);
 int hodor_fri_challenges(const hodor_fri_proto *p, hodor_fr *challenges /* num_steps */);
 int hodor_fri_final_coefficients(const hodor_fri_proto *p, hodor_fr *coeffs /* output_coeffs_at_degree_plus_one */);
-/* intermediate_values[step] (size n >> (step+1)) and the tree of step (-1 = l0 tree, size n) */
+/* intermediate_values[step] (size n >> (step+1)) and the tree of step (-1 = l0 tree, size n; a COSET2 tree has
+ * half as many entries as its vector) */
 int hodor_fri_intermediate_values(hodor_fri_proto *p, size_t step, hodor_fr *values);
 int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes);
 /* canonical prototype encoding (the reference defines none, README.md:44):
@@ -323,12 +355,20 @@ int hodor_gen_elements_dev(hodor_ctx *ctx, void *stream, hodor_fr *dst, uint64_t
                            uint64_t seed);
 /* Merkle tree over n device-resident leaves into n*32 device bytes */
 int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, uint8_t *nodes);
+int hodor_iop_create_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, int combiner,
+                                  uint8_t *nodes);
+/* IOP::query in the chosen format: COSET2 writes BOTH values of the coset {k, k + n/2}, k = natural_index mod n/2,
+ * to values[0..2) and the path of the combined leaf (log2(n) - 1 digests); TRIVIAL = hodor_iop_query_dev. */
+int hodor_iop_query_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, const uint8_t *nodes, size_t n,
+                                 int combiner, size_t natural_index, hodor_fr *values, uint8_t *path, size_t *path_len);
 /* IOP::query (src/iop/blake2s_trivial_iop.rs:324-338) on device-resident leaves and tree: the leaf
  * value and its authentication path (log2 n digests) are copied to the host buffers. */
 int hodor_iop_query_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, const uint8_t *nodes, size_t n,
                         size_t natural_index, hodor_fr *value, uint8_t *path, size_t *path_len);
 /* FRIProofPrototype::produce_proof (src/fri/query_producer.rs:10-53) against the device-resident
  * prototype: the serialised FRIProof (src/fri/mod.rs:139-147; layout documented in csrc/abi_fri.hip).
+ * A COSET2 prototype writes ONE query per round — u64 index (the smaller member of the coset), the two values
+ * (64 bytes), u64 path_len, path — where a TRIVIAL one writes two queries of one value each.
  * `lde_values_dev` is the codeword the prototype was committed from (device pointer).  Returns the
  * byte count; writes only when buf != NULL and cap is large enough; 0 on error. */
 size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_dev,
@@ -345,14 +385,27 @@ size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *lde_values_de
  * output_coeffs_at_degree_plus_one == 1 round-trip through produce_proof -> verify_proof. */
 int hodor_fri_verify_proof(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t natural_element_index,
                            const hodor_fr *expected_value_from_oracle, int *valid);
-/* The same verifier with the proof's SHAPE bound to the domain the caller expects before any hash is checked —
- * what the caveats above ask an integrator to do by hand.  *valid = 0 (HODOR_OK) unless
- * initial_degree_plus_one * lde_factor == expected_domain_size, n_roots == log2(initial_degree_plus_one /
- * out_deg) + 1, n_queries == 2 * n_roots, n_final == out_deg and every path has the length of its round's tree;
- * a truncated proof, which the reference's walk (and hodor_fri_verify_proof) accepts, is refused here. */
+/* The same verifier with the proof bound to the parameters the CALLER chose before any hash is checked — what
+ * the caveats above ask an integrator to do by hand.  *valid = 0 (HODOR_OK) unless the proof's lde_factor and
+ * output_coeffs_at_degree_plus_one EQUAL the expected ones (a proof re-encoded with lde_factor = 1 — rate 1, every
+ * function "low degree" — passes the reference's walk), initial_degree_plus_one == expected_domain_size /
+ * expected_lde_factor, n_roots == log2(initial_degree_plus_one / out_deg) + 1, n_queries == 2 * n_roots,
+ * n_final == out_deg and every path has the length of its round's tree; a truncated proof, which the reference's
+ * walk (and hodor_fri_verify_proof) accepts, is refused here. */
 int hodor_fri_verify_proof_strict(const hodor_ctx *ctx, const uint8_t *proof, size_t len, size_t expected_domain_size,
+                                  size_t expected_lde_factor, size_t expected_output_coeffs_at_degree_plus_one,
                                   size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
                                   int *valid);
+/* Both verifiers for a proof whose trees were built by `combiner` (COSET2: one query per round, checked with one
+ * path; n_queries == n_roots, path lengths log2(size) - 1). */
+int hodor_fri_verify_proof_combined(const hodor_ctx *ctx, const uint8_t *proof, size_t len, int combiner,
+                                    size_t natural_element_index, const hodor_fr *expected_value_from_oracle,
+                                    int *valid);
+int hodor_fri_verify_proof_strict_combined(const hodor_ctx *ctx, const uint8_t *proof, size_t len, int combiner,
+                                           size_t expected_domain_size, size_t expected_lde_factor,
+                                           size_t expected_output_coeffs_at_degree_plus_one,
+                                           size_t natural_element_index,
+                                           const hodor_fr *expected_value_from_oracle, int *valid);
 /* NaiveFriIop::verify_prototype — src/fri/verifier.rs:10-129: the folding walk against the prover's own
  * device-resident vectors (two elements fetched per round).  *valid as above. */
 int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_dev, size_t natural_element_index,
@@ -361,6 +414,9 @@ int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *lde_values_de
 int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
                          size_t lde_factor, size_t output_coeffs_at_degree_plus_one,
                          hodor_fri_proto **out);
+int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
+                                  size_t lde_factor, size_t output_coeffs_at_degree_plus_one, int combiner,
+                                  hodor_fri_proto **out);
 
 #ifdef __cplusplus
 }

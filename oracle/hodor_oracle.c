@@ -1045,6 +1045,78 @@ int o_iop_verify(const uint8_t root[32], const ofr *leaf, const uint8_t *path, s
 }
 
 /* ------------------------------------------------------------------------------------------
+ * COSET2 combiner (see hodor_oracle.h): leaf k = value[k] || value[k + n/2], one hash per coset
+ * ------------------------------------------------------------------------------------------ */
+void o_hash_leaf_pair(uint8_t out[32], const ofr *lo, const ofr *hi)
+{
+    uint8_t enc[64];
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) {
+            enc[8 * i + b] = (uint8_t)(lo->l[i] >> (8 * b));        /* encode_leaf :36-42, twice */
+            enc[32 + 8 * i + b] = (uint8_t)(hi->l[i] >> (8 * b));
+        }
+    o_blake2s(out, IOP_KEY, 19, IOP_PERSONAL, 7, enc, 64);
+}
+
+typedef struct { const ofr *values; size_t half; uint8_t *lh; } pairh_ctx;
+static void pairh_chunk(void *vctx, size_t ci, size_t start, size_t len)
+{
+    (void)ci;
+    pairh_ctx *c = (pairh_ctx *)vctx;
+    for (size_t k = start; k < start + len; k++) o_hash_leaf_pair(c->lh + 32 * k, &c->values[k], &c->values[k + c->half]);
+}
+
+/* Blake2sIopTree::create :131-219 over the n/2 combined leaves */
+int o_iop_create_coset2(const ofr *values, size_t n, uint8_t *nodes, uint32_t cpus)
+{
+    if (!is_pow2(n) || n < 4) return -1;
+    size_t leaves = n / 2;
+    uint8_t *lh = (uint8_t *)malloc(leaves * 32);
+    pairh_ctx pc = {values, leaves, lh};
+    worker_scope(cpus, leaves, pairh_chunk, &pc);
+    memset(nodes, 0, 32);
+    nodeh_ctx nc = {lh, nodes + 32 * (leaves / 2)};
+    worker_scope(cpus, leaves / 2, nodeh_chunk, &nc);
+    for (size_t width = leaves / 4; width >= 1; width /= 2) {
+        nodeh_ctx c = {nodes + 32 * (2 * width), nodes + 32 * width};
+        worker_scope(cpus, width, nodeh_chunk, &c);
+    }
+    free(lh);
+    return 0;
+}
+
+/* get_path :251-279 for the leaf that holds natural_index (k = natural_index mod n/2) */
+size_t o_iop_path_coset2(const uint8_t *nodes, const ofr *values, size_t n, size_t natural_index, uint8_t *path)
+{
+    size_t leaves = n / 2, k = natural_index % leaves, cnt = 0;
+    o_hash_leaf_pair(path, &values[k ^ 1], &values[(k ^ 1) + leaves]);
+    cnt++;
+    size_t idx = k >> 1;
+    for (size_t width = leaves / 2; width >= 2; width /= 2) {
+        memcpy(path + 32 * cnt, nodes + 32 * (width + (idx ^ 1)), 32);
+        cnt++;
+        idx >>= 1;
+    }
+    return cnt;
+}
+
+/* verify :236-249 with the combined leaf */
+int o_iop_verify_coset2(const uint8_t root[32], const ofr *lo, const ofr *hi, const uint8_t *path, size_t path_len,
+                        size_t leaf_index)
+{
+    uint8_t h[32], t[32];
+    o_hash_leaf_pair(h, lo, hi);
+    size_t idx = leaf_index;
+    for (size_t i = 0; i < path_len; i++) {
+        if ((idx & 1) == 0) o_hash_node(t, h, path + 32 * i);
+        else o_hash_node(t, path + 32 * i, h);
+        memcpy(h, t, 32);
+        idx >>= 1;
+    }
+    return memcmp(h, root, 32) == 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * NaiveFriIop::proof_from_lde_by_values — src/fri/fri_on_values.rs:11-159
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -1083,6 +1155,20 @@ static void powtab_chunk(void *vctx, size_t ci, size_t start, size_t len)
 int o_fri_commit(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
                  size_t out_deg_plus_one, uint32_t cpus, ofri_proto **outp)
 {
+    return o_fri_commit_combined(f, lde_values, n, lde_factor, out_deg_plus_one, O_COMBINER_TRIVIAL, cpus, outp);
+}
+
+static int tree_create(int combiner, const ofr *values, size_t n, uint8_t *nodes, uint32_t cpus)
+{
+    return combiner == O_COMBINER_COSET2 ? o_iop_create_coset2(values, n, nodes, cpus)
+                                         : o_iop_create(values, n, nodes, cpus);
+}
+
+int o_fri_commit_combined(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
+                          size_t out_deg_plus_one, int combiner, uint32_t cpus, ofri_proto **outp)
+{
+    if (combiner != O_COMBINER_TRIVIAL && combiner != O_COMBINER_COSET2) return -1;
+    const size_t min_tree = combiner == O_COMBINER_COSET2 ? 4 : 2;
     if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg_plus_one)) return -1;
     odomain d;
     if (odomain_new_for_size(f, n, &d)) return -1;
@@ -1096,7 +1182,7 @@ int o_fri_commit(const ofield *f, const ofr *lde_values, size_t n, size_t lde_fa
     p->output_coeffs_at_degree_plus_one = out_deg_plus_one;
     p->lde_factor = lde_factor;
     p->l0_nodes = (uint8_t *)malloc(n * 32);
-    o_iop_create(lde_values, n, p->l0_nodes, cpus);                      /* :17 */
+    if (tree_create(combiner, lde_values, n, p->l0_nodes, cpus)) { free(p->l0_nodes); free(p); return -1; }   /* :17 */
 
     ofr two, two_inv, omega_inv;
     ofr_from_u64(f, &two, 2);
@@ -1122,7 +1208,7 @@ int o_fri_commit(const ofield *f, const ofr *lde_values, size_t n, size_t lde_fa
         fold_ctx fc = {f, values, next, omegas_inv, next_size, (size_t)1 << i, challenge, two_inv};
         worker_scope(cpus, next_size, fold_chunk, &fc);                  /* :70-104 */
         uint8_t *nodes = (uint8_t *)malloc(next_size * 32);
-        if (next_size >= 2) o_iop_create(next, next_size, nodes, cpus);  /* :106 */
+        if (next_size >= min_tree) tree_create(combiner, next, next_size, nodes, cpus);  /* :106 */
         else { free(nodes); free(next); o_fri_free(p); free(roots); free(omegas_inv); return -1; }
         memcpy(roots[i], nodes + 32, 32);
         o_interpret_hash(f, nodes + 32, &challenge);

@@ -116,6 +116,23 @@ size_t o_iop_path(const uint8_t *nodes, const ofr *leafs, size_t n, size_t tree_
 int  o_iop_verify(const uint8_t root[32], const ofr *leaf, const uint8_t *path, size_t path_len,
                   size_t tree_index);                                   /* :236-249 */
 
+/* ---- coset combining (README.md:46 "Proof size optimization with coset combining", unchecked there; the seam
+ * is the CosetCombiner trait, src/iop/mod.rs:22-34, whose only instance is TrivialCombiner,
+ * src/iop/trivial_coset_combiner.rs:17-53).  COSET2 = a size-2 combiner as an opt-in tree format DEFINED BY THIS
+ * BUILD (the reference has none to be compared with):
+ *   natural index i of n values  <->  tree element index t = 2 (i mod n/2) + (i div n/2)   (natural_index_into_tree_index)
+ *   leaf k (k < n/2) = the 64 bytes  value[k] || value[k + n/2]  — the coset FRI opens together
+ *   (get_coset_for_natural_index :29-35, src/fri/query_producer.rs:27-34), hashed with ONE keyed BLAKE2s call;
+ *   nodes: the heap array of a tree over n/2 leaves, (n/2) x 32 bytes, root nodes[1]; path: log2(n) - 1 digests.
+ * n >= 4 (at least two leaves). */
+enum { O_COMBINER_TRIVIAL = 0, O_COMBINER_COSET2 = 1 };
+void o_hash_leaf_pair(uint8_t out[32], const ofr *lo, const ofr *hi);
+int  o_iop_create_coset2(const ofr *values, size_t n, uint8_t *nodes /* (n/2)*32 */, uint32_t cpus);
+size_t o_iop_path_coset2(const uint8_t *nodes, const ofr *values, size_t n, size_t natural_index,
+                         uint8_t *path /* (log2(n)-1)*32 */);
+int  o_iop_verify_coset2(const uint8_t root[32], const ofr *lo, const ofr *hi, const uint8_t *path,
+                         size_t path_len, size_t leaf_index);
+
 /* ---- FRI commit phase (src/fri/fri_on_values.rs:11-159) ---- */
 typedef struct {
     size_t num_steps;
@@ -130,6 +147,10 @@ typedef struct {
 } ofri_proto;
 int  o_fri_commit(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
                   size_t out_deg_plus_one, uint32_t cpus, ofri_proto **out);
+/* the same commit phase with every oracle (l0 and intermediates) built by `combiner`; the trees of a COSET2
+ * prototype hold (size/2)*32 bytes.  Every committed vector needs >= 4 values (lde_factor * out_deg >= 4). */
+int  o_fri_commit_combined(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
+                           size_t out_deg_plus_one, int combiner, uint32_t cpus, ofri_proto **out);
 void o_fri_free(ofri_proto *p);
 /* canonical prototype encoding (defined by this build, the reference has none — SURVEY F10):
  * u64le num_steps | roots[num_steps+1] (l0 + intermediates, 32 B each) | challenges[num_steps]

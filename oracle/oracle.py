@@ -344,14 +344,44 @@ class Oracle:
         return bool(self.L.o_iop_verify(bytes(root), C.byref(x), path.ctypes.data_as(C.c_void_p),
                                         C.c_size_t(len(path)), C.c_size_t(tree_index)))
 
+    # ---- COSET2 combiner (opt-in tree format, hodor_oracle.h)
+    def hash_leaf_pair(self, lo_mont, hi_mont):
+        out = (C.c_uint8 * 32)()
+        a, b = self.fr(lo_mont), self.fr(hi_mont)
+        self.L.o_hash_leaf_pair(out, C.byref(a), C.byref(b))
+        return bytes(out)
+
+    def iop_create_coset2(self, values, cpus=None):
+        n = len(values)
+        nodes = np.zeros((n // 2, 32), dtype=np.uint8)
+        rc = self.L.o_iop_create_coset2(_ptr(values), C.c_size_t(n), nodes.ctypes.data_as(C.c_void_p),
+                                        C.c_uint32(cpus or self.cpus))
+        if rc != 0:
+            raise ValueError("o_iop_create_coset2 failed")
+        return nodes
+
+    def iop_path_coset2(self, nodes, values, natural_index):
+        n = len(values)
+        path = np.zeros((max(1, n.bit_length() - 2), 32), dtype=np.uint8)
+        self.L.o_iop_path_coset2.restype = C.c_size_t
+        cnt = self.L.o_iop_path_coset2(nodes.ctypes.data_as(C.c_void_p), _ptr(values), C.c_size_t(n),
+                                       C.c_size_t(natural_index), path.ctypes.data_as(C.c_void_p))
+        return path[:cnt]
+
+    def iop_verify_coset2(self, root, lo_mont, hi_mont, path, leaf_index):
+        a, b = self.fr(lo_mont), self.fr(hi_mont)
+        path = np.ascontiguousarray(path)
+        return bool(self.L.o_iop_verify_coset2(bytes(root), C.byref(a), C.byref(b), path.ctypes.data_as(C.c_void_p),
+                                               C.c_size_t(len(path)), C.c_size_t(leaf_index)))
+
     # ---- FRI
-    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, cpus=None):
+    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, cpus=None, combiner=0):
         """Returns dict(serialized=bytes, roots, challenges (Montgomery ints), final_root,
-        final_coeffs (n,4), inter_values [arrays])."""
+        final_coeffs (n,4), inter_values [arrays]).  combiner: 0 TRIVIAL (the reference's), 1 COSET2."""
         pp = C.POINTER(OFriProto)()
-        rc = self.L.o_fri_commit(C.byref(self.f), _ptr(lde_values), C.c_size_t(len(lde_values)),
-                                 C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one),
-                                 C.c_uint32(cpus or self.cpus), C.byref(pp))
+        rc = self.L.o_fri_commit_combined(C.byref(self.f), _ptr(lde_values), C.c_size_t(len(lde_values)),
+                                          C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.c_int(combiner),
+                                          C.c_uint32(cpus or self.cpus), C.byref(pp))
         if rc != 0:
             raise ValueError("o_fri_commit failed")
         p = pp.contents

@@ -206,8 +206,70 @@ def iop_verify(root, leaf_mont, path, tree_index):
     return h == root
 
 
+# ------------------------------------------------------------------ COSET2 combiner (opt-in tree format of this build)
+# README.md:46 "Proof size optimization with coset combining" (unchecked in the reference); the seam is the
+# CosetCombiner trait (src/iop/mod.rs:22-34, only instance src/iop/trivial_coset_combiner.rs:17-53).
+TRIVIAL, COSET2 = 0, 1
+
+
+def coset2_natural_to_tree(i, n):
+    """natural_index_into_tree_index: the two members of a coset {k, k + n/2} become neighbours 2k, 2k + 1."""
+    return 2 * (i % (n // 2)) + i // (n // 2)
+
+
+def coset2_tree_to_natural(t, n):
+    return (t >> 1) + (t & 1) * (n // 2)
+
+
+def hash_leaf_pair(lo_mont, hi_mont):
+    return b2s(mont_to_bytes(lo_mont) + mont_to_bytes(hi_mont))
+
+
+def iop_create_coset2(values_mont):
+    """Tree over the n/2 combined leaves (value[k] || value[k + n/2]); heap array of n/2 digests."""
+    n = len(values_mont)
+    assert n >= 4 and n & (n - 1) == 0
+    L = n // 2
+    lh = [hash_leaf_pair(values_mont[k], values_mont[k + L]) for k in range(L)]
+    nodes = [b"\x00" * 32] * L
+    for i in range(L // 2):
+        nodes[L // 2 + i] = hash_node(lh[2 * i], lh[2 * i + 1])
+    w = L // 4
+    while w >= 1:
+        for i in range(w):
+            nodes[w + i] = hash_node(nodes[2 * (w + i)], nodes[2 * (w + i) + 1])
+        w //= 2
+    return nodes
+
+
+def iop_path_coset2(nodes, values_mont, natural_index):
+    n = len(values_mont)
+    L = n // 2
+    k = natural_index % L
+    path = [hash_leaf_pair(values_mont[k ^ 1], values_mont[(k ^ 1) + L])]
+    idx, w = k >> 1, L // 2
+    while w >= 2:
+        path.append(nodes[w + (idx ^ 1)])
+        idx >>= 1
+        w //= 2
+    return path
+
+
+def iop_verify_coset2(root, lo_mont, hi_mont, path, leaf_index):
+    h = hash_leaf_pair(lo_mont, hi_mont)
+    idx = leaf_index
+    for el in path:
+        h = hash_node(h, el) if idx & 1 == 0 else hash_node(el, h)
+        idx >>= 1
+    return h == root
+
+
+def _tree(combiner, mont):
+    return iop_create_coset2(mont) if combiner == COSET2 else iop_create(mont)
+
+
 # ------------------------------------------------------------------ FRI commit (by values)
-def fri_commit(F, lde_values, lde_factor, out_deg_plus_one):
+def fri_commit(F, lde_values, lde_factor, out_deg_plus_one, combiner=TRIVIAL):
     """src/fri/fri_on_values.rs:11-159. lde_values canonical ints.
     Returns dict(roots=[l0 + intermediates], challenges, final_root, final_coeffs, inter_values)."""
     p = F.p
@@ -217,7 +279,7 @@ def fri_commit(F, lde_values, lde_factor, out_deg_plus_one):
     two_inv = pow(2, -1, p)
     num_steps = ((n // lde_factor) // out_deg_plus_one).bit_length() - 1
     assert num_steps >= 1
-    nodes = iop_create([F.to_mont(v) for v in lde_values])
+    nodes = _tree(combiner, [F.to_mont(v) for v in lde_values])
     roots = [nodes[1]]
     challenge = interpret_hash(F, nodes[1])
     challenges = [challenge]
@@ -232,7 +294,7 @@ def fri_commit(F, lde_values, lde_factor, out_deg_plus_one):
             even = (a + b) % p
             odd = (a - b) * pow(omega_inv, idx * stride, p) % p
             nxt.append((odd * challenge + even) * two_inv % p)
-        nodes = iop_create([F.to_mont(v) for v in nxt])
+        nodes = _tree(combiner, [F.to_mont(v) for v in nxt])
         roots.append(nodes[1])
         challenge = interpret_hash(F, nodes[1])
         challenges.append(challenge)
@@ -298,18 +360,23 @@ def bytes_to_challenge_index(b, lde_size, lde_factor):
 
 
 # ------------------------------------------------------------------ FRI query phase
-def fri_produce_proof(F, proto, lde_values, natural_first_element_index, lde_factor, out_deg_plus_one):
+def fri_produce_proof(F, proto, lde_values, natural_first_element_index, lde_factor, out_deg_plus_one,
+                      combiner=TRIVIAL):
     """FRIProofPrototype::produce_proof, src/fri/query_producer.rs:10-53: for the l0 oracle and each
     intermediate one, the two queries of the (sorted) coset of domain_idx; the index halves with the
     domain.  `proto` = fri_commit(...) output, `lde_values` canonical ints.  Values are returned in
-    Montgomery form (the leaf bytes), like the device path does."""
+    Montgomery form (the leaf bytes), like the device path does.
+    COSET2: ONE query per round — (coset[0], (value[coset[0]], value[coset[1]]), path of log2(size) - 1 digests)."""
     domain_size, domain_idx = len(lde_values), natural_first_element_index
     queries, roots = [], []
     for r, vec in enumerate([lde_values] + proto["inter_values"]):
         leafs = [F.to_mont(v) for v in vec]
-        nodes = iop_create(leafs)
+        nodes = _tree(combiner, leafs)
         pair = (domain_idx + domain_size // 2) % domain_size
-        for idx in sorted([domain_idx, pair]):
+        if combiner == COSET2:
+            lo, hi = sorted([domain_idx, pair])
+            queries.append((lo, (leafs[lo], leafs[hi]), iop_path_coset2(nodes, leafs, lo)))
+        for idx in sorted([domain_idx, pair]) if combiner == TRIVIAL else []:
             queries.append((idx, leafs[idx], iop_path(nodes, leafs, idx)))
         roots.append(nodes[1])
         nxt = domain_size // 2
@@ -321,11 +388,13 @@ def fri_produce_proof(F, proto, lde_values, natural_first_element_index, lde_fac
 
 
 def fri_proof_to_bytes(proof):
-    """The FRIProof wire format this build defines (hodor_amd/csrc/abi_fri.hip, hodor_fri_produce_proof)."""
+    """The FRIProof wire format this build defines (hodor_amd/csrc/abi_fri.hip, hodor_fri_produce_proof); a COSET2
+    query carries both values of its coset (64 bytes) where a TRIVIAL one carries one."""
     u64 = lambda v: int(v).to_bytes(8, "little")
     out = u64(len(proof["queries"]))
     for idx, value, path in proof["queries"]:
-        out += u64(idx) + mont_to_bytes(value) + u64(len(path)) + b"".join(bytes(x) for x in path)
+        vb = b"".join(mont_to_bytes(v) for v in value) if isinstance(value, tuple) else mont_to_bytes(value)
+        out += u64(idx) + vb + u64(len(path)) + b"".join(bytes(x) for x in path)
     out += u64(len(proof["roots"])) + b"".join(bytes(r) for r in proof["roots"])
     out += u64(len(proof["final_coeffs"])) + b"".join(mont_to_bytes(c) for c in proof["final_coeffs"])
     out += u64(proof["initial_degree_plus_one"]) + u64(proof["output_coeffs_at_degree_plus_one"])
@@ -334,6 +403,57 @@ def fri_proof_to_bytes(proof):
 
 
 # ------------------------------------------------------------------ FRI verifier (acceptance oracle)
+def fri_verify_proof_queries_coset2(F, proof, natural_element_index, expected_value_from_oracle):
+    """verify_proof_queries (src/fri/verifier.rs:131-289) for COSET2 proofs: the same walk, with the two values of a
+    round arriving in ONE query that is checked against the root with ONE path."""
+    p = F.p
+    two_inv = pow(2, -1, p)
+    size = proof["initial_degree_plus_one"] * proof["lde_factor"]
+    omega, _, size = F.domain_generator(size)
+    x = pow(omega, natural_element_index, p)
+    if pow(x, size, p) != 1 or pow(x, size // 2, p) == 1:
+        raise ValueError("initial challenge value is not in the LDE domain")
+    omega_inv = pow(omega, -1, p)
+    expected = None
+    domain_size, domain_idx = size, natural_element_index
+    for rnd, (root, q) in enumerate(zip(proof["roots"], proof["queries"])):
+        if domain_size < 4:
+            raise ValueError("domain too small for a combined leaf")
+        pair = (domain_idx + domain_size // 2) % domain_size
+        coset = sorted([domain_idx, pair])
+        if q[0] not in coset:
+            return False
+        if q[0] != coset[0]:
+            raise ValueError("invalid tree index")
+        lo, hi = q[1]
+        supplied = lo if domain_idx == coset[0] else hi
+        if rnd == 0 and supplied != expected_value_from_oracle:
+            return False
+        if not iop_verify_coset2(root, lo, hi, q[2], coset[0]):
+            return False
+        challenge = interpret_hash(F, root)
+        if expected is not None and F.from_mont(supplied) != expected:
+            return False
+        f_at_omega, f_at_minus_omega = F.from_mont(lo), F.from_mont(hi)
+        divisor = pow(omega_inv, coset[0], p)
+        even = (f_at_omega + f_at_minus_omega) % p
+        odd = (f_at_omega - f_at_minus_omega) * divisor % p
+        expected = (odd * challenge + even) * two_inv % p
+        nxt = domain_size // 2
+        domain_idx = domain_idx if domain_idx < nxt else domain_idx - nxt
+        domain_size = nxt
+        omega = omega * omega % p
+        omega_inv = omega_inv * omega_inv % p
+    if expected is None:
+        raise ValueError("is some")
+    point = pow(omega, domain_idx, p)
+    acc, power = 0, 1
+    for c in proof["final_coeffs"]:
+        acc = (acc + power * F.from_mont(c)) % p
+        power = power * point % p
+    return acc == expected
+
+
 def fri_verify_proof_queries(F, proof, natural_element_index, expected_value_from_oracle, degree=2):
     """NaiveFriIop::verify_proof_queries, src/fri/verifier.rs:131-289, restated line for line.
     `proof`: dict(queries=[(natural_index, value_mont, [path digests])], roots=[bytes], final_coeffs=[mont],

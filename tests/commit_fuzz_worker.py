@@ -22,6 +22,8 @@ def main():
         n = 1 << lg
         a = O.random_elements(n, 5000 + lg)
         assert np.array_equal(ctx.iop_create(a), O.iop_create(a)), ("tree", lg)
+        if lg >= 2:   # the COSET2 format (combined leaf launch) under the same schedule knobs
+            assert np.array_equal(ctx.iop_create_combined(a, hodor_amd.COSET2), O.iop_create_coset2(a)), ("coset2 tree", lg)
         inv = a.copy()
         O.poly_batch_inversion(inv)
         d = torch.from_numpy(a.view(np.int64)).cuda()
@@ -36,6 +38,11 @@ def main():
                 got = proto.serialized
                 proto.free()
                 assert got == want, ("fri commit", lg, factor, out_deg)
+                want = O.fri_commit(code, factor, out_deg, combiner=1)["serialized"]
+                proto = ctx.fri_commit(code, factor, out_deg, combiner=hodor_amd.COSET2)
+                got = proto.serialized
+                proto.free()
+                assert got == want, ("coset2 fri commit", lg, factor, out_deg)
     print("COMMIT-FUZZ-OK")
 
 

@@ -183,10 +183,30 @@ def test_strict_fri_verifier_refuses_truncated_and_reshaped_proofs():
     raw = P.fri_proof_to_bytes(proof)
     expected = F.to_mont(lde[index])
     assert ctx.fri_verify_proof(raw, index, expected) is True
-    assert ctx.fri_verify_proof_strict(raw, n, index, expected) is True
-    assert ctx.fri_verify_proof_strict(raw, n, index, expected ^ 1) is False
-    assert ctx.fri_verify_proof_strict(raw, 2 * n, index, expected) is False       # not the domain the caller expects
-    assert ctx.fri_verify_proof_strict(raw, n // 2, index % (n // 2), expected) is False
+    assert ctx.fri_verify_proof_strict(raw, n, f, 1, index, expected) is True
+    assert ctx.fri_verify_proof_strict(raw, n, f, 1, index, expected ^ 1) is False
+    assert ctx.fri_verify_proof_strict(raw, 2 * n, f, 1, index, expected) is False       # not the domain the caller expects
+    assert ctx.fri_verify_proof_strict(raw, n // 2, f, 1, index % (n // 2), expected) is False
+    assert ctx.fri_verify_proof_strict(raw, n, 2 * f, 1, index, expected) is False       # not the rate the caller expects
+    assert ctx.fri_verify_proof_strict(raw, n, f, 2, index, expected) is False           # not the degree bound
+    with pytest.raises(_lib.HodorError):                                                   # not the format: malformed
+        ctx.fri_verify_proof_strict(raw, n, f, 1, index, expected, combiner=hodor_amd.COSET2)
+
+    # 0. the rate forgery (round-3 advisor finding): the reference's walk takes lde_factor / initial_degree_plus_one from
+    # the proof, so a prover may commit to a polynomial of TWICE the allowed degree over the same domain and encode
+    # {degree 2d, factor f/2}: every shape check that reads its parameters from the proof passes and the reference's
+    # walk accepts; the strict verifier, which is told the rate by its caller, refuses.
+    fat = P.poly_lde(F, [pow(3, 1000 + 7 * i * i, F.p) for i in range(2 << log_deg)], f // 2)
+    assert len(fat) == n
+    gproto = P.fri_commit(F, fat, f // 2, 1)
+    gproof = P.fri_produce_proof(F, gproto, fat, index, f // 2, 1)
+    graw = P.fri_proof_to_bytes(gproof)
+    gexp = F.to_mont(fat[index])
+    assert gproof["lde_factor"] == f // 2 and gproof["initial_degree_plus_one"] == 2 * n // f
+    assert P.fri_verify_proof_queries(F, gproof, index, gexp) is True
+    assert ctx.fri_verify_proof(graw, index, gexp) is True                               # reference-faithful: accepted
+    assert ctx.fri_verify_proof_strict(graw, n, f, 1, index, gexp) is False              # strict: the caller's rate binds
+    assert ctx.fri_verify_proof_strict(graw, n, f // 2, 1, index, gexp) is True          # (a caller who ASKS for that rate gets it)
 
     def variant(mut):
         bad = dict(proof, queries=list(proof["queries"]), roots=list(proof["roots"]),
@@ -209,7 +229,7 @@ def test_strict_fri_verifier_refuses_truncated_and_reshaped_proofs():
     assert P.fri_verify_proof_queries(F, dict(proof, queries=proof["queries"][:4], roots=proof["roots"][:2],
                                               final_coeffs=folded), index, expected) is True
     assert ctx.fri_verify_proof(cut, index, expected) is True                       # reference-faithful: accepted
-    assert ctx.fri_verify_proof_strict(cut, n, index, expected) is False            # strict: refused
+    assert ctx.fri_verify_proof_strict(cut, n, f, 1, index, expected) is False            # strict: refused
     # 2. the pure shape attacks: fewer rounds, extra final coefficients, a shortened path
     def drop_last_round(b):
         b["queries"] = b["queries"][:-2]
@@ -217,12 +237,12 @@ def test_strict_fri_verifier_refuses_truncated_and_reshaped_proofs():
     def extra_final(b): b["final_coeffs"] = b["final_coeffs"] + [0]
     def short_path(b): q = b["queries"][0]; b["queries"][0] = (q[0], q[1], list(q[2][:-1]))
     for mut in (drop_last_round, extra_final, short_path):
-        assert ctx.fri_verify_proof_strict(variant(mut), n, index, expected) is False
+        assert ctx.fri_verify_proof_strict(variant(mut), n, f, 1, index, expected) is False
     for cutlen in (0, 9, len(raw) - 1):
         with pytest.raises(_lib.HodorError):
-            ctx.fri_verify_proof_strict(raw[:cutlen] if cutlen else b"\x00", n, index, expected)
+            ctx.fri_verify_proof_strict(raw[:cutlen] if cutlen else b"\x00", n, f, 1, index, expected)
     with pytest.raises(_lib.HodorError):
-        ctx.fri_verify_proof_strict(raw, n, n, expected)                              # index outside the domain
+        ctx.fri_verify_proof_strict(raw, n, f, 1, n, expected)                              # index outside the domain
     ctx.close()
 
 

@@ -27,9 +27,10 @@ def test_prove_shaped_run_is_byte_identical_to_the_cpu_port(gpu_ctxs, oracles, l
     # ... and the proof VERIFIES: both FRI proofs under the strict verifier (shape bound to the domain, every Merkle path,
     # every fold, the final polynomial) and under the restated reference verifier; every oracle query against its root
     for raw, size, x, value in ps.prove.last["fri"]:
-        assert ctx.fri_verify_proof_strict(raw, size, x, value) is True
+        assert ctx.fri_verify_proof_strict(raw, size, lde_factor, 1, x, value) is True
         assert ctx.fri_verify_proof(raw, x, value) is True
-        assert ctx.fri_verify_proof_strict(raw, size, x, value ^ 1) is False
+        assert ctx.fri_verify_proof_strict(raw, size, lde_factor, 1, x, value ^ 1) is False
+        assert ctx.fri_verify_proof_strict(raw, size, lde_factor // 2, 1, x, value) is False   # the caller's rate binds
     for root, x, (value, path) in ps.prove.last["queries"]:
         assert ctx.iop_verify(root, value, path, x) is True
         assert O.iop_verify(root, value, path, x) is True
