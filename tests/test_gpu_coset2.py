@@ -158,7 +158,7 @@ def test_coset2_gpu_directly_against_python_fixtures(gpu_ctxs, field_name):
     assert seen == {"merkle", "fri"}
 
 
-@pytest.mark.parametrize("log_deg,lde_factor,out_deg,index", [(3, 4, 1, 5), (8, 8, 2, 777), (12, 8, 1, 31000), (14, 4, 1, 65535)])
+@pytest.mark.parametrize("log_deg,lde_factor,out_deg,index", [(3, 4, 1, 5), (8, 8, 2, 777), (12, 8, 1, 31001), (14, 4, 1, 65535)])
 def test_coset2_produce_proof(gpu_ctxs, oracles, log_deg, lde_factor, out_deg, index):
     """produce_proof on a device-resident COSET2 prototype: ONE query per round with both values of the coset and the
     combined leaf's path; bytes equal to the Python restatement's; half the paths of the TRIVIAL proof."""
