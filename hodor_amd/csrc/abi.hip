@@ -156,15 +156,33 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     t.log_n = log_n;
     t.log_r = log_r;
     uint64_t cnt = log_r ? (1ull << (log_r - 1)) : 1;
-    HIPCHK(hipMalloc((void **)&t.rtw, cnt * 112));
-    HIPCHK(pow_table_w3_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt,
-                               ctx->K3, ctx->P));
+    t.rtw = nullptr;
     t.rtw9 = nullptr;
+    // an error below must not leak what has been allocated so far: the entry is not in the cache yet, so nothing
+    // else (trim_table_cache, hodor_ctx_destroy) would ever free it
+    auto fail = [&](hipError_t e, const char *what) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        if (t.rtw) (void)hipFree(t.rtw);
+        if (t.rtw9) (void)hipFree(t.rtw9);
+        set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
+        return HODOR_ERR_DEVICE;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&t.rtw, cnt * 112)) != hipSuccess) return fail(e, "radix table (hipMalloc)");
+    if ((e = pow_table_w3_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt, ctx->K3,
+                                 ctx->P)) != hipSuccess)
+        return fail(e, "radix table (k_pow_table_w3)");
     if (log_r >= 6) {   // the 16 powers omega_R^(e R/32) = omega^(e << (log_n - 5)) the wave-uniform steps use
-        HIPCHK(hipMalloc((void **)&t.rtw9, 16 * W9_WORDS * sizeof(uint32_t)));
-        HIPCHK(pow_table_w9_launch(ctx->stream, t.rtw9, to_dev(omega), log_n - 5, 16, ctx->K9, ctx->P));
+        if ((e = hipMalloc((void **)&t.rtw9, 16 * W9_WORDS * sizeof(uint32_t))) != hipSuccess ||
+            (e = pow_table_w9_launch(ctx->stream, t.rtw9, to_dev(omega), log_n - 5, 16, ctx->K9, ctx->P)) != hipSuccess) {
+            // the W9 table is an optimisation: without it the pass takes the W3 path for every step
+            (void)hipGetLastError();
+            if (t.rtw9) (void)hipFree(t.rtw9);
+            t.rtw9 = nullptr;
+        }
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "radix table (synchronize)");
     ctx->radix_tables.push_back(t);
     *out = t.rtw;
     *out9 = t.rtw9;
@@ -473,6 +491,13 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
 extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->live_exchanges.load() != 0) {
+        // a hodor_exchange keeps a pointer to its context (error reporting, device): destroying the context under it
+        // would leave that pointer dangling.  Refuse — the handle stays valid, the caller destroys the exchanges
+        // first (header: "Destroy the handle before its context") and calls again.
+        set_err(ctx, "hodor_ctx_destroy: exchanges created on this context are still alive; destroy them first");
+        return;
+    }
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();

@@ -37,6 +37,9 @@ struct Rccl {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllToAll) AllToAll = nullptr;   // RCCL's own entry point (absent from NCCL proper): optional
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;   // optional: the device an adopted communicator lives on
+    decltype(&ncclCommCount) CommCount = nullptr;         // optional
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;   // optional
     std::string why;
     bool ok = false;
 };
@@ -70,6 +73,9 @@ const Rccl &rccl()
         BIND(Recv, ncclRecv)
 #undef BIND
         r.AllToAll = reinterpret_cast<decltype(r.AllToAll)>(dlsym(r.lib, "ncclAllToAll"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.lib, "ncclCommCuDevice"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
         r.ok = true;
         return r;
     }();
@@ -89,6 +95,7 @@ struct hodor_exchange {
     static constexpr uint64_t RING = 64;
     hipEvent_t done[RING] = {};     // done[t % RING]: recorded on comm_stream after exchange number t (tickets start at 1)
     uint64_t issued = 0;            // number of exchanges enqueued so far = the latest ticket
+    bool counted = false;           // registered in ctx->live_exchanges (hodor_ctx_destroy refuses while any is alive)
     std::mutex mu;
 };
 
@@ -134,6 +141,8 @@ static int exchange_finish(hodor_ctx *ctx, hodor_exchange *x, hodor_exchange **o
             hodor_exchange_destroy(x);
             return HODOR_ERR_DEVICE;
         }
+    ctx->live_exchanges.fetch_add(1);
+    x->counted = true;
     *out = x;
     return HODOR_OK;
 }
@@ -173,6 +182,24 @@ extern "C" int hodor_exchange_adopt(hodor_ctx *ctx, void *nccl_comm, uint32_t n_
     if (!nccl_comm || !out) return HODOR_ERR_INVALID;
     if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || rank >= n_ranks) return HODOR_ERR_SIZE;
     if (!rccl().ok) { set_err(ctx, rccl().why); return HODOR_ERR_DEVICE; }
+    // the adopted communicator must be the one the caller describes: on the context's device, n_ranks wide, this rank
+    {
+        const Rccl &R = rccl();
+        int dev = -1, cnt = -1, me = -1;
+        if (R.CommCuDevice && R.CommCuDevice((ncclComm_t)nccl_comm, &dev) == ncclSuccess && dev != ctx->device) {
+            set_err(ctx, "exchange_adopt: the communicator lives on device " + std::to_string(dev) +
+                             ", the context on device " + std::to_string(ctx->device));
+            return HODOR_ERR_INVALID;
+        }
+        if (R.CommCount && R.CommCount((ncclComm_t)nccl_comm, &cnt) == ncclSuccess && cnt != (int)n_ranks) {
+            set_err(ctx, "exchange_adopt: the communicator has " + std::to_string(cnt) + " ranks, not " + std::to_string(n_ranks));
+            return HODOR_ERR_SIZE;
+        }
+        if (R.CommUserRank && R.CommUserRank((ncclComm_t)nccl_comm, &me) == ncclSuccess && me != (int)rank) {
+            set_err(ctx, "exchange_adopt: this is rank " + std::to_string(me) + " of the communicator, not " + std::to_string(rank));
+            return HODOR_ERR_SIZE;
+        }
+    }
     hodor_exchange *x = new (std::nothrow) hodor_exchange();
     if (!x) return HODOR_ERR_INVALID;
     x->ctx = ctx;
@@ -193,6 +220,7 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
     for (uint64_t i = 0; i < hodor_exchange::RING; i++)
         if (x->done[i]) (void)hipEventDestroy(x->done[i]);
     if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+    if (x->counted && x->ctx) x->ctx->live_exchanges.fetch_sub(1);
     delete x;
 }
 

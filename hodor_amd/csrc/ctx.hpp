@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
@@ -162,6 +163,7 @@ struct hodor_ctx {
     IoLane lanes[IO_LANES];
     std::mutex lane_mu;
     std::condition_variable lane_cv;
+    std::atomic<int> live_exchanges{0};   // hodor_exchange handles that point at this context (abi_exchange.hip)
     void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
     size_t fri_slab_bytes = 0;
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X

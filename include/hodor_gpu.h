@@ -55,7 +55,8 @@ typedef struct {
  * two 4-limb fields have 255 and 252 bits). */
 int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
 /* Destroy after every prototype obtained from this context has been freed (hodor_fri_free hands the
- * prototype's device slab back to its context) and no call on it is in flight. */
+ * prototype's device slab back to its context), every hodor_exchange created on it has been destroyed (the call
+ * is refused otherwise: the context stays alive) and no call on it is in flight. */
 void hodor_ctx_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
@@ -323,11 +324,15 @@ int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor
  *   hodor_exchange_unique_id   ncclGetUniqueId: ONE rank calls it and hands the 128 opaque bytes to its peers by any
  *                              channel it has (a file, a socket, MPI)
  *   hodor_exchange_create      ncclCommInitRank on the context's device — collective: every rank calls it with the same
- *                              id; n_ranks a power of two.  The handle owns the communicator, a communication stream
- *                              and two events.  hodor_exchange_adopt wraps a communicator (ncclComm_t) the caller owns.
+ *                              id; n_ranks a power of two.  The handle owns the communicator, a highest-priority
+ *                              communication stream and 1 + 64 events (one "produced" event and a ring of completion
+ *                              events, one per ticket).  hodor_exchange_adopt wraps a communicator (ncclComm_t) the
+ *                              caller owns; it must live on the context's device and have n_ranks ranks of which
+ *                              this is `rank` (checked where the library exposes ncclCommCuDevice / Count / UserRank).
  *   hodor_sixstep_exchange_dev chunk `chunk` of 2^log_chunks (elements [chunk*n_local/K, (chunk+1)*n_local/K) of both
  *                              buffers, P slabs each: slab t of the send piece -> rank t, slab s of the receive piece
- *                              <- rank s) as grouped ncclSend/ncclRecv on the handle's communication stream, ordered
+ *                              <- rank s) as RCCL's all-to-all (ncclAllToAll; grouped ncclSend/ncclRecv where the
+ *                              library lacks it) on the handle's communication stream, ordered
  *                              AFTER everything enqueued on `stream` so far; `stream` does not wait, so the next chunk's
  *                              arithmetic overlaps the wire time; *ticket (may be NULL) numbers the exchange
  *   hodor_sixstep_exchange_wait_dev  `stream` waits for the exchange with that ticket and every earlier one (0: all
@@ -335,7 +340,8 @@ int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor
  *                              hodor_sixstep_rows_dev / _columns_dev; two transforms in flight on one handle wait for
  *                              their own exchanges only.  Send and receive buffers must stay alive and untouched
  *                              between the two calls.
- * Destroy the handle before its context. */
+ * Destroy the handle before its context: the handle keeps a pointer to it, and hodor_ctx_destroy REFUSES (leaves the
+ * context alive, sets hodor_last_error) while exchanges created on it exist. */
 typedef struct hodor_exchange hodor_exchange;
 #define HODOR_EXCHANGE_ID_BYTES 128
 int  hodor_exchange_available(void);

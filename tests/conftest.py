@@ -40,3 +40,25 @@ def gpu_ctxs():
     yield ctxs
     for c in ctxs.values():
         c.close()
+
+
+def need_hbm(bytes_needed, what):
+    """Flagship-size GPU tests must not turn into an unread `s`: free the caching allocator and retry once; skip only on
+    a part whose TOTAL memory cannot hold the case (an MI355X has 288 GB), FAIL when a big-enough part is merely full."""
+    import gc
+
+    import torch
+    for _ in range(2):
+        free, total = torch.cuda.mem_get_info()
+        if free >= bytes_needed:
+            return
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+    free, total = torch.cuda.mem_get_info()
+    if free >= bytes_needed:
+        return
+    if total < bytes_needed * 1.1:
+        pytest.skip("%s: the device has %.0f GiB in total, the case needs %.0f GiB" % (what, total / 2**30, bytes_needed / 2**30))
+    pytest.fail("%s: only %.0f of %.0f GiB of HBM are free (needs %.0f GiB) after emptying the allocator cache — "
+                "something earlier in the run holds device memory" % (what, free / 2**30, total / 2**30, bytes_needed / 2**30))

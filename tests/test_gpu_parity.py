@@ -941,9 +941,8 @@ def test_maximum_single_gpu_sizes(gpu_ctxs, oracles, log_n):
     from gpu_inputs import random_elements
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     n = 1 << log_n
-    free, _ = torch.cuda.mem_get_info()
-    if free < 3.4 * n * 32:
-        pytest.skip("not enough free HBM for 2^%d" % log_n)
+    from conftest import need_hbm
+    need_hbm(3.4 * n * 32, "single-device transform of 2^%d points" % log_n)
     a = random_elements(torch, n, 1000 + log_n)
     b = torch.empty_like(a)
     ctx.poly_fft_dev(a, b, log_n)

@@ -24,6 +24,13 @@ SETTINGS = [
     ({"HODOR_MAX_LOG_R": "10", "HODOR_TILE_LOG": "10", "HODOR_MIN_LOG_C": "0", "HODOR_TW_HI_MAX_LOG": "0"}, "10,13,15"),
     ({"HODOR_MAX_LOG_R": "11", "HODOR_TILE_LOG": "11", "HODOR_TW_HI_MAX_LOG": "20"}, "11,12,14,17"),
     ({"HODOR_MAX_LOG_R": "11", "HODOR_TILE_LOG": "11", "HODOR_MIN_LOG_C": "2", "HODOR_NTT_THREADS": "128"}, "11,12,16"),
+    # the wave-uniform W9 steps off / on without the skipped products, the generic Montgomery digit (HODOR_NTT_P1 = 0:
+    # the v_mul_lo path every modulus that is not 1 mod 2^29 takes), and a workgroup size that is not a multiple of 64
+    # (rounded down to whole waves by the launcher: the W9 steps deal their work per wave)
+    ({"HODOR_NTT_W9": "0"}, "8,9,16,17", "16:2:1"),
+    ({"HODOR_NTT_W9": "1", "HODOR_NTT_P1": "0"}, "8,9,16,17", "16:4:1"),
+    ({"HODOR_NTT_THREADS": "96", "HODOR_MAX_LOG_R": "8"}, "8,12,16"),
+    ({"HODOR_NTT_THREADS": "200", "HODOR_NTT_P1": "0"}, "9,13,17"),
 ]
 
 

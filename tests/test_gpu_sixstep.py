@@ -229,10 +229,8 @@ def test_config4_2_30_points_over_8_ranks_at_full_size(gpu_ctxs, oracles):
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     log_n = 30
     n = 1 << log_n
-    torch.cuda.empty_cache()
-    free, _ = torch.cuda.mem_get_info()
-    if free < 4.4 * n * 32:
-        pytest.skip("not enough free HBM for config[4] on one device (needs ~140 GiB)")
+    from conftest import need_hbm
+    need_hbm(4.4 * n * 32, "config[4] played on one device")     # ~140 GiB: fails (not skips) on a full 288 GB part
     checked = []
 
     def check(x, y, omega):
@@ -258,9 +256,8 @@ def test_four_step_at_world_1_with_2_16_tile_column_groups(gpu_ctxs):
     ctx = gpu_ctxs["bn256"]
     log_n = 27
     n = 1 << log_n
-    free, _ = torch.cuda.mem_get_info()
-    if free < 5.5 * n * 32:
-        pytest.skip("not enough free HBM")
+    from conftest import need_hbm
+    need_hbm(5.5 * n * 32, "4-step at world 1, 2^27 points")
     a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     ctx.gen_elements_dev(a, 0, n, FULL["ntt"]["27"]["seed"])
     w = ctx.domain(n)[2]
