@@ -833,6 +833,29 @@ def extra_lde_commit(ctx, torch, stream):
            "lde_commit_gib_per_s": alg_bytes / 2**30 / ((lde_ms + commit_ms) * 1e-3),
            "hbm_frac": alg_bytes / ((lde_ms + commit_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "root": root, "root_equals_cpu_oracle": True}
+    if "coset2_root" in fx:
+        # the same codeword committed in the COSET2 tree format (opt-in; the coset {i, i + n/2} is one 64-byte leaf):
+        # gated on the CPU oracle's committed root for that format
+        c2 = hodor_amd_COSET2()
+        nodes2 = nodes[:big // 2]
+        ctx.iop_create_combined_dev(lde, big, c2, nodes2, stream=stream)
+        torch.cuda.synchronize()
+        if bytes(nodes2[1].cpu().numpy()).hex() != fx["coset2_root"]:
+            raise SystemExit("LDE x8 + COSET2 commit: Merkle root differs from the CPU oracle's — refusing to report")
+        e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+        c2_ms = 0.0
+        for _ in range(reps):
+            ctx.poly_lde_dev(coeffs, lde, LDE_LOG_N, LDE_FACTOR, stream=stream)   # as in the leg above: the commit follows an LDE
+            e0.record()
+            ctx.iop_create_combined_dev(lde, big, c2, nodes2, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            c2_ms += e0.elapsed_time(e1)
+        c2_ms /= reps
+        alg2 = n * 32 + big * 32 + big * 16
+        out["commit_coset2"] = {"workload": "the same LDE committed with COSET2 trees (opt-in format, not the reference's bytes)",
+                                "commit_ms": c2_ms, "lde_commit_gib_per_s": alg2 / 2**30 / ((lde_ms + c2_ms) * 1e-3),
+                                "root": fx["coset2_root"], "root_equals_cpu_oracle": True}
     del lde, nodes, coeffs
     out["fri_commit"] = extra_fri_commit(ctx, torch, stream)
     out["fri_commit_coset2"] = out["fri_commit"].pop("coset2", None)

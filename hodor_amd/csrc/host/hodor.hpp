@@ -376,6 +376,76 @@ class TrivialBlake2sIOP {
     bool operator==(const TrivialBlake2sIOP &o) const { return get_root() == o.get_root(); }
 };
 
+// ---- CosetCombiner (src/iop/mod.rs:22-34) -------------------------------------------------------------------
+// TrivialCombiner is the reference's only instance (src/iop/trivial_coset_combiner.rs:17-53); Coset2Combiner is the
+// opt-in format of this build (HODOR_COMBINER_COSET2: the coset {i, i + n/2} is ONE 64-byte leaf — the README's
+// unchecked "coset combining", README.md:46).  The reference's trait maps indices without knowing the domain size;
+// a non-trivial combiner needs it, so the maps take `domain_size` here (INTEGRATION.md shows the Rust side).
+struct TrivialCombiner {
+    static constexpr int id = HODOR_COMBINER_TRIVIAL;
+    static constexpr size_t COSET_SIZE = 2, EXPECTED_DEGREE = 2;
+    static size_t tree_index_into_natural_index(size_t t, size_t) { return t; }
+    static size_t natural_index_into_tree_index(size_t i, size_t) { return i; }
+    static std::vector<size_t> get_coset_for_natural_index(size_t i, size_t n)
+    {
+        return Domain::coset_for_natural_index_and_size(i, n);
+    }
+};
+struct Coset2Combiner {
+    static constexpr int id = HODOR_COMBINER_COSET2;
+    static constexpr size_t COSET_SIZE = 2, EXPECTED_DEGREE = 2;
+    static size_t tree_index_into_natural_index(size_t t, size_t n) { return (t >> 1) + (t & 1) * (n / 2); }
+    static size_t natural_index_into_tree_index(size_t i, size_t n) { return 2 * (i % (n / 2)) + i / (n / 2); }
+    static std::vector<size_t> get_coset_for_natural_index(size_t i, size_t n)
+    {
+        return Domain::coset_for_natural_index_and_size(i, n);
+    }
+};
+
+// the IOP over a COSET2 tree: a query answers for the whole coset (both values, ONE path of log2(n) - 1 digests)
+struct Coset2Blake2sIopQuery {
+    size_t index;                 // the smaller member of the coset = the leaf index
+    Fr values_[2];                // value[index], value[index + n/2]
+    std::vector<Hash32> path_;
+    size_t natural_index() const { return index; }
+    const std::vector<Hash32> &path() const { return path_; }
+};
+class Coset2Blake2sIOP {
+  public:
+    const Field *F;
+    uint64_t size_;               // number of committed VALUES (the tree has size_/2 leaves)
+    std::vector<uint8_t> nodes;   // (size_/2) * 32, heap layout, root at [32, 64)
+    static Coset2Blake2sIOP create(const Field &F, const std::vector<Fr> &values)
+    {
+        Coset2Blake2sIOP t{&F, values.size(), std::vector<uint8_t>(values.size() * 16, 0)};
+        F.check(hodor_iop_create_combined(F.ctx(), values.data(), values.size(), HODOR_COMBINER_COSET2, t.nodes.data()),
+                "IopTree::create (COSET2)");
+        return t;
+    }
+    Hash32 get_root() const { return Hash32(nodes.begin() + 32, nodes.begin() + 64); }
+    Coset2Blake2sIopQuery query(size_t natural_index, const std::vector<Fr> &values) const
+    {
+        if (natural_index >= size_ || values.size() != size_) throw SynthesisError(HODOR_ERR_SIZE, "query index out of range");
+        const size_t half = size_ / 2, k = natural_index % half;
+        Coset2Blake2sIopQuery q{k, {values[k], values[k + half]}, {}};
+        std::vector<uint8_t> buf(32 * 64);
+        size_t cnt = 0;
+        F->check(hodor_iop_path_combined(F->ctx(), nodes.data(), values.data(), values.size(), HODOR_COMBINER_COSET2,
+                                         natural_index, buf.data(), &cnt), "get_path (COSET2)");
+        for (size_t i = 0; i < cnt; i++) q.path_.emplace_back(buf.begin() + 32 * i, buf.begin() + 32 * (i + 1));
+        return q;
+    }
+    static bool verify_query(const Field &F, const Coset2Blake2sIopQuery &q, const Hash32 &root, size_t n)
+    {
+        std::vector<uint8_t> flat;
+        for (auto &h : q.path_) flat.insert(flat.end(), h.begin(), h.end());
+        int ok = 0;
+        F.check(hodor_iop_verify_combined(F.ctx(), root.data(), q.values_, flat.data(), q.path_.size(), q.index, n,
+                                          HODOR_COMBINER_COSET2, &ok), "verify (COSET2)");
+        return ok != 0;
+    }
+};
+
 // src/fri/mod.rs:106-117 — field for field
 struct FRIProofPrototype {
     TrivialBlake2sIOP l0_commitment;
@@ -459,15 +529,18 @@ struct NaiveFriIop {
         return ok != 0;
     }
 
-    // the same verdict with the proof's shape bound to the domain the verifier expects first (hodor_fri_verify_proof_strict):
-    // what a verifier of UNTRUSTED proofs calls — the reference's walk accepts a proof whose last rounds were cut off
+    // the same verdict with the proof bound to the parameters the VERIFIER chose first (hodor_fri_verify_proof_strict):
+    // what a verifier of UNTRUSTED proofs calls — the reference's walk accepts a proof whose last rounds were cut off,
+    // and reads lde_factor / the degree bound from the proof itself (a prover may lower the rate)
     static bool verify_proof_strict(const Field &F, const FRIProof &proof, size_t expected_domain_size,
+                                    size_t expected_lde_factor, size_t expected_output_coeffs_at_degree_plus_one,
                                     size_t natural_element_index, const Fr &expected_value)
     {
         std::vector<uint8_t> raw = proof.to_bytes();
         int ok = 0;
-        F.check(hodor_fri_verify_proof_strict(F.ctx(), raw.data(), raw.size(), expected_domain_size,
-                                              natural_element_index, &expected_value, &ok), "verify_proof_queries (strict)");
+        F.check(hodor_fri_verify_proof_strict(F.ctx(), raw.data(), raw.size(), expected_domain_size, expected_lde_factor,
+                                              expected_output_coeffs_at_degree_plus_one, natural_element_index,
+                                              &expected_value, &ok), "verify_proof_queries (strict)");
         return ok != 0;
     }
 

@@ -106,6 +106,33 @@ static void test_make_small_iop(const Field &F)
     }
 }
 
+// make_small_iop again, over the COSET2 tree format (Coset2Combiner, hodor.hpp): every query answers for its whole
+// coset with ONE path of log2(64) - 1 digests, the index maps are inverse bijections that put a coset in one leaf
+static void test_make_small_iop_coset2(const Field &F)
+{
+    const size_t SIZE = 64;
+    std::vector<Fr> inputs;
+    Fr f = F.one();
+    for (size_t i = 0; i < SIZE; i++) { inputs.push_back(f); f = F.add(f, f); }
+    auto iop = Coset2Blake2sIOP::create(F, inputs);
+    auto root = iop.get_root();
+    CHECK(iop.nodes.size() == SIZE / 2 * 32);
+    CHECK(!(root == TrivialBlake2sIOP::create(F, inputs).get_root()));
+    for (size_t i = 0; i < SIZE; i++) {
+        size_t t = Coset2Combiner::natural_index_into_tree_index(i, SIZE);
+        CHECK(Coset2Combiner::tree_index_into_natural_index(t, SIZE) == i);
+        auto coset = Coset2Combiner::get_coset_for_natural_index(i, SIZE);
+        CHECK(coset.size() == Coset2Combiner::COSET_SIZE && (t >> 1) == coset[0]);
+        auto query = iop.query(i, inputs);
+        CHECK(query.index == coset[0] && query.path().size() == 5);
+        CHECK(query.values_[0] == inputs[coset[0]] && query.values_[1] == inputs[coset[1]]);
+        CHECK(Coset2Blake2sIOP::verify_query(F, query, root, SIZE));
+        auto bad = query;
+        bad.values_[1] = F.add(bad.values_[1], F.one());
+        CHECK(!Coset2Blake2sIOP::verify_query(F, bad, root, SIZE));
+    }
+}
+
 // test_one_fri_step (src/fri/mod.rs:252-361): coefficients 1,2,4,8, lde 4, output degree+1 = 2
 static void test_one_fri_step(const Field &F)
 {
@@ -309,6 +336,7 @@ int main()
     test_fft_inverse_identity(F);
     test_lde_correctness(F);
     test_make_small_iop(F);
+    test_make_small_iop_coset2(F);
     test_one_fri_step(F);
     test_fri_proof_and_verifier(F);
     test_sixstep_two_ranks(F);
