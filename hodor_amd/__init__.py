@@ -5,8 +5,8 @@ include/hodor_gpu.h).  This package is only the thin ctypes binding the tests an
 has no CPU fallback and fails loudly when the library is missing.
 """
 from ._lib import (BN256_FR_GENERATOR, BN256_FR_MODULUS, COSET2, EXPERIMENTS_FR_GENERATOR, TRIVIAL,
-                   EXPERIMENTS_FR_MODULUS, Context, Exchange, FriPrototype, HodorError, build, lib, lib_path)
+                   EXPERIMENTS_FR_MODULUS, Context, DirectExchange, Exchange, FriPrototype, HodorError, build, lib, lib_path)
 
-__all__ = ["Context", "Exchange", "FriPrototype", "HodorError", "build", "lib", "lib_path",
+__all__ = ["Context", "DirectExchange", "Exchange", "FriPrototype", "HodorError", "build", "lib", "lib_path",
            "BN256_FR_MODULUS", "BN256_FR_GENERATOR", "EXPERIMENTS_FR_MODULUS",
            "EXPERIMENTS_FR_GENERATOR", "TRIVIAL", "COSET2"]

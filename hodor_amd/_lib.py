@@ -53,6 +53,10 @@ EXPORTS = [
     "hodor_iop_create_combined_dev", "hodor_iop_query_combined_dev", "hodor_fri_commit_combined",
     "hodor_fri_commit_combined_dev", "hodor_fri_combiner", "hodor_fri_verify_proof_combined",
     "hodor_fri_verify_proof_strict_combined",
+    "hodor_ipc_export", "hodor_ipc_import", "hodor_ipc_close", "hodor_exchange_create_direct", "hodor_exchange_direct_flags",
+    "hodor_exchange_direct_set_peers", "hodor_exchange_direct_begin_dev", "hodor_exchange_direct_signal_dev",
+    "hodor_exchange_direct_wait_dev", "hodor_exchange_direct_release_dev", "hodor_sixstep_columns_direct_dev",
+    "hodor_sixstep_rows_direct_dev",
     "hodor_exchange_available", "hodor_exchange_unique_id", "hodor_exchange_create", "hodor_exchange_adopt",
     "hodor_exchange_destroy", "hodor_sixstep_exchange_dev", "hodor_sixstep_exchange_wait_dev",
 ]
@@ -332,6 +336,129 @@ class Exchange:
         if self.h:
             self.ctx.L.hodor_exchange_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _RawDeviceArray:
+    """A hipMalloc allocation seen through __cuda_array_interface__, so that torch can wrap it without copying."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+class DirectExchange:
+    """The direct transport of the 4-step exchange (csrc/abi_exchange.hip): every rank maps every rank's receive
+    buffers and the producing transform's last pass stores each slab straight into the buffer of the rank it is for —
+    no communicator, no copy, no chunks.  One instance per rank; `n_slots` receive buffers of `n_local` elements
+    (as many as transforms are in flight).  Wiring the peers:
+      * DirectExchange.connect_local(list of instances)   ranks that live in ONE process (played ranks, world 1)
+      * x.connect_processes(group)                        one process per rank: hipIpc handles travel once over
+                                                          torch.distributed (all_gather_object on `group`)"""
+
+    def __init__(self, ctx, n_ranks, rank, n_local, n_slots=4):
+        import torch
+        self.ctx, self.n_ranks, self.rank, self.n_local, self.n_slots = ctx, n_ranks, rank, n_local, n_slots
+        self.h = C.c_void_p()
+        ctx._chk(ctx.L.hodor_exchange_create_direct(ctx.h, C.c_uint32(n_ranks), C.c_uint32(rank), C.c_uint32(n_slots),
+                                                    C.byref(self.h)))
+        ctx._exchanges.add(self)
+        # the receive buffers are hipMalloc allocations of their own (not pieces of torch's caching allocator): an IPC
+        # handle names a whole allocation, and the peers must find the buffer at its start
+        self._raw, self.recv = [], []
+        for _ in range(n_slots):
+            p = C.c_void_p()
+            ctx._chk(ctx.L.hodor_buf_alloc(ctx.h, C.c_size_t(n_local * 32), C.byref(p)))
+            self._raw.append(p.value)
+            self.recv.append(torch.as_tensor(_RawDeviceArray(p.value, (n_local, 4)), device="cuda"))
+        fp, fb = C.c_void_p(), C.c_size_t()
+        ctx._chk(ctx.L.hodor_exchange_direct_flags(self.h, C.byref(fp), C.byref(fb)))
+        self.flags_ptr, self.flags_bytes = fp.value, fb.value
+        self._next = 0
+        self._imported = []
+
+    def _set_peers(self, slot, recv_ptrs, flag_ptrs):
+        r = (C.c_void_p * self.n_ranks)(*recv_ptrs)
+        f = (C.c_void_p * self.n_ranks)(*flag_ptrs)
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_set_peers(self.h, C.c_uint32(slot), r, f))
+
+    @staticmethod
+    def connect_local(instances):
+        for x in instances:
+            for slot in range(x.n_slots):
+                x._set_peers(slot, [p.recv[slot].data_ptr() for p in instances], [p.flags_ptr for p in instances])
+
+    def connect_processes(self, group=None):
+        import torch.distributed as dist
+        L, ctx = self.ctx.L, self.ctx
+
+        def export(ptr):
+            h = (C.c_uint8 * 64)()
+            ctx._chk(L.hodor_ipc_export(ctx.h, C.c_void_p(ptr), h))
+            return bytes(h)
+
+        mine = {"flags": export(self.flags_ptr), "recv": [export(p) for p in self._raw]}
+        everyone = [None] * self.n_ranks
+        dist.all_gather_object(everyone, mine, group=group)
+
+        def imp(handle):
+            p = C.c_void_p()
+            ctx._chk(L.hodor_ipc_import(ctx.h, (C.c_uint8 * 64).from_buffer_copy(handle), C.byref(p)))
+            self._imported.append(p.value)
+            return p.value
+        flag_ptrs = [self.flags_ptr if r == self.rank else imp(everyone[r]["flags"]) for r in range(self.n_ranks)]
+        for slot in range(self.n_slots):
+            recv_ptrs = [self.recv[slot].data_ptr() if r == self.rank else imp(everyone[r]["recv"][slot])
+                         for r in range(self.n_ranks)]
+            self._set_peers(slot, recv_ptrs, flag_ptrs)
+        dist.barrier(group=group)
+
+    def next_slot(self):
+        s = self._next
+        self._next = (self._next + 1) % self.n_slots
+        return s
+
+    def begin(self, slot, stream=None):
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_begin_dev(self.h, C.c_void_p(stream), C.c_uint32(slot)))
+
+    def signal(self, slot, stream=None):
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_signal_dev(self.h, C.c_void_p(stream), C.c_uint32(slot)))
+
+    def wait(self, slot, stream=None):
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_wait_dev(self.h, C.c_void_p(stream), C.c_uint32(slot)))
+
+    def release(self, slot, stream=None):
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_release_dev(self.h, C.c_void_p(stream), C.c_uint32(slot)))
+
+    def columns(self, src, slot, log_n1, log_n2, omega, log_chunks=0, chunk=0, stream=None):
+        w = _fr(omega)
+        self.ctx._chk(self.ctx.L.hodor_sixstep_columns_direct_dev(self.ctx.h, C.c_void_p(stream), _dptr(src), self.h,
+                                                                  C.c_uint32(slot), C.c_uint32(log_n1), C.c_uint32(log_n2),
+                                                                  C.byref(w), C.c_uint32(log_chunks), C.c_uint32(chunk)))
+
+    def rows(self, src, slot, log_n1, log_n2, omega, log_chunks=0, chunk=0, stream=None):
+        w = _fr(omega)
+        self.ctx._chk(self.ctx.L.hodor_sixstep_rows_direct_dev(self.ctx.h, C.c_void_p(stream), _dptr(src), self.h,
+                                                               C.c_uint32(slot), C.c_uint32(log_n1), C.c_uint32(log_n2),
+                                                               C.byref(w), C.c_uint32(log_chunks), C.c_uint32(chunk)))
+
+    def close(self):
+        if self.h:
+            import torch
+            torch.cuda.synchronize()
+            self.ctx.L.hodor_exchange_destroy(self.h)
+            self.h = None
+            for p in self._imported:
+                self.ctx.L.hodor_ipc_close(self.ctx.h, C.c_void_p(p))
+            self._imported = []
+            self.recv = []
+            for p in self._raw:
+                self.ctx.L.hodor_buf_free(self.ctx.h, C.c_void_p(p))
+            self._raw = []
 
     def __del__(self):
         try:

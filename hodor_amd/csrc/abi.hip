@@ -307,6 +307,12 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         bool in_place = (src == dst);
         if ((rc = ensure_scratch(ctx, 0, bytes, stream))) return rc;
         pool.arm(ctx, stream);
+        if (!dst && passes > 2) {
+            // direct exchange: the last pass writes into the peers' buffers and there is no local destination to
+            // ping-pong through — the second scratch buffer takes its place for the passes in between
+            if ((rc = ensure_scratch(ctx, 1, bytes, stream))) return rc;
+            dst = (uint4 *)ctx->scratch[1];
+        }
         uint4 *s0 = (uint4 *)ctx->scratch[0], *s1 = nullptr;
         // walk backwards: pass P-1 -> dst, P-2 -> s0, P-3 -> dst (or s1 if that would clobber src)...
         for (size_t i = 0; i < passes; i++) {
@@ -362,6 +368,12 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
         }
         if (lay && i == 0) A.src_split = lay->src_split;
         if (lay && i + 1 == passes) A.dst_split = lay->dst_split;
+        if (lay && i + 1 == passes && lay->peer_tab) {
+            A.peer_tab = lay->peer_tab;
+            A.peer_off = lay->peer_off;
+            A.peer_log = lay->peer_log;
+            A.peer_self = lay->peer_self;
+        }
         A.log_c = log_c;
         A.log_l = log_l;
         A.apply_tw = (i == 0) ? 0 : 1;

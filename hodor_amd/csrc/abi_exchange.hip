@@ -97,6 +97,17 @@ struct hodor_exchange {
     uint64_t issued = 0;            // number of exchanges enqueued so far = the latest ticket
     bool counted = false;           // registered in ctx->live_exchanges (hodor_ctx_destroy refuses while any is alive)
     std::mutex mu;
+    // ---- direct transport (no communicator, no copy: the producing pass stores into the peers' receive buffers)
+    struct Slot {
+        uint64_t *d_tab = nullptr;          // device array of n_ranks receive-buffer addresses (as mapped HERE)
+        bool set = false;
+        uint32_t produced = 0, consumed = 0;   // generations this rank has started producing into / consuming from the slot
+    };
+    uint32_t n_slots = 0;
+    Slot *slots = nullptr;
+    uint32_t *my_flags = nullptr;           // this rank's flag block: per slot { arrived[n_ranks], released[n_ranks] }
+    uint32_t *peer_flags[HODOR_EXCHANGE_MAX_RANKS] = {};   // every rank's flag block as mapped HERE (own one included)
+    uint32_t *d_err = nullptr;              // pinned host word (device-visible): set by a flag wait that timed out
 };
 
 static_assert(HODOR_EXCHANGE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the unique id travels as opaque bytes");
@@ -214,6 +225,14 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
 {
     if (!x) return;
     if (x->device >= 0) (void)hipSetDevice(x->device);
+    if (x->slots) {
+        (void)hipDeviceSynchronize();
+        for (uint32_t i = 0; i < x->n_slots; i++)
+            if (x->slots[i].d_tab) (void)hipFree(x->slots[i].d_tab);
+        delete[] x->slots;
+    }
+    if (x->my_flags) (void)hipFree(x->my_flags);
+    if (x->d_err) (void)hipHostFree(x->d_err);
     if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
     if (x->owns_comm && x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);
@@ -283,5 +302,256 @@ extern "C" int hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream, 
     if (ticket > x->issued) { set_err(ctx, "exchange: ticket from the future"); return HODOR_ERR_INVALID; }
     if (ticket == 0 || x->issued - ticket >= hodor_exchange::RING) ticket = x->issued;
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, x->done[ticket % hodor_exchange::RING], 0));
+    return HODOR_OK;
+}
+
+
+// =====================================================================================================================
+// Direct transport: the exchange without an exchange.  Every rank maps every rank's receive buffer (hipIpc* between
+// processes — hodor_ipc_export / _import below — or plain pointers when the ranks share a process) and the LAST pass
+// of the producing transform stores each output slab straight into the buffer of the rank it is for
+// (k_ntt_pass<1>, PassArgs::peer_tab: the kernel's streaming stores go out over xGMI while its other tiles compute).
+// No communicator, no copy kernel competing with the VALU-bound transform for CUs, no chunking (the overlap of wire
+// and arithmetic happens inside the one launch), no staging send buffer.  What remains of the collective is ordering,
+// done with two generation counters per (slot, peer) in fine-grained device memory:
+//     arrived[s]   written by rank s into MY block after its producer kernels: its slab of generation g is in my buffer
+//     released[t]  written by rank t into MY block after its consumer kernels: it has finished reading what I sent
+//   producer:  begin  (wait released[t] >= g - 1 for all t: the slot may be overwritten)
+//              hodor_sixstep_columns_direct_dev / _rows_direct_dev ...
+//              signal (arrived[me] := g in every peer's block)
+//   consumer:  wait   (arrived[s] >= g for all s) ; hodor_sixstep_rows_dev / _columns_dev on the local buffer ;
+//              release (released[me] := g in every peer's block)
+// Flag writes are one tiny kernel (system-scope stores behind a system fence, after the producer in stream order); flag
+// waits are a one-wave kernel that polls with system-scope loads, sleeps between polls and gives up after ~10 s (the
+// handle then reports HODOR_ERR_DEVICE at the next call instead of hanging the queue).  Unmeasured between real
+// devices: the pool's boxes have one GPU; exercised at world 1, with ranks played in one process, and
+// with processes sharing the one GPU over IPC handles.
+// =====================================================================================================================
+namespace hodor {
+
+struct FlagTargets {
+    uint32_t *p[HODOR_EXCHANGE_MAX_RANKS];
+};
+
+__global__ void k_flags_write(FlagTargets T, uint32_t count, uint32_t value)
+{
+    __threadfence_system();
+    if (threadIdx.x < count) __hip_atomic_store(T.p[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one wave: lane t polls flags[t] until it has reached `value` (wrap-safe), ~10 s at most
+__global__ void k_flags_wait(const uint32_t *flags, uint32_t count, uint32_t value, uint32_t *err)
+{
+    const uint32_t t = threadIdx.x;
+    if (t >= count) return;
+    const uint64_t t0 = wall_clock64();           // 100 MHz
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - value) >= 0) break;
+        if (wall_clock64() - t0 > 1000000000ull) { atomicExch(err, 1u); break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __threadfence_system();
+}
+
+}  // namespace hodor
+
+extern "C" int hodor_ipc_export(hodor_ctx *ctx, void *dev_ptr, uint8_t handle[HODOR_IPC_HANDLE_BYTES])
+{
+    NEED_DEVICE();
+    if (!dev_ptr || !handle) return HODOR_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) <= HODOR_IPC_HANDLE_BYTES, "IPC handle size");
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, dev_ptr));
+    memset(handle, 0, HODOR_IPC_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_ipc_import(hodor_ctx *ctx, const uint8_t handle[HODOR_IPC_HANDLE_BYTES], void **dev_ptr)
+{
+    NEED_DEVICE();
+    if (!dev_ptr || !handle) return HODOR_ERR_INVALID;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    HIPCHK(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_ipc_close(hodor_ctx *ctx, void *dev_ptr)
+{
+    NEED_DEVICE();
+    if (!dev_ptr) return HODOR_ERR_INVALID;
+    HIPCHK(hipIpcCloseMemHandle(dev_ptr));
+    return HODOR_OK;
+}
+
+extern "C" int hodor_exchange_create_direct(hodor_ctx *ctx, uint32_t n_ranks, uint32_t rank, uint32_t n_slots,
+                                            hodor_exchange **out)
+{
+    NEED_DEVICE();
+    if (!out) return HODOR_ERR_INVALID;
+    if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > HODOR_EXCHANGE_MAX_RANKS || rank >= n_ranks ||
+        n_slots == 0 || n_slots > 16) {
+        set_err(ctx, "exchange (direct): n_ranks a power of two <= 8, rank < n_ranks, 1 <= n_slots <= 16");
+        return HODOR_ERR_SIZE;
+    }
+    hodor_exchange *x = new (std::nothrow) hodor_exchange();
+    if (!x) return HODOR_ERR_INVALID;
+    x->ctx = ctx;
+    x->device = ctx->device;
+    x->n_ranks = n_ranks;
+    x->rank = rank;
+    x->n_slots = n_slots;
+    x->slots = new (std::nothrow) hodor_exchange::Slot[n_slots];
+    const size_t flag_bytes = (size_t)n_slots * 2 * n_ranks * sizeof(uint32_t);
+    hipError_t e = x->slots ? hipSuccess : hipErrorOutOfMemory;
+    // fine-grained: the flags are written by other devices while kernels of this one poll them
+    if (e == hipSuccess) e = hipExtMallocWithFlags((void **)&x->my_flags, flag_bytes, hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(x->my_flags, 0, flag_bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&x->d_err, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) *x->d_err = 0;
+    for (uint32_t i = 0; e == hipSuccess && i < n_slots; i++) e = hipMalloc((void **)&x->slots[i].d_tab, n_ranks * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_err(ctx, std::string("exchange (direct): ") + hipGetErrorString(e));
+        hodor_exchange_destroy(x);
+        return HODOR_ERR_DEVICE;
+    }
+    x->peer_flags[rank] = x->my_flags;
+    ctx->live_exchanges.fetch_add(1);
+    x->counted = true;
+    *out = x;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_exchange_direct_flags(hodor_exchange *x, void **flags_dev_ptr, size_t *bytes)
+{
+    if (!x || !x->my_flags || !flags_dev_ptr) return HODOR_ERR_INVALID;
+    *flags_dev_ptr = x->my_flags;
+    if (bytes) *bytes = (size_t)x->n_slots * 2 * x->n_ranks * sizeof(uint32_t);
+    return HODOR_OK;
+}
+
+extern "C" int hodor_exchange_direct_set_peers(hodor_exchange *x, uint32_t slot, void *const *recv, void *const *flags)
+{
+    if (!x || !x->ctx || !x->slots) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    if (!recv || slot >= x->n_slots) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(x->mu);
+    uint64_t tab[HODOR_EXCHANGE_MAX_RANKS];
+    for (uint32_t t = 0; t < x->n_ranks; t++) {
+        if (!recv[t]) { set_err(ctx, "exchange (direct): null receive buffer"); return HODOR_ERR_INVALID; }
+        tab[t] = (uint64_t)(uintptr_t)recv[t];
+        if (flags) {
+            if (!flags[t]) { set_err(ctx, "exchange (direct): null flag block"); return HODOR_ERR_INVALID; }
+            if (t != x->rank) x->peer_flags[t] = (uint32_t *)flags[t];
+        }
+    }
+    HIPCHK(hipMemcpy(x->slots[slot].d_tab, tab, x->n_ranks * sizeof(uint64_t), hipMemcpyHostToDevice));
+    x->slots[slot].set = true;
+    return HODOR_OK;
+}
+
+// flag word of (slot, kind, index) inside a rank's block: kind 0 = arrived[], 1 = released[]
+static inline uint32_t *flag_at(const hodor_exchange *x, uint32_t *block, uint32_t slot, uint32_t kind, uint32_t idx)
+{
+    return block + ((size_t)slot * 2 + kind) * x->n_ranks + idx;
+}
+
+static int direct_ready(hodor_exchange *x, uint32_t slot)
+{
+    hodor_ctx *ctx = x->ctx;
+    if (!x->slots || slot >= x->n_slots || !x->slots[slot].set) {
+        set_err(ctx, "exchange (direct): slot has no peers (hodor_exchange_direct_set_peers)");
+        return HODOR_ERR_INVALID;
+    }
+    for (uint32_t t = 0; t < x->n_ranks; t++)
+        if (!x->peer_flags[t]) { set_err(ctx, "exchange (direct): a peer's flag block is missing"); return HODOR_ERR_INVALID; }
+    if (*(volatile uint32_t *)x->d_err) {   // pinned host memory: no synchronisation with the device
+        set_err(ctx, "exchange (direct): a wait for a peer timed out earlier on this handle");
+        return HODOR_ERR_DEVICE;
+    }
+    return HODOR_OK;
+}
+
+static int direct_write(hodor_exchange *x, hipStream_t stream, uint32_t slot, uint32_t kind, uint32_t value)
+{
+    hodor_ctx *ctx = x->ctx;
+    hodor::FlagTargets T = {};
+    for (uint32_t t = 0; t < x->n_ranks; t++) T.p[t] = flag_at(x, x->peer_flags[t], slot, kind, x->rank);
+    hipLaunchKernelGGL(hodor::k_flags_write, dim3(1), dim3(64), 0, stream, T, x->n_ranks, value);
+    HIPCHK(hipGetLastError());
+    return HODOR_OK;
+}
+
+static int direct_wait(hodor_exchange *x, hipStream_t stream, uint32_t slot, uint32_t kind, uint32_t value)
+{
+    hodor_ctx *ctx = x->ctx;
+    hipLaunchKernelGGL(hodor::k_flags_wait, dim3(1), dim3(64), 0, stream, flag_at(x, x->my_flags, slot, kind, 0),
+                       x->n_ranks, value, x->d_err);
+    HIPCHK(hipGetLastError());
+    return HODOR_OK;
+}
+
+extern "C" int hodor_exchange_direct_begin_dev(hodor_exchange *x, void *stream, uint32_t slot)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = direct_ready(x, slot);
+    if (rc) return rc;
+    const uint32_t g = ++x->slots[slot].produced;
+    // every peer must have finished reading what this rank put into the slot last time
+    return g > 1 ? direct_wait(x, (hipStream_t)stream, slot, 1, g - 1) : HODOR_OK;
+}
+
+extern "C" int hodor_exchange_direct_signal_dev(hodor_exchange *x, void *stream, uint32_t slot)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = direct_ready(x, slot);
+    if (rc) return rc;
+    if (x->slots[slot].produced == 0) { set_err(ctx, "exchange (direct): signal without begin"); return HODOR_ERR_INVALID; }
+    return direct_write(x, (hipStream_t)stream, slot, 0, x->slots[slot].produced);
+}
+
+extern "C" int hodor_exchange_direct_wait_dev(hodor_exchange *x, void *stream, uint32_t slot)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = direct_ready(x, slot);
+    if (rc) return rc;
+    const uint32_t g = ++x->slots[slot].consumed;
+    return direct_wait(x, (hipStream_t)stream, slot, 0, g);
+}
+
+extern "C" int hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream, uint32_t slot)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = direct_ready(x, slot);
+    if (rc) return rc;
+    if (x->slots[slot].consumed == 0) { set_err(ctx, "exchange (direct): release without wait"); return HODOR_ERR_INVALID; }
+    return direct_write(x, (hipStream_t)stream, slot, 1, x->slots[slot].consumed);
+}
+
+// the device table of a slot and this rank's index, for abi_sixstep.hip
+extern "C" int hodor_exchange_direct_table(hodor_exchange *x, uint32_t slot, const uint64_t **tab, uint32_t *n_ranks,
+                                           uint32_t *rank)
+{
+    if (!x || !x->slots || slot >= x->n_slots || !x->slots[slot].set || !tab) return HODOR_ERR_INVALID;
+    *tab = x->slots[slot].d_tab;
+    if (n_ranks) *n_ranks = x->n_ranks;
+    if (rank) *rank = x->rank;
     return HODOR_OK;
 }

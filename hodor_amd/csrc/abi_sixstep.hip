@@ -184,6 +184,84 @@ extern "C" int hodor_sixstep_rows_dev(hodor_ctx *ctx, void *stream, const hodor_
                     nullptr, nullptr, nullptr, 1u << log_rows, &L);
 }
 
+// ---- the producers of the direct exchange (abi_exchange.hip): the same transforms with their last pass storing slab t
+// into rank t's receive buffer (slot `slot` of the handle) instead of a local send buffer; forward = the column
+// transforms, inverse = the inverse row transforms.  The consumers are the plain calls above on the local buffer.
+extern "C" int hodor_exchange_direct_table(hodor_exchange *x, uint32_t slot, const uint64_t **tab, uint32_t *n_ranks,
+                                           uint32_t *rank);
+
+extern "C" int hodor_sixstep_columns_direct_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_exchange *x,
+                                                uint32_t slot, uint32_t log_n1, uint32_t log_n2, const hodor_fr *omega,
+                                                uint32_t log_chunks, uint32_t chunk)
+{
+    NEED_DEVICE();
+    if (!src || !omega || !x) return HODOR_ERR_INVALID;
+    const uint64_t *tab = nullptr;
+    uint32_t P = 0, rank = 0;
+    if (hodor_exchange_direct_table(x, slot, &tab, &P, &rank)) { set_err(ctx, "sixstep (direct): slot not set up"); return HODOR_ERR_INVALID; }
+    const uint32_t log_p = log2u(P);
+    int rc = sixstep_check(ctx, log_n1, log_n2, log_p, rank);
+    if (rc) return rc;
+    const uint32_t log_r1 = log_n1 - log_p, log_c2 = log_n2 - log_p, log_n = log_n1 + log_n2;
+    if ((rc = chunk_check(ctx, log_c2, log_chunks, chunk))) return rc;
+    HFr w = to_h(omega);
+    HFr w1 = ctx->F.pow(w, 1ull << log_n2);
+    const uint32_t log_cw = log_c2 - log_chunks;
+    NttLayout L;
+    L.col_mode = true;
+    L.tw2d_root = &w;
+    L.tw2d_log_order = log_n;
+    L.tw2d_on_load = false;
+    L.log_width = log_cw;
+    L.src_log_width = log_c2;
+    L.src_col_off = (uint64_t)chunk << log_cw;
+    L.col0 = ((uint64_t)rank << log_c2) + ((uint64_t)chunk << log_cw);
+    L.peer_tab = tab;
+    L.peer_log = log_r1;                                   // output row k1 goes to rank k1 >> log_r1 ...
+    L.peer_self = rank;                                    // ... as row rank*r1 + (k1 mod r1) of its [P][r1][cw] chunk buffer
+    L.peer_off = (uint64_t)chunk << (log_n1 + log_cw);     // chunk buffers back to back: n_local / K elements each
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, nullptr, log_n1, w1, 1ull << log_n1, nullptr, nullptr,
+                    nullptr, 1u << L.log_width, &L);
+}
+
+extern "C" int hodor_sixstep_rows_direct_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_exchange *x,
+                                             uint32_t slot, uint32_t log_n1, uint32_t log_n2, const hodor_fr *omega,
+                                             uint32_t log_chunks, uint32_t chunk)
+{
+    NEED_DEVICE();
+    if (!src || !omega || !x) return HODOR_ERR_INVALID;
+    const uint64_t *tab = nullptr;
+    uint32_t P = 0, rank = 0;
+    if (hodor_exchange_direct_table(x, slot, &tab, &P, &rank)) { set_err(ctx, "sixstep (direct): slot not set up"); return HODOR_ERR_INVALID; }
+    const uint32_t log_p = log2u(P);
+    int rc = sixstep_check(ctx, log_n1, log_n2, log_p, rank);
+    if (rc) return rc;
+    const uint32_t log_r1 = log_n1 - log_p, log_c2 = log_n2 - log_p;
+    if ((rc = chunk_check(ctx, log_r1, log_chunks, chunk))) return rc;
+    HFr w = to_h(omega);
+    if (!ctx->F.inverse(w, &w)) return HODOR_ERR_INVALID;
+    HFr w2 = ctx->F.pow(w, 1ull << log_n1);
+    const uint32_t log_rows = log_r1 - log_chunks;         // this call: rows chunk*rb .. of B
+    src += ((size_t)chunk << log_rows) << log_n2;
+    NttLayout L;
+    SplitAddr S = {};                                      // element n2 = s*c2 + j of row i -> slab s, [rb][c2]
+    S.on = 1;
+    S.lo_log = log_c2;
+    S.mid_mask = 0;
+    S.stride_mid = 0;
+    S.hi_log = log_c2;
+    S.stride_hi = 1ull << (log_rows + log_c2);
+    S.batch_stride = 1ull << log_c2;
+    L.dst_split = S;
+    L.peer_tab = tab;
+    L.peer_self = rank;
+    L.peer_off = (uint64_t)chunk << (log_p + log_rows + log_c2);   // [K][P][rb][c2]
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, nullptr, log_n2, w2, 1ull << log_n2, nullptr, nullptr,
+                    nullptr, 1u << log_rows, &L);
+}
+
 extern "C" int hodor_sixstep_pack_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_fr *dst,
                                       uint32_t log_rows, uint32_t log_cols, uint32_t log_p)
 {

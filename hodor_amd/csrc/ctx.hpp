@@ -280,6 +280,10 @@ struct NttLayout {
     uint32_t tw2d_log_order = 0;     // ... of order 2^tw2d_log_order, on the first pass's inputs (true) or the
     bool tw2d_on_load = false;       //     last pass's outputs (false)
     SplitAddr src_split = {}, dst_split = {};
+    // direct exchange: the last pass writes slab t into peer_tab[t] (see PassArgs)
+    const uint64_t *peer_tab = nullptr;
+    uint64_t peer_off = 0;
+    uint32_t peer_log = 0, peer_self = 0;
 };
 int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, const HFr &omega,
              uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post, uint32_t batch = 1,

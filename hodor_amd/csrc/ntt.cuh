@@ -77,6 +77,12 @@ struct PassArgs {
     uint32_t tw2d_on_load;   // ... applied to the inputs of the first pass (1) or the outputs of the last pass (0)
     SplitAddr src_split;     // first pass: where input element x of batch member b lives
     SplitAddr dst_split;     // last pass: where output element x of batch member b goes
+    // ---- direct exchange (abi_exchange.hip, "direct" transport): the last pass stores every output slab straight into
+    // the receive buffer of the rank it is for, so the all-to-all of the 4-step transform disappears into the store phase
+    const uint64_t *peer_tab; // device array: peer_tab[t] = address of rank t's receive buffer as mapped in this process (null: off)
+    uint64_t peer_off;       // element offset of this call's chunk buffer inside every receive buffer
+    uint32_t peer_log;       // column mode: log2(rows per slab): output row o goes to rank o >> peer_log, as row
+    uint32_t peer_self;      //   (peer_self << peer_log) + (o mod rows per slab); split mode: rank x >> hi_log, slab peer_self
     uint32_t dbg;            // read only by -DHODOR_ABLATE builds (bench/ablate.sh): 1 skip butterflies, 2 twiddles, 4 loads, 8 stores
 };
 

@@ -474,7 +474,22 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         if (ABL(8) && y.v[0] != 0x12345u) continue;
         // streaming stores: the output crosses the chip once and should not push the twiddle tables out of L2
         // (-1 % on the 2^24 step; streaming LOADS of the data measured +0.8 %)
-        if (MODE == 1 && colm) fr_store_nt(A.dst + 2 * ((o << A.dst_log_width) + A.dst_col_off + colbase + c), y);
+        if (MODE == 1 && A.peer_tab != nullptr) {
+            // direct exchange: the slab this element belongs to lives in another rank's receive buffer
+            uint64_t t, at;
+            if (colm) {
+                t = o >> A.peer_log;
+                const uint64_t row = ((uint64_t)A.peer_self << A.peer_log) + (o & ((1ull << A.peer_log) - 1));
+                at = (row << A.dst_log_width) + A.dst_col_off + colbase + c;
+            } else {
+                const SplitAddr &S = A.dst_split;
+                t = o >> S.hi_log;
+                at = A.peer_self * S.stride_hi + ((o >> S.lo_log) & S.mid_mask) * S.stride_mid + by * S.batch_stride +
+                     (o & ((1ull << S.lo_log) - 1));
+            }
+            uint4 *base = reinterpret_cast<uint4 *>(A.peer_tab[t]);
+            fr_store_nt(base + 2 * (A.peer_off + at), y);
+        } else if (MODE == 1 && colm) fr_store_nt(A.dst + 2 * ((o << A.dst_log_width) + A.dst_col_off + colbase + c), y);
         else if (MODE == 1 && A.dst_split.on) fr_store_nt(A.dst + 2 * split_index(A.dst_split, o, by), y);
         else fr_store_nt(dst_b + 2 * o, y);
     }
@@ -505,7 +520,7 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     }();
     if (attr_rc != hipSuccess) return attr_rc;
     uint64_t n = 1ull << A.log_n;
-    const bool general = A.col_mode || A.src_split.on || A.dst_split.on;
+    const bool general = A.col_mode || A.src_split.on || A.dst_split.on || A.peer_tab != nullptr;
     // column mode: one sub-transform position per workgroup, grid.y walks the array's columns C at a time
     uint64_t grid = A.col_mode ? n >> A.log_r : n >> (A.log_r + A.log_c);
     // grid.y is limited to 65535: a larger count (2^16 tile-column groups of a wide column-mode array, 2^16+ rows of

@@ -30,10 +30,12 @@ import torch.distributed as dist
 class HipBackend:
     """Local steps on the MI355X through the C ABI (device tensors of shape (m, 4), int64)."""
 
-    def __init__(self, ctx, stream=None, exchange=None):
+    def __init__(self, ctx, stream=None, exchange=None, direct=None):
         # exchange: a hodor_amd.Exchange — the all-to-alls then run through the C ABI (hodor_sixstep_exchange_dev,
         # grouped ncclSend/ncclRecv on the library's communication stream) instead of torch.distributed
-        self.ctx, self.stream, self.exchange = ctx, stream, exchange
+        # direct: a hodor_amd.DirectExchange — no all-to-all at all: the producing transform stores every slab straight
+        # into the receive buffer of the rank it is for (hodor_sixstep_columns_direct_dev / _rows_direct_dev)
+        self.ctx, self.stream, self.exchange, self.direct = ctx, stream, exchange, direct
 
     # ---- 4-step building blocks
     def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
@@ -191,12 +193,38 @@ def _exchange_end(works):
         w.wait()                                     # the current stream waits for the exchange
 
 
+class _DirectWait:
+    def __init__(self, direct, slot, stream):
+        self.direct, self.slot, self.stream = direct, slot, stream
+
+    def wait(self):
+        self.direct.wait(self.slot, stream=self.stream)
+        return True
+
+
+def _direct_begin(backend, produce_direct, log_chunks):
+    """The direct transport's counterpart of _exchange_begin: claim a slot, wait until every peer has released it, run
+    the producing transform (its last pass writes into the peers' buffers), signal.  Returns the handle pieces."""
+    d, st = backend.direct, backend.stream
+    slot = d.next_slot()
+    d.begin(slot, stream=st)
+    for k in range(1 << log_chunks):
+        produce_direct(slot, k)
+    d.signal(slot, stream=st)
+    return d.recv[slot], [_DirectWait(d, slot, st)], (lambda: d.release(slot, stream=st))
+
+
 def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
     """First half of sixstep_forward: the column transforms, chunk by chunk, each chunk's all-to-all started
     behind it.  The caller may enqueue unrelated work (the other half of another transform) before
     sixstep_forward_end, which waits for the exchange and runs the row transforms."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
+    if getattr(backend, "direct", None) is not None:
+        d = backend.direct
+        recv, works, release = _direct_begin(
+            backend, lambda slot, k: d.columns(a, slot, log_n1, log_n2, omega, log_chunks, k, stream=backend.stream), log_chunks)
+        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
     def produce(k, out):
         if k is None:
@@ -211,7 +239,10 @@ def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log
 def sixstep_forward_end(backend, h):
     log_n1, log_n2, log_p, rank, omega, log_chunks = h["args"]
     _exchange_end(h["works"])
-    return backend.rows(h["recv"], log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
+    out = backend.rows(h["recv"], log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
+    if "release" in h:
+        h["release"]()                               # direct transport: the peers may overwrite the slot again
+    return out
 
 
 def sixstep_forward(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
@@ -224,6 +255,11 @@ def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log
     """First half of sixstep_inverse: the inverse row transforms chunk by chunk with their all-to-alls."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
+    if getattr(backend, "direct", None) is not None:
+        d = backend.direct
+        recv, works, release = _direct_begin(
+            backend, lambda slot, k: d.rows(b, slot, log_n1, log_n2, omega, log_chunks, k, stream=backend.stream), log_chunks)
+        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
     def produce(k, out):
         if k is None:
@@ -238,7 +274,10 @@ def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log
 def sixstep_inverse_end(backend, h):
     log_n1, log_n2, log_p, rank, omega, log_chunks = h["args"]
     _exchange_end(h["works"])
-    return backend.columns(h["recv"], log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
+    out = backend.columns(h["recv"], log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
+    if "release" in h:
+        h["release"]()
+    return out
 
 
 def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None, log_chunks=0):

@@ -344,6 +344,8 @@ int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor
  * context alive, sets hodor_last_error) while exchanges created on it exist. */
 typedef struct hodor_exchange hodor_exchange;
 #define HODOR_EXCHANGE_ID_BYTES 128
+#define HODOR_EXCHANGE_MAX_RANKS 8     /* direct transport: the GPUs of one node */
+#define HODOR_IPC_HANDLE_BYTES 64
 int  hodor_exchange_available(void);
 int  hodor_exchange_unique_id(uint8_t id[HODOR_EXCHANGE_ID_BYTES]);
 int  hodor_exchange_create(hodor_ctx *ctx, const uint8_t id[HODOR_EXCHANGE_ID_BYTES], uint32_t n_ranks, uint32_t rank,
@@ -353,6 +355,42 @@ void hodor_exchange_destroy(hodor_exchange *x);
 int  hodor_sixstep_exchange_dev(hodor_exchange *x, void *stream, const hodor_fr *send, hodor_fr *recv, size_t n_local,
                                 uint32_t log_chunks, uint32_t chunk, uint64_t *ticket);
 int  hodor_sixstep_exchange_wait_dev(hodor_exchange *x, void *stream, uint64_t ticket);
+/* ---- direct transport: the exchange without an exchange (csrc/abi_exchange.hip) ------------------------------------
+ * Every rank maps every rank's receive buffer into its own address space — hodor_ipc_export / _import (hipIpc*) between
+ * processes, plain pointers when the ranks share a process — and the LAST pass of the producing transform stores each
+ * output slab straight into the buffer of the rank it is for: no communicator, no copy kernel taking CUs from the
+ * VALU-bound transform, no chunks, no send buffer.  Ordering is two generation counters per (slot, peer) in
+ * fine-grained device memory, written by one tiny kernel and polled by a one-wave kernel (bounded: ~10 s, then the
+ * handle reports HODOR_ERR_DEVICE).  A slot is one receive buffer of n/P elements on every rank; use as many slots as
+ * transforms are in flight.
+ *   hodor_exchange_create_direct       handle with n_slots slots (no RCCL needed); hodor_exchange_direct_flags: this
+ *                                      rank's flag block, to be exported to the peers like a receive buffer
+ *   hodor_exchange_direct_set_peers    slot's receive buffers recv[t] and (once) the flag blocks flags[t] of all ranks
+ *                                      as mapped in THIS process (recv[rank] / flags[rank]: this rank's own)
+ *   producer:  hodor_exchange_direct_begin_dev (the slot may be overwritten: every peer released it)
+ *              hodor_sixstep_columns_direct_dev (forward) / hodor_sixstep_rows_direct_dev (inverse), chunked or not
+ *              hodor_exchange_direct_signal_dev
+ *   consumer:  hodor_exchange_direct_wait_dev (every peer's slab has arrived), then hodor_sixstep_rows_dev (forward) /
+ *              hodor_sixstep_columns_dev(inverse = 1) on this rank's own receive buffer, then
+ *              hodor_exchange_direct_release_dev
+ * All stream-ordered on `stream`.  Unmeasured between real devices (single-GPU boxes): exercised at world 1, with
+ * played ranks, and between processes that share the one GPU. */
+int  hodor_ipc_export(hodor_ctx *ctx, void *dev_ptr, uint8_t handle[HODOR_IPC_HANDLE_BYTES]);
+int  hodor_ipc_import(hodor_ctx *ctx, const uint8_t handle[HODOR_IPC_HANDLE_BYTES], void **dev_ptr);
+int  hodor_ipc_close(hodor_ctx *ctx, void *dev_ptr);
+int  hodor_exchange_create_direct(hodor_ctx *ctx, uint32_t n_ranks, uint32_t rank, uint32_t n_slots, hodor_exchange **out);
+int  hodor_exchange_direct_flags(hodor_exchange *x, void **flags_dev_ptr, size_t *bytes);
+int  hodor_exchange_direct_set_peers(hodor_exchange *x, uint32_t slot, void *const *recv, void *const *flags);
+int  hodor_exchange_direct_begin_dev(hodor_exchange *x, void *stream, uint32_t slot);
+int  hodor_exchange_direct_signal_dev(hodor_exchange *x, void *stream, uint32_t slot);
+int  hodor_exchange_direct_wait_dev(hodor_exchange *x, void *stream, uint32_t slot);
+int  hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream, uint32_t slot);
+int  hodor_sixstep_columns_direct_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_exchange *x, uint32_t slot,
+                                      uint32_t log_n1, uint32_t log_n2, const hodor_fr *omega, uint32_t log_chunks,
+                                      uint32_t chunk);
+int  hodor_sixstep_rows_direct_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_exchange *x, uint32_t slot,
+                                   uint32_t log_n1, uint32_t log_n2, const hodor_fr *omega, uint32_t log_chunks,
+                                   uint32_t chunk);
 /* Synthetic input for tests and benchmarks: dst[r] = element first_index + r of the
  * index-addressable SplitMix64 stream `seed` — uniform canonical residues (rejection-sampled < p)
  * in Montgomery form, i.e. what the reference's tests draw with Fr::rand (src/fft/mod.rs:71-77), but

@@ -427,3 +427,138 @@ def test_bench_multi_rank_path_with_ranks_sharing_the_gpu(world, log_n, chunks):
     total = log_n + world.bit_length() - 1
     if str(total) in FULL["ntt"]:
         assert line["checks"].get("fft_digest_vs_cpu_oracle") is True
+
+
+# ---------------------------------------------------------------- direct transport (no all-to-all)
+@pytest.mark.parametrize("world,log_n,log_chunks", [(1, 9, 0), (1, 14, 0), (1, 14, 2), (2, 11, 0), (2, 12, 1), (4, 13, 0),
+                                                    (4, 14, 2), (8, 12, 0), (8, 16, 1), (2, 20, 0), (8, 21, 0)])
+def test_direct_exchange_with_played_ranks(gpu_ctxs, oracles, world, log_n, log_chunks):
+    """hodor_sixstep_columns_direct_dev / _rows_direct_dev: the last pass of the producing transform stores every slab
+    straight into the receive buffer of the rank it is for (csrc/abi_exchange.hip, direct transport).  The P ranks are
+    played in one process (DirectExchange.connect_local: the "peers' buffers" are other allocations of this device);
+    what lands in every receive buffer must equal the hand-made all-to-all of the plain calls' send buffers, the
+    consumers then give layout B / layout A, and the begin / signal / wait / release protocol runs for real."""
+    import torch
+    import hodor_amd
+    from hodor_amd.sixstep import HipBackend, split_logs
+    from sixstep_ref import layout_a, layout_b
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    hip = HipBackend(ctx)
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = world.bit_length() - 1
+    n = 1 << log_n
+    m = n // world
+    K = 1 << log_chunks
+    step = m // K
+    full = O.random_elements(n, 190 + log_n)
+    _, k, w = O.domain(n)
+    spec = full.copy()
+    O.best_fft(spec, w, k)
+    xs = [hodor_amd.DirectExchange(ctx, world, r, m, n_slots=2) for r in range(world)]
+    hodor_amd.DirectExchange.connect_local(xs)
+
+    def exchange_chunks(send):
+        recv = [torch.empty_like(send[0]) for _ in range(world)]
+        sl = step // world
+        for c in range(K):
+            for t in range(world):
+                for s_ in range(world):
+                    recv[t][c * step + s_ * sl:c * step + (s_ + 1) * sl] = send[s_][c * step + t * sl:c * step + (t + 1) * sl]
+        return recv
+
+    a = [_dev(layout_a(full, log_n, r, world)) for r in range(world)]
+    for rnd in range(3):                 # generations 1, 2, 3 of slot rnd % 2: the release / begin handshake is exercised
+        slot = rnd % 2
+        # ---- forward: producers of every rank, then the consumers
+        send = []
+        for r in range(world):
+            buf = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+            for c in range(K):
+                hip.columns(a[r], log_n1, log_n2, log_p, r, w, False, log_chunks, c, out=buf[c * step:(c + 1) * step])
+            send.append(buf)
+        want = exchange_chunks(send)
+        for r in range(world):
+            xs[r].begin(slot)
+            for c in range(K):
+                xs[r].columns(a[r], slot, log_n1, log_n2, w, log_chunks, c)
+            xs[r].signal(slot)
+        b = []
+        for r in range(world):
+            xs[r].wait(slot)
+            ctx.synchronize()
+            assert torch.equal(xs[r].recv[slot], want[r]), ("forward slabs", rnd, r)
+            b.append(hip.rows(xs[r].recv[slot], log_n1, log_n2, log_p, r, w, False, log_chunks, 0))
+            xs[r].release(slot)
+        ctx.synchronize()
+        for r in range(world):
+            assert np.array_equal(_host(b[r]), layout_b(spec, log_n, r, world)), ("rows", rnd, r)
+        # ---- inverse
+        send = []
+        for r in range(world):
+            buf = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+            for c in range(K):
+                hip.rows(b[r], log_n1, log_n2, log_p, r, w, True, log_chunks, c, out=buf[c * step:(c + 1) * step])
+            send.append(buf)
+        want = exchange_chunks(send)
+        slot2 = 1 - slot
+        for r in range(world):
+            xs[r].begin(slot2)
+            for c in range(K):
+                xs[r].rows(b[r], slot2, log_n1, log_n2, w, log_chunks, c)
+            xs[r].signal(slot2)
+        for r in range(world):
+            xs[r].wait(slot2)
+            ctx.synchronize()
+            assert torch.equal(xs[r].recv[slot2], want[r]), ("inverse slabs", rnd, r)
+            a2 = hip.columns(xs[r].recv[slot2], log_n1, log_n2, log_p, r, w, True, log_chunks, 0)
+            xs[r].release(slot2)
+            ctx.synchronize()
+            assert torch.equal(a2, a[r]), ("columns^-1", rnd, r)
+    for x in xs:
+        x.close()
+
+
+def test_direct_exchange_through_the_schedule_at_world_1(gpu_ctxs):
+    """sixstep_forward / sixstep_inverse with HipBackend(direct=...) at 2^24 points: the forward result, transposed to
+    natural order, hashes to the CPU oracle's committed digest; the inverse returns the input."""
+    import torch
+    import hodor_amd
+    from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse, split_logs
+    ctx = gpu_ctxs["bn256"]
+    log_n = 24
+    n = 1 << log_n
+    e = FULL["ntt"][str(log_n)]
+    a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a, 0, n, e["seed"])
+    w = ctx.domain(n)[2]
+    x = hodor_amd.DirectExchange(ctx, 1, 0, n, n_slots=2)
+    hodor_amd.DirectExchange.connect_local([x])
+    hip = HipBackend(ctx, direct=x)
+    for _ in range(3):
+        b = sixstep_forward(hip, a, log_n, w, 0, 1)
+        c = sixstep_inverse(hip, b, log_n, w, 0, 1)
+    l1, l2 = split_logs(log_n)
+    nat = hip.transpose(b, 1 << l1, 1 << l2)
+    ctx.synchronize()
+    assert hashlib.blake2s(memoryview(nat.cpu().numpy()).cast("B"), digest_size=32).hexdigest() == e["fft"]
+    assert torch.equal(c, a)
+    x.close()
+
+
+def test_direct_exchange_between_two_processes_sharing_the_gpu():
+    """The real thing minus the second device: two processes (torchrun, gloo for the control traffic) map each other's
+    receive buffers and flag blocks through hipIpc handles (hodor_ipc_export / _import) and run bench.py's 4-step steps
+    with --exchange direct; the line is printed only if the round trip holds and the gathered forward transform equals
+    the CPU oracle's digest of the 2^22-point transform."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("HODOR_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--exchange",
+                          "direct", "--log-n", "21", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra",
+                          "--launch-timeout", "600"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["mode"] == "sixstep" and line["scaling"] == "weak", line
+    assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
+    assert "direct" in line["exchange"]["transport"]
