@@ -62,6 +62,49 @@ def main():
             print("P = %d  transform 2^%d = 2^%d x 2^%d, 2^%d points per rank, %d chunk(s): local arithmetic %.3f ms per "
                   "NTT+iNTT (%.2fx the P = 1 shape); on the wire per rank and transform %.0f MB"
                   % (world, log_n, l1, l2, log_local, chunks, ms, ms / base, wire / 1e6))
+        # the direct transport (csrc/abi_exchange.hip): rank 0's producers store slab t into "rank t's" receive buffer —
+        # here P local allocations stand in for the peers — un-chunked (the overlap of stores and arithmetic happens
+        # inside the one launch), with the begin / signal / wait / release flag kernels of a real step
+        xs = [hodor_amd.DirectExchange(ctx, world, r, m, n_slots=2) for r in range(world)]
+        hodor_amd.DirectExchange.connect_local(xs)
+        x0 = xs[0]
+
+        def direct_step():
+            x0.begin(0)
+            x0.columns(a, 0, l1, l2, omega)
+            x0.signal(0)
+            for p in xs[1:]:
+                p.begin(0); p.signal(0)          # the played peers only keep the generation counters moving
+            x0.wait(0)
+            be.rows(x0.recv[0], l1, l2, log_p, 0, omega, False, 0, 0, out=out)
+            x0.release(0)
+            for p in xs[1:]:
+                p.wait(0); p.release(0)
+            x0.begin(1)
+            x0.rows(out, 1, l1, l2, omega)
+            x0.signal(1)
+            for p in xs[1:]:
+                p.begin(1); p.signal(1)
+            x0.wait(1)
+            be.columns(x0.recv[1], l1, l2, log_p, 0, omega, True, 0, 0, out=send)
+            x0.release(1)
+            for p in xs[1:]:
+                p.wait(1); p.release(1)
+
+        for _ in range(20):
+            direct_step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            direct_step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print("P = %d  the same with the DIRECT transport (producers store into %d receive buffers, no chunks, flag kernels "
+              "included): %.3f ms per NTT+iNTT (%.2fx the P = 1 shape)" % (world, world, ms, ms / base))
+        for p in xs:
+            p.close()
 
 
 if __name__ == "__main__":

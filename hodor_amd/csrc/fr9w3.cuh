@@ -86,6 +86,52 @@ __device__ __forceinline__ Fr9 fr9_mul3(const Fr9 &a, const Fr9W3 &W, const Fr9P
     return t;
 }
 
+// two products by the same W3 constant with their accumulator chains interleaved and un-pinned: no mad depends on the
+// one issued just before it (no wait state between them), at the price of two live accumulators and twelve more live
+// limbs.  Experiment of round 4 (-DHODOR_EXP_X2, profiles/r04/diet_ab.txt): see DESIGN.md §8.
+template <bool P1 = false>
+__device__ __forceinline__ void fr9_mul3x2(Fr9 &a, Fr9 &b, const Fr9W3 &W, const Fr9Params &P)
+{
+    uint32_t ma[3], mb[3];
+    Fr9 ta, tb;
+    uint64_t acca = 0, accb = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (k - j >= 0 && k - j < 9) {
+                    acca += (uint64_t)a.v[3 * c + j] * W.w[c][k - j];
+                    accb += (uint64_t)b.v[3 * c + j] * W.w[c][k - j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j < k && k - j < 9) {
+                acca += (uint64_t)ma[j] * P.p[k - j];
+                accb += (uint64_t)mb[j] * P.p[k - j];
+            }
+        }
+        if (k < 3) {
+            ma[k] = fr9_mont_digit<P1>((uint32_t)acca, P);
+            mb[k] = fr9_mont_digit<P1>((uint32_t)accb, P);
+            acca += (uint64_t)ma[k] * P.p[0];
+            accb += (uint64_t)mb[k] * P.p[0];
+        } else {
+            ta.v[k - 3] = (uint32_t)acca & HODOR_M29;
+            tb.v[k - 3] = (uint32_t)accb & HODOR_M29;
+        }
+        acca >>= 29;
+        accb >>= 29;
+    }
+    ta.v[8] = (uint32_t)acca;
+    tb.v[8] = (uint32_t)accb;
+    a = ta;
+    b = tb;
+}
+
 // ---- W9: the same idea with one-limb groups, for WAVE-UNIFORM constants ------------------------------------
 //     V_c = w * 2^(29 (c + 1)) mod p,  c = 0 .. 8;     T = sum_c x_c V_c  ==  x w 2^29 (mod p),  9 columns
 //     r = (T + m p) / 2^29  ==  x w (mod p),           m = -T p^-1 mod 2^29

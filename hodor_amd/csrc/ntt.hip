@@ -404,10 +404,19 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 Fr9 t;
                 if (m > 1) {
                     const Fr9W3 wa = twiddle(jp << (log_r - log_m - 1));
+#ifdef HODOR_EXP_X2
+                    {
+                        Fr9 t1 = x1, t3 = x3;
+                        fr9_mul3x2<P1>(t1, t3, wa, Q);
+                        x1 = fr9_sub5(x0, t1, Q); x0 = fr9_add(x0, t1);
+                        x3 = fr9_sub5(x2, t3, Q); x2 = fr9_add(x2, t3);
+                    }
+#else
                     t = fr9_mul3<P1>(x1, wa, Q);
                     x1 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                     t = fr9_mul3<P1>(x3, wa, Q);
                     x3 = fr9_sub5(x2, t, Q); x2 = fr9_add(x2, t);
+#endif
                     // the second stage multiplies the lazy sums (limbs < 2^29 + 2^30): the W3 product only needs
                     // its three 87-bit limb GROUPS below 2^87 for its (4 + 2^-25) p bound — two carries, not eight
 #ifdef HODOR_EXP_FULLNORM

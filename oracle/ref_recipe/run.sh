@@ -9,6 +9,7 @@ rm -rf "$OUT/hodor" && mkdir -p "$OUT" && cp -r /root/reference "$OUT/hodor"
 cp "$HERE/gen_fixtures.rs" "$OUT/hodor/src/gen_fixtures.rs"
 printf '\n#[cfg(test)]\nmod gen_fixtures;\n' >> "$OUT/hodor/src/lib.rs"
 mkdir -p "$HERE/../_ref"
+OFFLINE=""; [ "${CARGO_NET_OFFLINE:-}" = "true" ] && OFFLINE="--offline"   # a vendored / mirrored registry (README.md lists the crates)
 (cd "$OUT/hodor" && HODOR_FIXTURES_OUT="$HERE/../_ref/fullsize_digests_rust.json" \
-    cargo test --release gen_fixtures -- --nocapture --ignored)
+    cargo test $OFFLINE --release gen_fixtures -- --nocapture --ignored)
 python3 "$HERE/compare.py" "$HERE/../_ref/fullsize_digests_rust.json" "$HERE/../../tests/golden/fullsize_digests.json"

@@ -105,3 +105,54 @@ def test_gpu_lde_equals_sympy(gpu_ctxs, oracles, name):
         got = [ctx.into_repr(sum(int(out[j][i]) << (64 * i) for i in range(4))) for j in range(n * factor)]
         src = [v * pow(F.g, i, F.p) % F.p for i, v in enumerate(can)] if coset else can
         assert got == [int(x) for x in ntt(src + [0] * (n * factor - n), F.p)], coset
+
+
+def _fri_rounds_against_sympy(F, coeffs_can, factor, out_deg, challenges_can, round_values_can):
+    """A Merkle-free FRI invariant sympy can check on its own (src/fri/mod.rs:194-203 against
+    src/fri/fri_on_values.rs:77-100): round k's vector must be the values, on the size n/2^k domain, of the polynomial whose
+    coefficients are the previous ones folded a_(2i) + beta_k a_(2i+1) — i.e. sympy's intt of the round's vector must give
+    exactly those folded coefficients followed by zeros (the low-degree property FRI is about)."""
+    c = list(coeffs_can)
+    for k, (beta, vec) in enumerate(zip(challenges_can, round_values_can)):
+        c = [(c[2 * i] + beta * c[2 * i + 1]) % F.p for i in range(len(c) // 2)]
+        got = [int(x) for x in intt(vec, F.p)]
+        assert got[:len(c)] == c, ("round", k)
+        assert not any(got[len(c):]), ("round", k, "degree")
+        assert len(vec) == len(c) * factor
+    return c[:out_deg]
+
+
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+@pytest.mark.parametrize("log_deg,factor,out_deg", [(3, 4, 1), (5, 8, 2), (6, 4, 1)])
+def test_oracle_fri_folds_equal_sympy(oracles, name, log_deg, factor, out_deg):
+    O, F = oracles[name], FIELDS[name]
+    a = O.gen_elements(0, 1 << log_deg, 0x465249 + log_deg)
+    can = _canon(O, a)
+    lde = O.poly_lde(a, factor)
+    assert _canon(O, lde) == [int(x) for x in ntt(can + [0] * (len(lde) - len(can)), F.p)]
+    for combiner in (0, 1):              # the folds do not depend on the tree format, only the challenges do
+        if combiner == 1 and factor * out_deg < 4:
+            continue
+        ref = O.fri_commit(lde, factor, out_deg, combiner=combiner)
+        final = _fri_rounds_against_sympy(F, can, factor, out_deg, [O.to_canonical(b) for b in ref["challenges"]],
+                                          [_canon(O, v) for v in ref["inter_values"]])
+        assert _canon(O, ref["final_coeffs"]) == final
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bn256", "experiments"])
+@pytest.mark.parametrize("log_deg,factor,out_deg", [(4, 4, 1), (7, 8, 2), (10, 4, 1)])
+def test_gpu_fri_folds_equal_sympy(gpu_ctxs, oracles, name, log_deg, factor, out_deg):
+    """The device FRI commit (fold fused into the leaf launch, fused tail) against the same third-party invariant: the
+    challenges are the library's own, every round's vector comes off the device, sympy does the rest."""
+    ctx, O, F = gpu_ctxs[name], oracles[name], FIELDS[name]
+    a = O.gen_elements(0, 1 << log_deg, 0x465250 + log_deg)
+    can = _canon(O, a)
+    lde = ctx.poly_lde(a, factor)
+    n = len(lde)
+    for combiner in (0, 1):
+        proto = ctx.fri_commit(lde, factor, out_deg, combiner=combiner)
+        rounds = [_canon(O, proto.intermediate_values(i, n >> (i + 1))) for i in range(proto.num_steps)]
+        final = _fri_rounds_against_sympy(F, can, factor, out_deg, [ctx.into_repr(b) for b in proto.challenges], rounds)
+        assert [ctx.into_repr(v) for v in array_to_ints(proto.final_coeffs)] == final
+        proto.free()
