@@ -50,7 +50,7 @@ EXPORTS = [
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_proof_strict", "hodor_fri_verify_prototype",
     "hodor_iop_create_combined", "hodor_hash_leaf_combined", "hodor_iop_path_combined", "hodor_iop_verify_combined",
-    "hodor_iop_create_combined_dev", "hodor_iop_query_combined_dev", "hodor_fri_commit_combined",
+    "hodor_iop_create_combined_dev", "hodor_iop_create_batch_combined_dev", "hodor_iop_query_combined_dev", "hodor_fri_commit_combined",
     "hodor_fri_commit_combined_dev", "hodor_fri_combiner", "hodor_fri_verify_proof_combined",
     "hodor_fri_verify_proof_strict_combined",
     "hodor_ipc_export", "hodor_ipc_import", "hodor_ipc_close", "hodor_exchange_create_direct", "hodor_exchange_direct_flags",
@@ -857,6 +857,10 @@ class Context:
                                                        C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one),
                                                        C.c_int(combiner), C.byref(h)))
         return FriPrototype(self, h)
+
+    def iop_create_batch_combined_dev(self, leafs, n, batch, combiner, nodes, stream=None):
+        self._chk(self.L.hodor_iop_create_batch_combined_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n),
+                                                             C.c_size_t(batch), C.c_int(combiner), _dptr(nodes)))
 
     def iop_create_combined_dev(self, leafs, n, combiner, nodes, stream=None):
         self._chk(self.L.hodor_iop_create_combined_dev(self.h, C.c_void_p(stream), _dptr(leafs), C.c_size_t(n),

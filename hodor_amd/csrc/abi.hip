@@ -679,6 +679,19 @@ extern "C" int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const ho
     return HODOR_OK;
 }
 
+// the batched commit in the chosen tree format (COSET2: batch node arrays of (n/2)*32 bytes back to back)
+extern "C" int hodor_iop_create_batch_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n,
+                                                   size_t batch, int combiner, uint8_t *nodes)
+{
+    if (combiner == HODOR_COMBINER_TRIVIAL) return hodor_iop_create_batch_dev(ctx, stream, leafs, n, batch, nodes);
+    NEED_DEVICE();
+    if (combiner != HODOR_COMBINER_COSET2 || !leafs || !nodes) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 4 || batch == 0 || batch > 65535) return HODOR_ERR_SIZE;
+    HIPCHK(merkle_build_launch(pick_stream(ctx, stream), (const uint4 *)leafs, (uint4 *)nodes, n, ctx->mid,
+                               (uint32_t)batch, nullptr, nullptr, true));
+    return HODOR_OK;
+}
+
 // a[i] *= g^i through the cached two-level table of g (caller holds ctx->mu)
 static int distribute_powers_exec(hodor_ctx *ctx, hipStream_t stream, uint4 *a, size_t n, const HFr &g)
 {

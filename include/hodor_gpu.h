@@ -241,6 +241,9 @@ int hodor_poly_lde_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, 
                              uint32_t log_n, size_t factor, int coset, size_t batch);
 int hodor_iop_create_batch_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, size_t batch,
                                uint8_t *nodes);
+/* the same in the chosen tree format (HODOR_COMBINER_COSET2: batch node arrays of (n/2)*32 bytes back to back) */
+int hodor_iop_create_batch_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *leafs, size_t n, size_t batch,
+                                        int combiner, uint8_t *nodes);
 int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_t n, const hodor_fr *g);
 /* Polynomial<F, Coefficients>::evaluate_at_domain_for_degree_one (coset != 0: coset_evaluate_at_...) —
  * src/polynomials/mod.rs:229-258, :260-290: out[i] = alpha * u_i + c for q(x) = c + alpha x, u_i = w^i over the

@@ -265,3 +265,23 @@ def test_knobs_are_reported_and_bench_refuses_them():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--skip-checks"], capture_output=True,
                        text=True, env=clean)
     assert r.returncode != 0 and "--allow-knobs" in r.stderr
+
+
+def test_bare_multi_gpu_bench_launch_never_answers_with_silence():
+    """`python3 bench.py --gpus 2` without a torchrun environment re-executes itself under torch.distributed.run; where
+    that cannot work at all (this container has no GPU) the retreat to replicas fails too and the command still prints
+    ONE parseable line that says so ("scaling": "failed", the reason) and exits non-zero."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (the working launch is tests/test_gpu_sixstep.py)")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("HODOR_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--launch-timeout", "240"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "failed" and d["n_gpus"] == 2 and d["value"] == 0.0 and "reason" in d

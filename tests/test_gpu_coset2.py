@@ -68,6 +68,27 @@ def test_coset2_tree_large_matches_oracle(gpu_ctxs, oracles, log_n):
     assert np.array_equal(d_n.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("log_n,batch", [(3, 5), (10, 3), (14, 4), (20, 2)])
+def test_coset2_batched_commit_matches_single_trees(gpu_ctxs, oracles, log_n, batch):
+    """hodor_iop_create_batch_combined_dev: `batch` columns committed in one call (all registers' LDEs,
+    src/prover/mod.rs:73-80) = the trees of the columns one by one, which the oracle pins."""
+    import torch
+    from gpu_inputs import random_elements
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    d_l = random_elements(torch, n * batch, 277 + log_n)
+    d_n = torch.empty((batch * (n // 2), 32), dtype=torch.uint8, device="cuda")
+    ctx.iop_create_batch_combined_dev(d_l, n, batch, C2, d_n)
+    ctx.synchronize()
+    host = d_l.cpu().numpy().view(np.uint64)
+    for j in range(batch):
+        assert np.array_equal(d_n[j * (n // 2):(j + 1) * (n // 2)].cpu().numpy(), O.iop_create_coset2(host[j * n:(j + 1) * n])), j
+    t_n = torch.empty((batch * n, 32), dtype=torch.uint8, device="cuda")
+    ctx.iop_create_batch_combined_dev(d_l, n, batch, T, t_n)
+    ctx.synchronize()
+    assert np.array_equal(t_n[:n].cpu().numpy(), O.iop_create(host[:n]))
+
+
 def test_coset2_query_dev_matches_oracle(gpu_ctxs, oracles):
     import torch
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]

@@ -562,3 +562,25 @@ def test_direct_exchange_between_two_processes_sharing_the_gpu():
     assert line["n_gpus"] == 2 and line["mode"] == "sixstep" and line["scaling"] == "weak", line
     assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
     assert "direct" in line["exchange"]["transport"]
+
+
+def test_bare_bench_launch_with_two_ranks_spawns_its_own_torchrun():
+    """`python3 bench.py --gpus 2 ...` from a clean environment — the exact shape of the driver's command, no torchrun, no
+    RANK — re-executes itself under torch.distributed.run and relays ONE JSON line (here with the ranks sharing the one
+    GPU over gloo; on a multi-GPU node the same command without --backend runs RCCL)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith("HODOR_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--log-n", "21",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--launch-timeout", "900"],
+                         capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["mode"] == "sixstep", line
+    assert "self-spawned" in line["launcher"]
+    assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
+    assert line["extra"]["lde_commit"].get("root_equals_cpu_oracle") is True
