@@ -341,10 +341,12 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
             hipLaunchKernelGGL((k_merkle_subtree<true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
         else if (first)
             hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
+        // (the launches above the leaves use `n` only as the distance between the batch's node arrays: n/2 entries for a
+        // COSET2 tree)
         else if (lat)
-            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
+            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, comb ? n >> 1 : n, mid, FoldArgs(), Fr9Params());
         else
-            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
+            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, comb ? n >> 1 : n, mid, FoldArgs(), Fr9Params());
         m >>= levels;
         first = false;
     }
