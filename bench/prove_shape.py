@@ -7,7 +7,7 @@ transcript driving every challenge, query phase included as in Prover::prove) wi
 FRI vector resident in HBM, prints the per-phase times in the reference's phase names, the number of host round trips
 and the peak HBM, then runs the SAME sequence on the CPU oracle (the C port of the reference's schedules, all host
 cores) and requires the two proofs to be byte-identical.
-    python bench/prove_shape.py [log_rows=20] [registers=4] [lde_factor=16] [--no-cpu]"""
+    python bench/prove_shape.py [log_rows=20] [registers=4] [lde_factor=16] [--no-cpu] [--coset2]"""
 import hashlib
 import os
 import sys
@@ -32,6 +32,7 @@ def main():
     registers = int(args[1]) if len(args) > 1 else 4
     lde_factor = int(args[2]) if len(args) > 2 else 16
     with_cpu = "--no-cpu" not in sys.argv
+    combiner = hodor_amd.COSET2 if "--coset2" in sys.argv else hodor_amd.TRIVIAL   # every oracle in the COSET2 tree format
     ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=0)
     O = Oracle(P.BN256.p, P.BN256.g)
     trace, prep = ps.make_trace(O, log_rows, registers)
@@ -41,7 +42,7 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter()
 
-    dev = ps.DeviceProver(O, ctx)
+    dev = ps.DeviceProver(O, ctx, combiner=combiner)
     proof, _, _ = ps.prove(dev, d_trace, d_prep, lde_factor, clock)          # warm-up: twiddle tables, FRI slab
     torch.cuda.reset_peak_memory_stats()
     runs = []
@@ -55,14 +56,15 @@ def main():
     runs.sort(key=lambda r: r[0])
     total, times = runs[len(runs) // 2]
     peak = torch.cuda.max_memory_allocated() / 2**30
-    print("prove-shaped run: %d registers x 2^%d rows, LDE %d (f LDEs 2^%d, g LDE / h2 2^%d points), src/bn256.rs field"
+    print("prove-shaped run: %d registers x 2^%d rows, LDE %d (f LDEs 2^%d, g LDE / h2 2^%d points), src/bn256.rs field, %s"
           % (registers, log_rows, lde_factor, log_rows + lde_factor.bit_length() - 1,
-             log_rows + 2 + lde_factor.bit_length() - 1))
+             log_rows + 2 + lde_factor.bit_length() - 1,
+             "COSET2 oracles (opt-in tree format)" if combiner else "the reference's tree format"))
     print("proof %d bytes, blake2s %s" % (len(proof), hashlib.blake2s(proof, digest_size=32).hexdigest()))
     cpu_times = None
     if with_cpu:
         t = time.perf_counter()
-        cpu_proof, cpu_times, cpu_marks = ps.prove(ps.OracleProver(O, P.BN256), trace, prep, lde_factor)
+        cpu_proof, cpu_times, cpu_marks = ps.prove(ps.OracleProver(O, P.BN256, combiner=combiner), trace, prep, lde_factor)
         cpu_total = time.perf_counter() - t
         assert cpu_marks == marks, ("phase digests differ", cpu_marks, marks)
         assert cpu_proof == proof, "device-resident proof differs from the CPU port's"

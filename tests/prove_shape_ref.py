@@ -112,7 +112,8 @@ def prove(ops, trace, prep, lde_factor, clock=None):
     out = [u64(len(f_at_z_m))] + [fr_bytes(v) for v in f_at_z_m] + [fr_bytes(g_at_z)]
     out += f_roots + [g_root]
     for value, path in f_queries + [g_query]:
-        out += [fr_bytes(value), u64(len(path))] + [bytes(x) for x in path]
+        vb = b"".join(fr_bytes(v) for v in value) if isinstance(value, tuple) else fr_bytes(value)
+        out += [vb, u64(len(path))] + [bytes(x) for x in path]
     out += [u64(len(ops.fri_roots(p1)))] + ops.fri_roots(p1) + [u64(len(ops.fri_roots(p2)))] + ops.fri_roots(p2)
     out += [u64(x1), u64(len(proof1)), proof1, u64(x2), u64(len(proof2)), proof2]
     # what a verifier needs besides the proof bytes: the two FRI proofs and the values the h oracles hold at the queried
@@ -129,8 +130,10 @@ def prove(ops, trace, prep, lde_factor, clock=None):
 
 # ------------------------------------------------------------------------------------------- CPU oracle ("CPU port")
 class OracleProver:
-    def __init__(self, O, F):
-        self.O, self.F = O, F
+    def __init__(self, O, F, combiner=0):
+        # combiner: 0 = the reference's tree format, 1 = COSET2 (every oracle — f, g, FRI — commits the coset
+        # {i, i + n/2} as one leaf; include/hodor_gpu.h HODOR_COMBINER_COSET2)
+        self.O, self.F, self.combiner = O, F, combiner
         self.ali, self.deep = ali.OracleOps(O), deep.OracleOps(O)
 
     def transcript(self):
@@ -159,13 +162,15 @@ class OracleProver:
         return [self.O.poly_lde(p, factor) for p in polys]
 
     def commit_all(self, ldes):
+        if self.combiner:
+            return [self.O.iop_create_coset2(l) for l in ldes]
         return [self.O.iop_create(l) for l in ldes]
 
     def root(self, nodes):
         return bytes(nodes[1])
 
     def fri_commit(self, lde, factor):
-        return self.O.fri_commit(lde, factor, 1)
+        return self.O.fri_commit(lde, factor, 1, combiner=self.combiner)
 
     def fri_roots(self, p):
         return list(p["roots"])
@@ -188,17 +193,24 @@ class OracleProver:
         size, idx = len(lde), index
         queries, roots = [], []
         for vec in [lde] + p["inter_values"]:
-            nodes = self.O.iop_create(vec)
             pair = (idx + size // 2) % size
-            for i in sorted([idx, pair]):
-                queries.append((i, array_to_ints(vec[i:i + 1])[0], self.O.iop_path(nodes, vec, i)))
+            if self.combiner:
+                nodes = self.O.iop_create_coset2(vec)
+                lo, hi = sorted([idx, pair])
+                both = array_to_ints(vec[lo:lo + 1])[0], array_to_ints(vec[hi:hi + 1])[0]
+                queries.append((lo, both, self.O.iop_path_coset2(nodes, vec, lo)))
+            else:
+                nodes = self.O.iop_create(vec)
+                for i in sorted([idx, pair]):
+                    queries.append((i, array_to_ints(vec[i:i + 1])[0], self.O.iop_path(nodes, vec, i)))
             roots.append(bytes(nodes[1]))
             nxt = size // 2
             idx = idx if idx < nxt else idx - nxt
             size = nxt
         out = u64(len(queries))
         for i, value, path in queries:
-            out += u64(i) + fr_bytes(value) + u64(len(path)) + b"".join(bytes(x) for x in path)
+            vb = b"".join(fr_bytes(v) for v in value) if isinstance(value, tuple) else fr_bytes(value)
+            out += u64(i) + vb + u64(len(path)) + b"".join(bytes(x) for x in path)
         out += u64(len(roots)) + b"".join(roots)
         fc = self.fri_final_coeffs(p)
         out += u64(len(fc)) + b"".join(fr_bytes(c) for c in fc)
@@ -206,6 +218,11 @@ class OracleProver:
 
     def query(self, nodes, lde, index):
         from oracle.oracle import array_to_ints
+        if self.combiner:
+            half = len(lde) // 2
+            k = index % half
+            return (array_to_ints(lde[k:k + 1])[0], array_to_ints(lde[k + half:k + half + 1])[0]), \
+                self.O.iop_path_coset2(nodes, lde, index)
         return array_to_ints(lde[index:index + 1])[0], self.O.iop_path(nodes, lde, index)
 
     def value_at(self, a, index):
@@ -221,8 +238,8 @@ class DeviceProver:
     """Every polynomial, LDE, tree and FRI vector stays in HBM; what crosses to the host are the 32-byte roots,
     the evaluations at z, the FRI prototypes' roots / final coefficients and the query answers."""
 
-    def __init__(self, O, ctx, stream=None):
-        self.O, self.ctx, self.stream = O, ctx, stream
+    def __init__(self, O, ctx, stream=None, combiner=0):
+        self.O, self.ctx, self.stream, self.combiner = O, ctx, stream, combiner
         self.host_round_trips = 0
         prover = self
 
@@ -272,15 +289,12 @@ class DeviceProver:
         n = ldes[0].shape[0]
         same = all(l.data_ptr() == ldes[0].data_ptr() + i * n * 32 for i, l in enumerate(ldes))
         leafs = ldes[0] if len(ldes) == 1 else (torch.cat(ldes) if not same else None)
-        nodes = torch.empty((len(ldes) * n, 32), dtype=torch.uint8, device=ldes[0].device)
-        if leafs is None:        # the batch LDE left the columns back to back: commit them where they are
-            import ctypes as C
-            from hodor_amd._lib import _dptr
-            self.ctx._chk(self.ctx.L.hodor_iop_create_batch_dev(self.ctx.h, C.c_void_p(self.stream), _dptr(ldes[0]),
-                                                                C.c_size_t(n), C.c_size_t(len(ldes)), _dptr(nodes)))
-        else:
-            self.ctx.iop_create_batch_dev(leafs, n, len(ldes), nodes, stream=self.stream)
-        return [nodes[i * n:(i + 1) * n] for i in range(len(ldes))]
+        per = n // 2 if self.combiner else n          # a COSET2 tree has n/2 entries
+        nodes = torch.empty((len(ldes) * per, 32), dtype=torch.uint8, device=ldes[0].device)
+        # (when the batch LDE left the columns back to back they are committed where they are)
+        self.ctx.iop_create_batch_combined_dev(ldes[0] if leafs is None else leafs, n, len(ldes), self.combiner, nodes,
+                                               stream=self.stream)
+        return [nodes[i * per:(i + 1) * per] for i in range(len(ldes))]
 
     def root(self, nodes):
         self.host_round_trips += 1
@@ -288,7 +302,7 @@ class DeviceProver:
 
     def fri_commit(self, lde, factor):
         self.host_round_trips += 1
-        return self.ctx.fri_commit_dev(lde, lde.shape[0], factor, 1, stream=self.stream)
+        return self.ctx.fri_commit_dev(lde, lde.shape[0], factor, 1, stream=self.stream, combiner=self.combiner)
 
     def fri_roots(self, p):
         return list(p.roots)
@@ -309,6 +323,9 @@ class DeviceProver:
 
     def query(self, nodes, lde, index):
         self.host_round_trips += 1
+        if self.combiner:
+            values, path = self.ctx.iop_query_combined_dev(lde, nodes, lde.shape[0], self.combiner, index, stream=self.stream)
+            return tuple(values), path
         return self.ctx.iop_query_dev(lde, nodes, lde.shape[0], index, stream=self.stream)
 
     def value_at(self, a, index):
