@@ -240,6 +240,10 @@ def main():
     ap.add_argument("--skip-checks", action="store_true",
                     help="ablation builds only (bench/ablate.sh): results are wrong by construction; needs "
                          "--allow-knobs and marks the line \"checks\": {\"skipped\": true}")
+    ap.add_argument("--soak-seconds", type=float, default=3.0,
+                    help="after the timed region: keep stepping for about this long (the same step, untimed for `value`), then "
+                         "re-run the round-trip gate on what the LAST step left behind; reported as `soak` (sustained ms per "
+                         "step once the part sits at its power limit, and a determinism check); 0 = skip")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="bare `python bench.py --gpus N` (N > 1, no torchrun environment): seconds each self-spawned "
                          "torch.distributed.run attempt may take")
@@ -554,6 +558,28 @@ def main():
         s_step()
         ms_strict = timed(s_step, s_drain, args.strict_steps)
 
+    # sustained load: the timed region is ~0.3 s; a few seconds more of the same steps show what the step costs once the
+    # package has settled at its power limit, make the GPU's activity visible to an outside sampler (rocm-smi reads the
+    # part a few times per run), and put the gates below on the output of the LAST of several hundred steps
+    soak = None
+    if args.backend != "nccl":
+        args.soak_seconds = min(args.soak_seconds, 0.5)      # the gloo testing aid stages every exchange through the host
+    if args.soak_seconds > 0 and not args.skip_checks:
+        per = dt / args.steps
+        count = max(1, int(args.soak_seconds / per))          # the same on every rank: dt is the max over the ranks
+        barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(count):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        barrier()
+        sd = time.perf_counter() - ts
+        if multi:
+            sd = all_reduce_scalar(sd, dist.ReduceOp.MAX)
+        soak = {"steps": count, "seconds": sd, "ms_per_step": sd / count * 1e3}
+
     if args.mode == "sixstep":
         c = holder["c"]
     # correctness gates, AFTER the timed region (the host-side hashing idles the GPU for a second: in front of the
@@ -665,6 +691,9 @@ def main():
         "knobs": knobs,
         "warmup_extra_steps": extra_warm,
     }
+    if soak:
+        soak["gates_below_ran_on_its_last_step"] = True
+        result["soak"] = soak
     if args.mode == "sixstep":
         result["pipelined_across_steps"] = bool(pipelined)
         result["ms_per_step_strict"] = ms_strict      # un-pipelined: one NTT + iNTT end to end, exchanges hidden only behind their own chunks

@@ -3,7 +3,7 @@
 # pass stores into the receive buffer), RCCL's all-to-all forced (torch.distributed and the library's own, 4 chunks,
 # pipelined across steps), and the plain single-device transform.  usage: bash bench/direct_ab.sh [rounds]
 R=${1:-2}
-COMMON="--no-cpu-baseline --no-extra --steps 60 --warmup 20"
+COMMON="--no-cpu-baseline --no-extra --soak-seconds 0 --steps 60 --warmup 20"
 ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3f ms (strict %.3f)' % (d['ms_per_step'], d.get('ms_per_step_strict', d['ms_per_step'])))"; }
 tr() { python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29500 + RANDOM % 1000)) bench.py --gpus 1 "$@" 2>/dev/null | grep '^{' | ms; }
 for i in $(seq $R); do

@@ -5,7 +5,7 @@
 VAR=$1; shift
 ROUNDS=2; VALS=()
 for a in "$@"; do case $a in x*) ROUNDS=${a#x};; *) VALS+=("$a");; esac; done
-run() { env "$VAR=$1" python bench.py --steps 30 --warmup 5 --no-cpu-baseline --allow-knobs 2>/dev/null | python -c "
+run() { env "$VAR=$1" python bench.py --steps 30 --warmup 5 --no-cpu-baseline --soak-seconds 0 --allow-knobs 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); e = d['extra']
 print('step %.3f ms  lde %.3f  commit %.3f  fri %.3f' % (d['ms_per_step'], e['lde_ms'], e['commit_ms'], e['fri_commit']['ms']))"; }

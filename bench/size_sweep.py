@@ -135,6 +135,27 @@ def main():
         if fx:
             assert ser.hex() == fx["serialized"], "FRI prototype differs from the CPU oracle"
             row["fri_commit"]["bytes_equal_cpu_oracle"] = True
+        # the same codeword in the COSET2 tree format (opt-in, HODOR_COMBINER_COSET2): commit and FRI commit
+        c2 = hodor_amd.COSET2
+        nodes2 = torch.empty((n // 2, 32), dtype=torch.uint8, device="cuda")
+        ms = timeit(lambda: ctx.iop_create_combined_dev(a, n, c2, nodes2))
+        row["commit_coset2_ms"] = ms
+        del nodes2
+        proto = ctx.fri_commit_dev(a, n, f, 1, combiner=c2)
+        ser2 = proto.serialized
+        proto.free()
+        best = 1e9
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            p = ctx.fri_commit_dev(a, n, f, 1, combiner=c2)
+            best = min(best, time.perf_counter() - t)
+            p.free()
+        row["fri_commit_coset2"] = {"ms": best * 1e3, "speedup_vs_reference_format": row["fri_commit"]["ms"] / (best * 1e3)}
+        fx2 = FIX.get("fri_coset2", {}).get(str(log_n))
+        if fx and fx2:
+            assert ser2.hex() == fx2["serialized"], "COSET2 FRI prototype differs from the CPU oracle"
+            row["fri_commit_coset2"]["bytes_equal_cpu_oracle"] = True
         del a, coeffs
         torch.cuda.empty_cache()
         rows.append(row)
