@@ -100,7 +100,8 @@ static int free_tables(hodor_ctx *ctx)
 // table: evicting later would free tables the same operation already holds pointers to.
 int trim_table_cache(hodor_ctx *ctx)
 {
-    if (ctx->pow_tables.size() > 40 || ctx->radix_tables.size() > 80) return free_tables(ctx);
+    const size_t cap = (size_t)knobs().table_cache;   // HODOR_TABLE_CACHE (40): a debugging aid — small values evict often
+    if (ctx->pow_tables.size() > cap || ctx->radix_tables.size() > 2 * cap) return free_tables(ctx);
     return HODOR_OK;
 }
 

@@ -298,6 +298,7 @@ static Knobs read_knobs()
     k.fri_tail = get("HODOR_FRI_TAIL", 1, 0, 1);
     k.fri_fuse_fold = get("HODOR_FRI_FUSE_FOLD", 1, 0, 2);
     k.batchinv_seq = get("HODOR_BATCHINV_SEQ", 8, 2, 64);
+    k.table_cache = get("HODOR_TABLE_CACHE", 40, 1, 1000);
     return k;
 }
 const Knobs &knobs()

@@ -19,6 +19,7 @@ struct Knobs {
     int fri_tail;         // HODOR_FRI_TAIL        fused tail of the FRI commit                          1
     int fri_fuse_fold;    // HODOR_FRI_FUSE_FOLD   fold inside the tree's leaf launch: 0 never, 1 always, 2 small rounds only   1
     int batchinv_seq;     // HODOR_BATCHINV_SEQ    elements per lane and level in batch inversion        8
+    int table_cache;      // HODOR_TABLE_CACHE     power tables kept per context before the cache is emptied    40
     char set[256];        // "NAME=value ..." of the variables that were present in the environment
 };
 const Knobs &knobs();

@@ -584,3 +584,40 @@ def test_bare_bench_launch_with_two_ranks_spawns_its_own_torchrun():
     assert "self-spawned" in line["launcher"]
     assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
     assert line["extra"]["lde_commit"].get("root_equals_cpu_oracle") is True
+
+
+def test_direct_exchange_misuse_and_a_missing_peer_do_not_hang(gpu_ctxs):
+    """The ordering protocol of the direct transport is bounded: a wait for a peer that never signals gives up after ~10 s
+    (one-wave kernel with a wall-clock limit) and the handle then refuses further work with HODOR_ERR_DEVICE; calls out of
+    order and unconfigured slots are refused up front."""
+    import time
+    import torch
+    import hodor_amd
+    ctx = gpu_ctxs["bn256"]
+    m = 1 << 10
+    xs = [hodor_amd.DirectExchange(ctx, 2, r, m, n_slots=2) for r in range(2)]
+    with pytest.raises(hodor_amd.HodorError):
+        xs[0].begin(0)                                   # no peers yet
+    hodor_amd.DirectExchange.connect_local(xs)
+    with pytest.raises(hodor_amd.HodorError):
+        xs[0].signal(0)                                  # signal without begin
+    with pytest.raises(hodor_amd.HodorError):
+        xs[0].release(0)                                 # release without wait
+    with pytest.raises(hodor_amd.HodorError):
+        xs[0].begin(2)                                   # no such slot
+    xs[0].begin(0)
+    xs[0].signal(0)
+    t = time.perf_counter()
+    xs[0].wait(0)                                        # rank 1 never signals generation 1
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t
+    assert 5.0 < waited < 30.0, waited
+    with pytest.raises(hodor_amd.HodorError) as e:
+        xs[0].begin(1)
+    assert e.value.code == hodor_amd._lib.ERR_DEVICE and "timed out" in str(e.value)
+    for x in xs:
+        x.close()
+    # the context is still usable
+    a = torch.zeros((8, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a, 0, 8, 1)
+    ctx.synchronize()
