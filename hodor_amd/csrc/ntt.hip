@@ -321,9 +321,20 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         __syncthreads();
     }
     if (ABL(1)) log_m = log_r;
+    // Lazy hand-over between steps (round 4): a step that is followed by a W3 step stores its four sums WITHOUT the
+    // carry propagation (limbs < 5 * 2^29: a normalized x0 plus at most two offset subtractions, < 2^30 each, and two
+    // products, < 2^29 each), and the W3 step brings in what it needs itself: x0 — only ever added to — is carried
+    // in full, so that its own sums stay below 5 * 2^29 again; x1 and x3 enter products, which need their 87-bit
+    // limb GROUPS below 2^87 (fr9_normalize_groups, 6 instructions); x2 enters two additions (limbs < 7 * 2^29 < 2^32)
+    // and is group-carried with the rest of the mid-step sums.  Column sums of those products: at most seven limbs
+    // < 7 * 2^29 and two < 3 * 2^29 times a table limb < 2^29, plus three reduction terms and the carry: < 2^64.
+    // Per item 27 + 4 x 6 carry instructions instead of 4 x 27 + 2 x 6.  The wave-uniform (W9) steps and the store
+    // phase take normalized limbs, so a step in front of them carries its sums as before.
+    bool lazy_in = false;
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
+        const bool lazy_out = A.lazy_steps && log_m + 2 < log_r && log_m + 2 >= A.w9_limit;
         if (log_m < A.w9_limit) {
             // ---- wave-uniform step: the step's twiddles take only m (<= 8) different sets of values, and the
             // items are dealt so that the 64 lanes of a wave share ONE of them (jp = twiddle index): the constants
@@ -369,10 +380,12 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 }
                 t = fr9_mul9<P1>(x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane(((jp + m) << (log_r - log_m - 2)) >> e_shift), Q);
                 x3 = fr9_sub11(x1, t, Q); x1 = fr9_add(x1, t);
-                fr9_normalize(x0);
-                fr9_normalize(x1);
-                fr9_normalize(x2);
-                fr9_normalize(x3);
+                if (!lazy_out) {
+                    fr9_normalize(x0);
+                    fr9_normalize(x1);
+                    fr9_normalize(x2);
+                    fr9_normalize(x3);
+                }
                 lds_put(D, s0, x0);
                 lds_put(D, s1, x1);
                 lds_put(D, s2, x2);
@@ -381,6 +394,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             STAMP(3 + log_m);
             __syncthreads();
             STAMP(4 + log_m);
+            lazy_in = lazy_out;
             continue;
         }
         const bool tw_global = tw_sub != 0 && log_r - log_m - 2 < tw_sub;   // finest index of this step: jp << (log_r - log_m - 2)
@@ -403,6 +417,11 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 Fr9 x3 = lds_get(D, s3);
                 Fr9 t;
                 if (m > 1) {
+                    if (lazy_in) {
+                        fr9_normalize(x0);
+                        fr9_normalize_groups(x1);
+                        fr9_normalize_groups(x3);
+                    }
                     const Fr9W3 wa = twiddle(jp << (log_r - log_m - 1));
 #ifdef HODOR_EXP_X2
                     {
@@ -440,10 +459,12 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 }
                 t = fr9_mul3<P1>(x3, twiddle((jp + m) << (log_r - log_m - 2)), Q);
                 x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
-                fr9_normalize(x0);
-                fr9_normalize(x1);
-                fr9_normalize(x2);
-                fr9_normalize(x3);
+                if (!lazy_out) {
+                    fr9_normalize(x0);
+                    fr9_normalize(x1);
+                    fr9_normalize(x2);
+                    fr9_normalize(x3);
+                }
                 lds_put(D, s0, x0);
                 lds_put(D, s1, x1);
                 lds_put(D, s2, x2);
@@ -455,6 +476,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         STAMP(3 + log_m);          // 3, 5, 7, 9: end of the arithmetic of the step with half-size 2^log_m
         __syncthreads();
         STAMP(4 + log_m);          // 4, 6, 8, 10: released from its barrier
+        lazy_in = lazy_out;
     }
 
     // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
@@ -570,6 +592,7 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     //     offset: such a step raises the bound by 22p instead of 10p; 20p instead of 14p for the twiddle-free one).
     B.w9_limit = 0;
     B.w9_skip_one = knobs().ntt_w9 >= 2 ? 1 : 0;
+    B.lazy_steps = knobs().ntt_lazy ? 1 : 0;
     if (knobs().ntt_w9 && A.rtw9 && A.log_r >= 6) {
         uint32_t lm0 = A.log_skip, bound0 = 4;
         if ((A.log_r - lm0) & 1) { lm0 += 1; bound0 = 9; }
