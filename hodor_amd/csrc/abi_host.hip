@@ -293,7 +293,6 @@ static Knobs read_knobs()
     k.ntt_tw_sub = get("HODOR_NTT_TW_SUB", 1, 0, 1);
     k.ntt_w9 = get("HODOR_NTT_W9", 2, 0, 2);
     k.ntt_p1 = get("HODOR_NTT_P1", 1, 0, 1);
-    k.ntt_lazy = get("HODOR_NTT_LAZY", 1, 0, 1);
     k.merkle_tail_log = get("HODOR_MERKLE_TAIL_LOG", 6, 0, 30);
     k.merkle_lat_log = get("HODOR_MERKLE_LAT_LOG", 19, 0, 40);
     k.fri_tail = get("HODOR_FRI_TAIL", 1, 0, 1);

@@ -14,7 +14,6 @@ struct Knobs {
     int ntt_tw_sub;       // HODOR_NTT_TW_SUB      sub-sampled LDS twiddle table (last step from L2)      1
     int ntt_w9;           // HODOR_NTT_W9          wave-uniform W9 twiddles in the first steps: 0 off, 1 on, 2 on + skip products by one   2
     int ntt_p1;           // HODOR_NTT_P1          subtraction instead of v_mul_lo for the Montgomery digit when p = 1 mod 2^29   1
-    int ntt_lazy;         // HODOR_NTT_LAZY        radix-4 steps hand lazy (un-carried) sums to a following W3 step                 1
     int merkle_tail_log;  // HODOR_MERKLE_TAIL_LOG level width at which a throughput chunk stops         6
     int merkle_lat_log;   // HODOR_MERKLE_LAT_LOG  largest level on the latency schedule                19
     int fri_tail;         // HODOR_FRI_TAIL        fused tail of the FRI commit                          1

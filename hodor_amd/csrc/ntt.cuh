@@ -61,7 +61,6 @@ struct PassArgs {
     uint32_t w9_limit;       // set by the launcher: radix-4 steps with half-size m < 2^this take their twiddles from
                              //   rtw9 (0: none), items dealt so that a wave works on ONE twiddle set
     uint32_t w9_skip_one;    // 1: a wave whose twiddle index is 0 skips the products by one
-    uint32_t lazy_steps;     // set by the launcher: a radix-4 step that is followed by a W3 step stores its sums un-carried (see k_ntt_pass)
     uint32_t tw_sub;         // set by the launcher: the LDS twiddle table holds every 2^tw_sub-th entry (see k_ntt_pass)
     uint32_t log_skip;       // first pass of a zero-padded transform: nnz == n >> log_skip (see k_ntt_pass)
     // ---- generalized layouts (k_ntt_pass<1> only; all zero for plain arrays)

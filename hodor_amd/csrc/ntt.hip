@@ -321,20 +321,28 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
         __syncthreads();
     }
     if (ABL(1)) log_m = log_r;
-    // Lazy hand-over between steps (round 4): a step that is followed by a W3 step stores its four sums WITHOUT the
-    // carry propagation (limbs < 5 * 2^29: a normalized x0 plus at most two offset subtractions, < 2^30 each, and two
-    // products, < 2^29 each), and the W3 step brings in what it needs itself: x0 — only ever added to — is carried
-    // in full, so that its own sums stay below 5 * 2^29 again; x1 and x3 enter products, which need their 87-bit
-    // limb GROUPS below 2^87 (fr9_normalize_groups, 6 instructions); x2 enters two additions (limbs < 7 * 2^29 < 2^32)
-    // and is group-carried with the rest of the mid-step sums.  Column sums of those products: at most seven limbs
-    // < 7 * 2^29 and two < 3 * 2^29 times a table limb < 2^29, plus three reduction terms and the carry: < 2^64.
-    // Per item 27 + 4 x 6 carry instructions instead of 4 x 27 + 2 x 6.  The wave-uniform (W9) steps and the store
-    // phase take normalized limbs, so a step in front of them carries its sums as before.
-    bool lazy_in = false;
+    // Lazy hand-over between steps (round 4): every radix-4 step but the last one of the pass stores its four sums
+    // WITHOUT the carry propagation (limbs < 5 * 2^29: a normalized x0 plus at most two offset subtractions, < 2^30
+    // each, and two products, < 2^29 each), and the next step brings in what it needs itself.  A W3 step carries x0 —
+    // only ever added to — in full, so that its own sums stay below 5 * 2^29 again; x1 and x3 enter products, which
+    // need their 87-bit limb GROUPS below 2^87 (fr9_normalize_groups, 6 instructions); x2 enters two additions (limbs
+    // < 7 * 2^29 < 2^32) and is group-carried with the rest of the mid-step sums.  Column sums of those products: at
+    // most seven limbs < 7 * 2^29 and two < 2^29 times a table limb < 2^29, plus three reduction terms and the carry:
+    // < 55 * 2^58 < 2^64 (replayed with the worst limbs in tests/test_lazy_step_bounds_cpu.py).  Per item 27 + 4 x 6
+    // carry instructions instead of 4 x 27 + 2 x 6.  A wave-uniform (W9) step multiplies limb by limb and carries x0,
+    // x1 and x3 in full (3 x 27 instead of 4 x 27).  The store phase takes normalized limbs: the last step carries its
+    // sums.  Which form a step has is decided at COMPILE time (the W3 step exists with and without the final carry, a
+    // W9 step is never the last one): with run-time flags the extra live SGPRs and branches cost what the carries save
+    // (profiles/r04/lazy_ab.txt).  -DHODOR_NO_LAZY builds the round-3 hand-over for A/B runs.
+#ifdef HODOR_NO_LAZY
+    constexpr bool LAZY = false;
+#else
+    constexpr bool LAZY = true;
+#endif
+    const uint32_t first_lm = log_m;   // the step that reads what the load phase (or the radix-2 stage) stored: normalized
     for (; log_m < log_r; log_m += 2) {   // radix-4 step = stages with half-size m and 2m
         const uint32_t m = 1u << log_m;
         const uint32_t items = (R >> 2) << log_c;
-        const bool lazy_out = A.lazy_steps && log_m + 2 < log_r && log_m + 2 >= A.w9_limit;
         if (log_m < A.w9_limit) {
             // ---- wave-uniform step: the step's twiddles take only m (<= 8) different sets of values, and the
             // items are dealt so that the 64 lanes of a wave share ONE of them (jp = twiddle index): the constants
@@ -358,6 +366,11 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 Fr9 x2 = lds_get(D, s2);
                 Fr9 x3 = lds_get(D, s3);
                 Fr9 t;
+                if (LAZY && log_m != first_lm) {
+                    fr9_normalize(x0);
+                    fr9_normalize(x1);
+                    fr9_normalize(x3);
+                }
                 const bool ones = jp == 0 && (m == 1 || A.w9_skip_one);   // wa = wb = 1 (wave-uniform branch)
                 if (!ones) {
                     fr9_mul9x2<P1>(x1, x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 1)) >> e_shift), Q);
@@ -380,7 +393,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 }
                 t = fr9_mul9<P1>(x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane(((jp + m) << (log_r - log_m - 2)) >> e_shift), Q);
                 x3 = fr9_sub11(x1, t, Q); x1 = fr9_add(x1, t);
-                if (!lazy_out) {
+                if (!LAZY) {   // (a W9 step is never the last step of a pass: ntt_launch_pass)
                     fr9_normalize(x0);
                     fr9_normalize(x1);
                     fr9_normalize(x2);
@@ -394,12 +407,12 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
             STAMP(3 + log_m);
             __syncthreads();
             STAMP(4 + log_m);
-            lazy_in = lazy_out;
             continue;
         }
         const bool tw_global = tw_sub != 0 && log_r - log_m - 2 < tw_sub;   // finest index of this step: jp << (log_r - log_m - 2)
-        auto step_items = [&](auto from_global) {
+        auto step_items = [&](auto from_global, auto carry_out) {
             constexpr bool G = decltype(from_global)::value;
+            constexpr bool CARRY_OUT = decltype(carry_out)::value;   // last step of the pass (or a HODOR_NO_LAZY build)
             auto twiddle = [&](uint32_t idx) -> Fr9W3 {
                 if constexpr (G) return fr9w3_load(A.rtw + 7 * idx);
                 else return fr9w3_load(T + 7 * (idx >> tw_sub));
@@ -417,7 +430,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 Fr9 x3 = lds_get(D, s3);
                 Fr9 t;
                 if (m > 1) {
-                    if (lazy_in) {
+                    if (LAZY) {   // (also when this is the pass's first radix-4 step and the limbs are normalized already)
                         fr9_normalize(x0);
                         fr9_normalize_groups(x1);
                         fr9_normalize_groups(x3);
@@ -459,7 +472,7 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 }
                 t = fr9_mul3<P1>(x3, twiddle((jp + m) << (log_r - log_m - 2)), Q);
                 x3 = fr9_sub5(x1, t, Q); x1 = fr9_add(x1, t);
-                if (!lazy_out) {
+                if (CARRY_OUT) {
                     fr9_normalize(x0);
                     fr9_normalize(x1);
                     fr9_normalize(x2);
@@ -471,12 +484,14 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
                 lds_put(D, s3, x3);
             }
         };
-        if (tw_global) step_items(std::true_type{});
-        else step_items(std::false_type{});
+        // three forms: a step that is followed by another one reads the LDS twiddle table (its indices are multiples
+        // of 2^tw_sub, see the launcher) and stores lazy sums; the last step reads the LDS or the global table
+        if (LAZY && log_m + 2 < log_r && !tw_global) step_items(std::false_type{}, std::false_type{});
+        else if (tw_global) step_items(std::true_type{}, std::true_type{});
+        else step_items(std::false_type{}, std::true_type{});
         STAMP(3 + log_m);          // 3, 5, 7, 9: end of the arithmetic of the step with half-size 2^log_m
         __syncthreads();
         STAMP(4 + log_m);          // 4, 6, 8, 10: released from its barrier
-        lazy_in = lazy_out;
     }
 
     // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
@@ -592,7 +607,6 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     //     offset: such a step raises the bound by 22p instead of 10p; 20p instead of 14p for the twiddle-free one).
     B.w9_limit = 0;
     B.w9_skip_one = knobs().ntt_w9 >= 2 ? 1 : 0;
-    B.lazy_steps = knobs().ntt_lazy ? 1 : 0;
     if (knobs().ntt_w9 && A.rtw9 && A.log_r >= 6) {
         uint32_t lm0 = A.log_skip, bound0 = 4;
         if ((A.log_r - lm0) & 1) { lm0 += 1; bound0 = 9; }
@@ -604,6 +618,7 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
                 if (w9) {
                     any = true;
                     if (A.log_r - 2 + A.log_c < 6 + lm) ok = false;          // fewer than 64 items per twiddle index
+                    if (lm + 2 >= A.log_r) ok = false;                        // never the last step (it stores lazy sums)
                 }
                 if (lm == 0) bound = w9 ? 20 : 14;
                 else bound += w9 ? 22 : 10;

@@ -31,10 +31,9 @@ SETTINGS = [
     ({"HODOR_NTT_W9": "1", "HODOR_NTT_P1": "0"}, "8,9,16,17", "16:4:1"),
     ({"HODOR_NTT_THREADS": "96", "HODOR_MAX_LOG_R": "8"}, "8,12,16"),
     ({"HODOR_NTT_THREADS": "200", "HODOR_NTT_P1": "0"}, "9,13,17"),
-    # the lazy hand-over between radix-4 steps off (every step carries its sums), alone and with the W9 steps off (then
-    # every step after the first is a W3 step and the default build hands over lazily three times per radix-256 pass)
-    ({"HODOR_NTT_LAZY": "0"}, "8,9,16,17", "16:2:1"),
-    ({"HODOR_NTT_LAZY": "0", "HODOR_NTT_W9": "0", "HODOR_MAX_LOG_R": "10"}, "10,12,17"),
+    # W9 steps off: every step after the first is a W3 step and takes the lazy (un-carried) sums of the one before it,
+    # three or four hand-overs per pass at radix 2^10 / 2^11
+    ({"HODOR_NTT_W9": "0", "HODOR_MAX_LOG_R": "10"}, "10,12,17"),
     ({"HODOR_NTT_W9": "0", "HODOR_MAX_LOG_R": "11", "HODOR_TILE_LOG": "11"}, "11,15,17"),
 ]
 

@@ -171,3 +171,16 @@ def test_normalized_step_output_is_the_same_value(name):
         x = worst_lazy(rng.randrange(40 * p, 62 * p), 5, rng)
         y = normalize(x)
         assert value_of(y) == value_of(x) and max(y[:8]) < U and y[8] < (1 << 29)
+
+
+@pytest.mark.parametrize("name", sorted(FIELDS))
+def test_offsets_leave_room_for_a_lazy_minuend(name):
+    """A wave-uniform (W9) step that receives lazy sums carries x0, x1 and x3 in full and leaves x2 as it is: x2 only
+    enters `x2 + t` and `x2 + (c11p - t)` before the mid-step carry.  The spread offsets are below 2^30 in limbs 0..7
+    (abi.hip), so both stay below 7 * 2^29 < 2^32; its own outputs are a normalized x0 plus two such terms: < 5 * 2^29."""
+    p = FIELDS[name]
+    for k in (5, 11):
+        c = spread(k * p)
+        assert max(c[:8]) < (1 << 30) and min(c[:8]) >= U - 1
+        assert 5 * U + max(c[:8]) < 7 * U
+        assert U + 2 * max(c[:8]) <= 5 * U
