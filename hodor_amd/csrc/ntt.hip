@@ -196,10 +196,22 @@ __device__ __forceinline__ uint64_t split_index(const SplitAddr &S, uint64_t x, 
 // MODE 0: plain arrays (every transform of the single-GPU API).  MODE 1: the same pass with the
 // generalized layouts of PassArgs (column mode, 2D twiddle, split addressing) compiled in.
 // P1: modulus = 1 mod 2^29 (fr9_mont_digit): chosen by the launcher from Fr9Params::pinv.
+// All arguments of the pass as ONE kernel argument, so that the store phase can read its own from the kernel-argument
+// segment when it gets there (`late` below) instead of holding them in SGPRs (spilled to VGPR lanes) through the whole pass.
+struct PassKArgs {
+    PassArgs A;
+    Fr9 scale;
+    uint32_t has_scale;
+    Fr9Params Q;
+};
+typedef const __attribute__((address_space(4))) PassKArgs *PassKArgsLate;
+
 template <int MODE, bool P1>
 __global__ void __launch_bounds__(NTT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
-k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
+k_ntt_pass(PassKArgs K)
 {
+    const PassArgs &A = K.A;
+    const Fr9Params &Q = K.Q;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t log_r = A.log_r, log_c = A.log_c;
@@ -242,7 +254,6 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     // independent size-n arrays — or, in column mode, the tile's first array column
     const uint32_t by = blockIdx.z * gridDim.y + blockIdx.y;
     const uint4 *src_b = A.src + 2ull * by * A.src_batch_stride;   // first LDE pass: n/f apart
-    uint4 *dst_b = A.dst + ((2ull * by) << A.log_n);
     const uint64_t n_over_r = 1ull << (A.log_n - log_r);
     const bool colm = MODE == 1 && A.col_mode;
     const uint64_t colbase = colm ? ((uint64_t)by << log_c) : 0;   // first array column of this tile
@@ -495,49 +506,84 @@ k_ntt_pass(PassArgs A, Fr9 scale, uint32_t has_scale, Fr9Params Q)
     }
 
     // ---- store: LDS -> (scale, post-scale) -> reduce -> global, Stockham output index
-    const bool transposed = (A.log_l == 0) && !colm;   // first pass: outputs of one sub-transform are contiguous
-    const bool last = (A.log_l + log_r == A.log_n);
+    // What only this phase needs (destination, output scalings, the reduction's constants, the 4-step layouts) is read
+    // from the kernel-argument segment HERE: the compiler loads by-value kernel arguments in the entry block, and with
+    // the SGPR file full through the butterfly steps those that are used last spend the pass in VGPR lanes
+    // (v_writelane / v_readlane).  The empty asm makes the segment's address opaque, so these loads cannot be merged
+    // with (or hoisted to) the entry block's.
+#ifdef HODOR_NO_LATE_ARGS
+    const PassKArgs *const late = &K;
+#else
+    uint64_t kseg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kseg));
+    const PassKArgsLate late = (PassKArgsLate)kseg;
+#endif
+    const uint32_t s_log_l = late->A.log_l, s_log_n = late->A.log_n;
+    const uint64_t s_lmask = (1ull << s_log_l) - 1;
+    uint4 *const s_dst = late->A.dst;
+    uint4 *const s_dst_b = s_dst + ((2ull * by) << s_log_n);
+    const TwoLevel s_post = {late->A.post.lo, late->A.post.hi, late->A.post.lo_bits};
+    Fr9Params QS;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { QS.p[k] = Q.p[k]; QS.c4p[k] = 0; QS.c5p[k] = 0; QS.c11p[k] = 0; }
+    QS.pinv = Q.pinv;
+    QS.mu = late->Q.mu;
+    QS.red_shift = late->Q.red_shift;
+    const bool s_has_scale = late->has_scale != 0;
+    Fr9 s_scale;
+#pragma unroll
+    for (int k = 0; k < 9; k++) s_scale.v[k] = s_has_scale ? late->scale.v[k] : 0u;
+    const bool transposed = (s_log_l == 0) && !colm;   // first pass: outputs of one sub-transform are contiguous
+    const bool last = (s_log_l + log_r == s_log_n);
     for (uint32_t e = tid; e < tile; e += nthreads) {
         uint32_t c, cc;
         if (transposed) { cc = e & (R - 1); c = e >> log_r; }
         else            { c = e & (C - 1);  cc = e >> log_c; }
         uint64_t j = colm ? j0 : j0 + c;
-        uint64_t p = j & Lmask;
-        uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << A.log_l);
+        uint64_t p = j & s_lmask;
+        uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << s_log_l);
         Fr9 x = lds_get(D, SLOT(cc, c));
-        if (has_scale) x = fr9_mul(x, scale, Q);
-        if (A.post.lo != nullptr) x = mul_two_level<P1>(x, A.post, o, false, Q);
-        if (MODE == 1 && colm && A.tw2d.lo != nullptr && !A.tw2d_on_load)
-            x = mul_two_level<P1>(x, A.tw2d, o * (A.col0 + colbase + c), false, Q);
+        if (s_has_scale) x = fr9_mul(x, s_scale, QS);
+        if (s_post.lo != nullptr) x = mul_two_level<P1>(x, s_post, o, false, QS);
+        if (MODE == 1 && colm && late->A.tw2d.lo != nullptr && !late->A.tw2d_on_load) {
+            const TwoLevel t2 = {late->A.tw2d.lo, late->A.tw2d.hi, late->A.tw2d.lo_bits};
+            x = mul_two_level<P1>(x, t2, o * (late->A.col0 + colbase + c), false, QS);
+        }
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y;
         if (ABL(32) && !last) {                   // ... and no reduction / pack on the way out
 #pragma unroll
             for (int k = 0; k < 8; k++) y.v[k] = x.v[k];
         } else {
-            y = last ? fr9_to_canonical<true>(x, Q) : fr9_to_packed<true>(x, Q);
+            y = last ? fr9_to_canonical<true>(x, QS) : fr9_to_packed<true>(x, QS);
         }
         if (ABL(8) && y.v[0] != 0x12345u) continue;
         // streaming stores: the output crosses the chip once and should not push the twiddle tables out of L2
         // (-1 % on the 2^24 step; streaming LOADS of the data measured +0.8 %)
-        if (MODE == 1 && A.peer_tab != nullptr) {
+        if (MODE == 1 && late->A.peer_tab != nullptr) {
             // direct exchange: the slab this element belongs to lives in another rank's receive buffer
             uint64_t t, at;
+            const uint32_t peer_self = late->A.peer_self;
             if (colm) {
-                t = o >> A.peer_log;
-                const uint64_t row = ((uint64_t)A.peer_self << A.peer_log) + (o & ((1ull << A.peer_log) - 1));
-                at = (row << A.dst_log_width) + A.dst_col_off + colbase + c;
+                const uint32_t peer_log = late->A.peer_log;
+                t = o >> peer_log;
+                const uint64_t row = ((uint64_t)peer_self << peer_log) + (o & ((1ull << peer_log) - 1));
+                at = (row << late->A.dst_log_width) + late->A.dst_col_off + colbase + c;
             } else {
-                const SplitAddr &S = A.dst_split;
-                t = o >> S.hi_log;
-                at = A.peer_self * S.stride_hi + ((o >> S.lo_log) & S.mid_mask) * S.stride_mid + by * S.batch_stride +
-                     (o & ((1ull << S.lo_log) - 1));
+                const uint32_t hi_log = late->A.dst_split.hi_log, lo_log = late->A.dst_split.lo_log;
+                t = o >> hi_log;
+                at = peer_self * late->A.dst_split.stride_hi + ((o >> lo_log) & late->A.dst_split.mid_mask) * late->A.dst_split.stride_mid +
+                     by * late->A.dst_split.batch_stride + (o & ((1ull << lo_log) - 1));
             }
-            uint4 *base = reinterpret_cast<uint4 *>(A.peer_tab[t]);
-            fr_store_nt(base + 2 * (A.peer_off + at), y);
-        } else if (MODE == 1 && colm) fr_store_nt(A.dst + 2 * ((o << A.dst_log_width) + A.dst_col_off + colbase + c), y);
-        else if (MODE == 1 && A.dst_split.on) fr_store_nt(A.dst + 2 * split_index(A.dst_split, o, by), y);
-        else fr_store_nt(dst_b + 2 * o, y);
+            uint4 *base = reinterpret_cast<uint4 *>(late->A.peer_tab[t]);
+            fr_store_nt(base + 2 * (late->A.peer_off + at), y);
+        } else if (MODE == 1 && colm) fr_store_nt(s_dst + 2 * ((o << late->A.dst_log_width) + late->A.dst_col_off + colbase + c), y);
+        else if (MODE == 1 && late->A.dst_split.on) {
+            SplitAddr S;
+            S.on = 1; S.lo_log = late->A.dst_split.lo_log; S.hi_log = late->A.dst_split.hi_log; S.mid_mask = late->A.dst_split.mid_mask;
+            S.stride_mid = late->A.dst_split.stride_mid; S.stride_hi = late->A.dst_split.stride_hi; S.batch_stride = late->A.dst_split.batch_stride;
+            fr_store_nt(s_dst + 2 * split_index(S, o, by), y);
+        } else fr_store_nt(s_dst_b + 2 * o, y);
     }
     STAMP(11);
 }
@@ -649,10 +695,15 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     const bool p1 = knobs().ntt_p1 && Q.pinv == HODOR_M29;
     const dim3 g3((unsigned)grid, (unsigned)grid_y, grid_z);
     const uint32_t hs = scale ? 1u : 0u;
-    if (general && p1) hipLaunchKernelGGL((k_ntt_pass<1, true>), g3, dim3(threads), lds, stream, B, s, hs, Q);
-    else if (general)  hipLaunchKernelGGL((k_ntt_pass<1, false>), g3, dim3(threads), lds, stream, B, s, hs, Q);
-    else if (p1)       hipLaunchKernelGGL((k_ntt_pass<0, true>), g3, dim3(threads), lds, stream, B, s, hs, Q);
-    else               hipLaunchKernelGGL((k_ntt_pass<0, false>), g3, dim3(threads), lds, stream, B, s, hs, Q);
+    PassKArgs K;
+    K.A = B;
+    K.scale = s;
+    K.has_scale = hs;
+    K.Q = Q;
+    if (general && p1) hipLaunchKernelGGL((k_ntt_pass<1, true>), g3, dim3(threads), lds, stream, K);
+    else if (general)  hipLaunchKernelGGL((k_ntt_pass<1, false>), g3, dim3(threads), lds, stream, K);
+    else if (p1)       hipLaunchKernelGGL((k_ntt_pass<0, true>), g3, dim3(threads), lds, stream, K);
+    else               hipLaunchKernelGGL((k_ntt_pass<0, false>), g3, dim3(threads), lds, stream, K);
     return hipGetLastError();
 }
 
