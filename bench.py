@@ -945,7 +945,36 @@ def extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_redu
         del out
     ms = total / reps * 1e3
     alg_bytes = n * 32 + big * 32 + big * 32      # read coeffs + write LDE + write nodes, whole job
-    return {"workload": "LDE x8 of 2^22 + BLAKE2s Merkle commit (BASELINE config[2]) over %d ranks: cosets dealt to the "
+    # the same job with COSET2 trees (opt-in format): paired blocks out of the interleave, COSET2 subtrees, the same
+    # all-gather (hodor_amd/distributed.py); reported only if the root is the CPU oracle's committed COSET2 root
+    coset2 = None
+    if "coset2_root" in fx and n % (2 * world) == 0:
+        try:
+            def run2():
+                return lde_commit_by_cosets_distributed(nb, tb, coeffs, LDE_LOG_N, LDE_FACTOR, omega_big, rank, world, combiner=1)
+            _, root2, _, _ = run2()
+            torch.cuda.synchronize()
+            good2 = 1.0 if bytes(root2).hex() == fx["coset2_root"] else 0.0
+            if all_reduce_scalar(good2, dist.ReduceOp.MIN) < 0.5:
+                coset2 = {"error": "COSET2 root differs from the CPU oracle's"}
+            else:
+                total2 = 0.0
+                for _ in range(reps):
+                    barrier()
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    out = run2()
+                    torch.cuda.synchronize()
+                    barrier()
+                    total2 += all_reduce_scalar(time.perf_counter() - t, dist.ReduceOp.MAX)
+                    del out
+                coset2 = {"workload": "the same job with COSET2 trees: paired blocks, COSET2 subtrees, one all-gather "
+                                      "(opt-in format, not the reference's bytes)",
+                          "ms": total2 / reps * 1e3, "root": fx["coset2_root"], "root_equals_cpu_oracle": True}
+        except Exception as exc:   # noqa: BLE001
+            coset2 = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+    return {"coset2": coset2,
+            "workload": "LDE x8 of 2^22 + BLAKE2s Merkle commit (BASELINE config[2]) over %d ranks: cosets dealt to the "
                         "ranks, one all-to-all interleave, subtree commit + 32-byte all-gather" % world,
             "scaling": "strong", "ms": ms,
             "lde_commit_gib_per_s": alg_bytes / 2**30 / (ms * 1e-3),

@@ -286,3 +286,60 @@ def test_coset2_repeated_commits_are_identical(gpu_ctxs, log_code):
                   p.tree_nodes(step, n >> (step + 2)).tobytes()))
         p.free()
     assert len(seen) == 1
+
+
+# ---------------------------------------------------------------- COSET2 trees across ranks (hodor_amd/distributed.py)
+@pytest.mark.parametrize("coset", [False, True])
+def test_coset2_commit_by_cosets_single_rank_on_device(gpu_ctxs, oracles, coset):
+    """lde_commit_by_cosets_distributed(combiner=COSET2) with the HIP backends at world = 1: the values are the fused LDE's
+    (a paired block of ONE rank is the natural order) and the tree is the single-device COSET2 tree."""
+    import torch
+    from hodor_amd.distributed import HipTreeBackend, lde_commit_by_cosets_distributed
+    from hodor_amd.sixstep import HipBackend
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    log_n, factor = 14, 8
+    n = 1 << log_n
+    coeffs = O.random_elements(n, 31337)
+    d = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    _, _, Omega = O.domain(n * factor)
+    shift = O.const("generator") if coset else None
+    lde, root, nodes, top = lde_commit_by_cosets_distributed(HipBackend(ctx), HipTreeBackend(ctx), d, log_n, factor,
+                                                             Omega, 0, 1, coset_shift=shift, combiner=1)
+    ctx.synchronize()
+    exp = O.poly_lde(coeffs, factor, coset)
+    assert np.array_equal(lde.cpu().numpy().view(np.uint64), exp)
+    exp_nodes = O.iop_create_coset2(exp)
+    assert root == bytes(exp_nodes[1]) and np.array_equal(nodes.cpu().numpy()[1:], exp_nodes[1:])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_coset2_subtrees_of_paired_blocks_compose_the_global_tree(gpu_ctxs, oracles, world):
+    """The device side of the multi-rank COSET2 commit with the ranks played one after the other (the exchange that
+    hands out the paired blocks runs for real in tests/test_sixstep_cpu.py): the COSET2 tree that rank d builds over its
+    paired block — natural values [d B/2, (d+1) B/2) then N/2 + the same — is subtree d of the single-device COSET2 tree,
+    node for node, and the P roots hash up to its root."""
+    import torch
+    from hodor_amd.distributed import HipTreeBackend, global_node_index
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    big = 1 << 13
+    values = O.random_elements(big, 4242)
+    nodes = O.iop_create_coset2(values)
+    tb = HipTreeBackend(ctx)
+    hb = big // world // 2
+    roots = []
+    for r in range(world):
+        block = np.concatenate([values[r * hb:(r + 1) * hb], values[big // 2 + r * hb:big // 2 + (r + 1) * hb]])
+        ln = tb.tree(torch.from_numpy(block.view(np.int64)).cuda(), 1)
+        ctx.synchronize()
+        ln = ln.cpu().numpy()
+        assert ln.shape[0] == hb
+        w = hb // 2
+        while w >= 1:
+            idx = [global_node_index(w + j, w, r, world) for j in range(w)]
+            assert np.array_equal(ln[w:2 * w], nodes[idx]), (r, w)
+            w //= 2
+        roots.append(bytes(ln[1]))
+    level = roots
+    while len(level) > 1:
+        level = [ctx.hash_node(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+    assert level[0] == bytes(nodes[1])

@@ -397,6 +397,8 @@ def test_bench_multi_rank_extras_with_ranks_sharing_the_gpu(world, log_n, big):
     assert line["pipelined_across_steps"] is True and line["ms_per_step_strict"] > 0
     lde = line["extra"]["lde_commit"]
     assert lde.get("root_equals_cpu_oracle") is True and lde["root"] == FULL["lde"]["22"]["root"], lde
+    # ... and the same job with COSET2 trees: paired blocks out of the interleave, the committed COSET2 root
+    assert lde["coset2"].get("root_equals_cpu_oracle") is True and lde["coset2"]["root"] == FULL["lde"]["22"]["coset2_root"], lde
     c4 = line["extra"]["config4"]
     assert c4["checks"]["roundtrip"] is True and c4["checks"]["output_points_vs_direct_evaluation"] == 2, c4
     assert c4["checks"].get("fft_digest_vs_cpu_oracle") is True

@@ -96,9 +96,9 @@ class OracleTreeBackend:
     def __init__(self, O):
         self.O = O
 
-    def tree(self, leafs):
+    def tree(self, leafs, combiner=0):
         arr = np.ascontiguousarray(leafs.numpy().view(np.uint64))
-        return torch.from_numpy(self.O.iop_create(arr))
+        return torch.from_numpy(self.O.iop_create_coset2(arr) if combiner else self.O.iop_create(arr))
 
     def hash_node(self, left, right):
         return self.O.hash_node(left, right)
@@ -188,6 +188,56 @@ def test_lde_by_cosets_distributed_matches_single_device(world, log_n, factor, c
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_coset_worker, args=(world, _free_port(), log_n, factor, coset, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r] == (True, True, True, True), (r, ret[r])
+
+
+# ---------------------------------------------------------------- COSET2 trees across ranks: paired blocks
+def _coset2_worker(rank, world, port, log_n, factor, coset, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hodor_amd.distributed import global_node_index, lde_commit_by_cosets_distributed
+        be = OracleBackend()
+        O = be.O
+        n = 1 << log_n
+        big = n * factor
+        coeffs = O.random_elements(n, 1717)
+        _, _, Omega = O.domain(big)
+        shift = O.const("generator") if coset else None
+        d = torch.from_numpy(coeffs.copy().view(np.int64))
+        lde_block, root, local_nodes, top = lde_commit_by_cosets_distributed(
+            be, OracleTreeBackend(O), d, log_n, factor, Omega, rank, world, coset_shift=shift, combiner=1)
+        full = O.poly_lde(coeffs, factor, coset)
+        nodes = O.iop_create_coset2(full)                     # the single-device COSET2 tree: big / 2 leaves
+        hb = big // world // 2                                # half a block
+        exp_block = np.concatenate([full[rank * hb:(rank + 1) * hb], full[big // 2 + rank * hb:big // 2 + (rank + 1) * hb]])
+        ok_lde = np.array_equal(lde_block.numpy().view(np.uint64), exp_block)
+        ok_root = root == bytes(nodes[1])
+        ok_top = all(top[g] == bytes(nodes[g]) for g in top)
+        ln = local_nodes.numpy()
+        ok_nodes = ln.shape[0] == hb
+        w = hb // 2
+        while w >= 1:
+            for j in range(w):
+                ok_nodes &= bytes(ln[w + j]) == bytes(nodes[global_node_index(w + j, w, rank, world)])
+            w //= 2
+        ret[rank] = (ok_lde, ok_root, ok_top, ok_nodes)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,factor,coset", [(2, 5, 4, False), (2, 4, 8, True), (4, 6, 8, False), (4, 5, 4, True),
+                                                      (1, 4, 4, False)])
+def test_coset2_commit_by_cosets_distributed_matches_single_device(world, log_n, factor, coset):
+    """The opt-in COSET2 tree format over the ranks of a node: the LDE by cosets hands out PAIRED blocks (both members of
+    every combined leaf on one rank), each rank builds the COSET2 subtree of its chunk of leaves, one all-gather of the
+    roots: values, every local node, the replicated top levels and the root equal the single-device COSET2 tree's."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_coset2_worker, args=(world, _free_port(), log_n, factor, coset, ret), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
         assert ret[r] == (True, True, True, True), (r, ret[r])
