@@ -215,14 +215,17 @@ def main():
                          "testing aid that stages every exchange through the host, so that several ranks can share "
                          "ONE GPU and the whole multi-rank path can be exercised on a single-GPU box (the line is "
                          "then marked \"backend\": \"gloo\" and is not a measurement)")
-    ap.add_argument("--exchange", choices=["torch", "native", "direct"], default="torch",
+    ap.add_argument("--exchange", choices=["torch", "native", "direct", "copy"], default="torch",
                     help="who runs the all-to-alls of the 4-step schedule: 'torch' = torch.distributed (all_to_all_single, "
                          "async); 'native' = the library's own exchange behind the C ABI (hodor_sixstep_exchange_dev: "
                          "grouped ncclSend/ncclRecv on a communicator and communication stream it owns — what a Rust "
                          "caller links); needs RCCL and one GPU per rank; 'direct' = no all-to-all at all: every rank maps "
                          "every rank's receive buffers (hipIpc handles, shipped once over the control group) and the "
                          "producing transform's last pass stores each slab straight into the buffer of the rank it is for "
-                         "(hodor_sixstep_columns_direct_dev / _rows_direct_dev) — no copy kernel competing for CUs, no chunks")
+                         "(hodor_sixstep_columns_direct_dev / _rows_direct_dev) — no copy kernel competing for CUs, no chunks; "
+                         "'copy' = the same mapped buffers and flags, but the chunked schedule's local send pieces are moved by "
+                         "device-to-device copies on the handle's own stream (hodor_exchange_direct_copy_dev: SDMA between "
+                         "devices, wire time spread over the step)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sixstep with collectives: finish each step's inverse transform before the next step's forward "
                          "transform starts (default: the inverse of step i and the forward of step i+1 — independent, "
@@ -385,13 +388,13 @@ def main():
                 native = hodor_amd.Exchange.over_process_group(ctx, rank, world, group=ctl["group"])
                 torch.cuda.synchronize()
         direct = None
-        if args.exchange == "direct":
+        if args.exchange in ("direct", "copy"):
             direct = hodor_amd.DirectExchange(ctx, world, rank, n, n_slots=4)
             if world == 1:
                 hodor_amd.DirectExchange.connect_local([direct])
             else:
                 direct.connect_processes(ctl["group"])
-        be = HipBackend(ctx, stream=stream, exchange=native, direct=direct)
+        be = HipBackend(ctx, stream=stream, exchange=native, direct=direct, direct_copy=(args.exchange == "copy"))
         if world > 1:
             # the generator's natural block -> this rank's column block (layout A): pack + one exchange, untimed
             from hodor_amd.sixstep import natural_to_a
@@ -400,7 +403,7 @@ def main():
         pipelined = (world > 1 or args.force_collectives) and not args.no_pipeline
         # chunks: each costs a little arithmetic (shorter launches); pipelined, an exchange also hides behind the
         # other transform's arithmetic, so 4 pieces are enough at any N
-        chunks = args.exchange_chunks or (1 if (world == 1 or direct is not None) else (4 if (world == 2 or pipelined) else 8))
+        chunks = args.exchange_chunks or (1 if (world == 1 or args.exchange == "direct") else (4 if (world == 2 or pipelined) else 8))
         log_chunks = chunks.bit_length() - 1
         assert 1 << log_chunks == chunks, "--exchange-chunks must be a power of two"
 
@@ -619,7 +622,9 @@ def main():
         torch.cuda.synchronize()
         sent = n * 32 * (world - 1) / world
         ms = e0.elapsed_time(e1) / reps
-        exchange = {"transport": ("direct: the producing pass stores each slab into the peer's receive buffer (C ABI: "
+        exchange = {"transport": ("copy engines: the chunked schedule's send pieces copied into the peers' mapped receive buffers on the "
+                                  "handle's own stream (C ABI: hodor_exchange_direct_copy_dev, the direct transport's flags)" if args.exchange == "copy" else
+                                  "direct: the producing pass stores each slab into the peer's receive buffer (C ABI: "
                                   "hodor_sixstep_columns_direct_dev / _rows_direct_dev, no all-to-all, no copy)" if direct is not None else
                                   "C ABI: hodor_sixstep_exchange_dev (grouped ncclSend/ncclRecv on the library's stream)"
                                   if native is not None else "torch.distributed all_to_all_single (async)"),
@@ -672,7 +677,7 @@ def main():
         "higher_is_better": True,
         "scaling": "replicas-fallback" if fallback and args.mode == "replicas" else "weak",
         "mode": args.mode if world > 1 or args.mode == "sixstep" else "single",
-        "collective_on_data_path": bool(args.mode == "sixstep" and (world > 1 or args.force_collectives) and args.exchange != "direct"),
+        "collective_on_data_path": bool(args.mode == "sixstep" and (world > 1 or args.force_collectives) and args.exchange not in ("direct", "copy")),
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",

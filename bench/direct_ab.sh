@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box comparison of the 4-step step at world 1 (2^24 points): no exchange at all, the direct transport (the producing
-# pass stores into the receive buffer), RCCL's all-to-all forced (torch.distributed and the library's own, 4 chunks,
+# pass stores into the receive buffer), the copy-engine variant (on ONE device its copies are blit kernels, not SDMA), RCCL's all-to-all forced (torch.distributed and the library's own, 4 chunks,
 # pipelined across steps), and the plain single-device transform.  usage: bash bench/direct_ab.sh [rounds]
 R=${1:-2}
 COMMON="--no-cpu-baseline --no-extra --soak-seconds 0 --steps 60 --warmup 20"
@@ -10,6 +10,7 @@ for i in $(seq $R); do
   echo "single-device transform      : $(python bench.py $COMMON 2>/dev/null | ms)"
   echo "4-step, no exchange          : $(python bench.py --mode sixstep $COMMON 2>/dev/null | ms)"
   echo "4-step, direct transport     : $(python bench.py --mode sixstep --exchange direct $COMMON 2>/dev/null | ms)"
+  echo "4-step, copy engines, 4 chunks: $(tr --mode sixstep --force-collectives --exchange copy --exchange-chunks 4 $COMMON)"
   echo "4-step, RCCL (torch), forced : $(tr --mode sixstep --force-collectives $COMMON)"
   echo "4-step, RCCL (native), forced: $(tr --mode sixstep --force-collectives --exchange native $COMMON)"
 done

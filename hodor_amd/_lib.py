@@ -49,6 +49,7 @@ EXPORTS = [
     "hodor_poly_batch_inversion_dev", "hodor_poly_evaluate_at_dev", "hodor_gen_elements_dev",
     "hodor_sixstep_columns_dev", "hodor_sixstep_rows_dev", "hodor_sixstep_pack_dev", "hodor_transpose_dev",
     "hodor_iop_create_dev", "hodor_iop_query_dev", "hodor_fri_produce_proof", "hodor_fri_commit_dev", "hodor_fri_verify_proof", "hodor_fri_verify_proof_strict", "hodor_fri_verify_prototype",
+    "hodor_exchange_direct_copy_dev",
     "hodor_iop_create_combined", "hodor_hash_leaf_combined", "hodor_iop_path_combined", "hodor_iop_verify_combined",
     "hodor_iop_create_combined_dev", "hodor_iop_create_batch_combined_dev", "hodor_iop_query_combined_dev", "hodor_fri_commit_combined",
     "hodor_fri_commit_combined_dev", "hodor_fri_combiner", "hodor_fri_verify_proof_combined",
@@ -433,6 +434,12 @@ class DirectExchange:
 
     def release(self, slot, stream=None):
         self.ctx._chk(self.ctx.L.hodor_exchange_direct_release_dev(self.h, C.c_void_p(stream), C.c_uint32(slot)))
+
+    def copy(self, slot, send, log_chunks=0, chunk=0, stream=None):
+        """copy-engine variant: chunk `chunk` of the local send buffer -> the peers' receive buffers of `slot`"""
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_copy_dev(self.h, C.c_void_p(stream), C.c_uint32(slot), _dptr(send),
+                                                                C.c_size_t(send.shape[0]), C.c_uint32(log_chunks),
+                                                                C.c_uint32(chunk)))
 
     def columns(self, src, slot, log_n1, log_n2, omega, log_chunks=0, chunk=0, stream=None):
         w = _fr(omega)

@@ -100,6 +100,7 @@ struct hodor_exchange {
     // ---- direct transport (no communicator, no copy: the producing pass stores into the peers' receive buffers)
     struct Slot {
         uint64_t *d_tab = nullptr;          // device array of n_ranks receive-buffer addresses (as mapped HERE)
+        uint64_t h_tab[HODOR_EXCHANGE_MAX_RANKS] = {};   // the same addresses on the host (copy-engine transport)
         bool set = false;
         uint32_t produced = 0, consumed = 0;   // generations this rank has started producing into / consuming from the slot
     };
@@ -412,6 +413,9 @@ extern "C" int hodor_exchange_create_direct(hodor_ctx *ctx, uint32_t n_ranks, ui
     if (e == hipSuccess) e = hipHostMalloc((void **)&x->d_err, sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) *x->d_err = 0;
     for (uint32_t i = 0; e == hipSuccess && i < n_slots; i++) e = hipMalloc((void **)&x->slots[i].d_tab, n_ranks * sizeof(uint64_t));
+    // copy-engine transport (hodor_exchange_direct_copy_dev): a stream of its own for the peer copies and their flags
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -451,6 +455,7 @@ extern "C" int hodor_exchange_direct_set_peers(hodor_exchange *x, uint32_t slot,
         }
     }
     HIPCHK(hipMemcpy(x->slots[slot].d_tab, tab, x->n_ranks * sizeof(uint64_t), hipMemcpyHostToDevice));
+    for (uint32_t t = 0; t < x->n_ranks; t++) x->slots[slot].h_tab[t] = tab[t];
     x->slots[slot].set = true;
     return HODOR_OK;
 }
@@ -543,6 +548,50 @@ extern "C" int hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream
     if (rc) return rc;
     if (x->slots[slot].consumed == 0) { set_err(ctx, "exchange (direct): release without wait"); return HODOR_ERR_INVALID; }
     return direct_write(x, (hipStream_t)stream, slot, 1, x->slots[slot].consumed);
+}
+
+// Copy-engine transport: the chunked schedule's send pieces (hodor_sixstep_columns_dev / _rows_dev into a LOCAL send
+// buffer, exactly as for hodor_sixstep_exchange_dev) moved into the peers' mapped receive buffers by P device-to-device
+// copies per chunk on the handle's own stream — between devices the runtime runs those on the SDMA engines, so the
+// exchange takes no CU from the VALU-bound transforms and, unlike the direct stores, is spread over whatever the caller
+// enqueues next.  Slab t of the piece lands in rank t's buffer where an all-to-all would put it (piece `chunk`, slab
+// `rank`).  Chunk 0 first waits until every peer has released the slot; the last chunk is followed by the `arrived`
+// flags.  The consumer is the direct transport's: hodor_exchange_direct_wait_dev, the plain rows / columns call on the
+// slot's own receive buffer, hodor_exchange_direct_release_dev.  `send` must stay valid until that wait has been
+// enqueued (this rank's own `arrived` flag is written after all of its copies).  Unmeasured between real devices.
+extern "C" int hodor_exchange_direct_copy_dev(hodor_exchange *x, void *stream, uint32_t slot, const hodor_fr *send,
+                                              size_t n_local, uint32_t log_chunks, uint32_t chunk)
+{
+    if (!x || !x->ctx) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    if (!send || !x->comm_stream) return HODOR_ERR_INVALID;
+    if (log_chunks > 20 || chunk >= (1u << log_chunks) || n_local == 0 ||
+        n_local % ((size_t)x->n_ranks << log_chunks) != 0) {
+        set_err(ctx, "exchange (copy): n_local must be a multiple of n_ranks * chunks, chunk < chunks");
+        return HODOR_ERR_SIZE;
+    }
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = direct_ready(x, slot);
+    if (rc) return rc;
+    const size_t piece = n_local >> log_chunks, slab = piece / x->n_ranks;
+    HIPCHK(hipEventRecord(x->ready, (hipStream_t)stream));
+    HIPCHK(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
+    if (chunk == 0) {
+        const uint32_t g = ++x->slots[slot].produced;
+        if (g > 1 && (rc = direct_wait(x, x->comm_stream, slot, 1, g - 1))) return rc;
+    } else if (x->slots[slot].produced == 0) {
+        set_err(ctx, "exchange (copy): chunk 0 opens a generation");
+        return HODOR_ERR_INVALID;
+    }
+    const uint8_t *src = (const uint8_t *)(send + (size_t)chunk * piece);
+    for (uint32_t i = 0; i < x->n_ranks; i++) {
+        const uint32_t t = (x->rank + 1 + i) % x->n_ranks;          // start with the neighbour: the ranks' copies fan out over the links
+        uint8_t *dst = (uint8_t *)(uintptr_t)x->slots[slot].h_tab[t] + ((size_t)chunk * piece + (size_t)x->rank * slab) * 32;
+        HIPCHK(hipMemcpyAsync(dst, src + (size_t)t * slab * 32, slab * 32, hipMemcpyDeviceToDevice, x->comm_stream));
+    }
+    if (chunk + 1 == (1u << log_chunks)) return direct_write(x, x->comm_stream, slot, 0, x->slots[slot].produced);
+    return HODOR_OK;
 }
 
 // the device table of a slot and this rank's index, for abi_sixstep.hip

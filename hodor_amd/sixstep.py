@@ -30,12 +30,15 @@ import torch.distributed as dist
 class HipBackend:
     """Local steps on the MI355X through the C ABI (device tensors of shape (m, 4), int64)."""
 
-    def __init__(self, ctx, stream=None, exchange=None, direct=None):
+    def __init__(self, ctx, stream=None, exchange=None, direct=None, direct_copy=False):
         # exchange: a hodor_amd.Exchange — the all-to-alls then run through the C ABI (hodor_sixstep_exchange_dev,
         # grouped ncclSend/ncclRecv on the library's communication stream) instead of torch.distributed
         # direct: a hodor_amd.DirectExchange — no all-to-all at all: the producing transform stores every slab straight
         # into the receive buffer of the rank it is for (hodor_sixstep_columns_direct_dev / _rows_direct_dev)
-        self.ctx, self.stream, self.exchange, self.direct = ctx, stream, exchange, direct
+        # direct_copy: with `direct`, the copy-engine variant — the CHUNKED schedule writes its local send pieces as for an
+        # all-to-all and the handle copies each into the peers' mapped buffers on its own stream (hodor_exchange_direct_copy_dev:
+        # SDMA between devices, no CU, spread over whatever is enqueued next); consumer and flags are the direct transport's
+        self.ctx, self.stream, self.exchange, self.direct, self.direct_copy = ctx, stream, exchange, direct, direct_copy
 
     # ---- 4-step building blocks
     def columns(self, src, log_n1, log_n2, log_p, rank, omega, inverse=False, log_chunks=0, chunk=0, out=None):
@@ -214,13 +217,39 @@ def _direct_begin(backend, produce_direct, log_chunks):
     return d.recv[slot], [_DirectWait(d, slot, st)], (lambda: d.release(slot, stream=st))
 
 
+class _CopyWait:
+    def __init__(self, direct, slot, stream, keep):
+        self.direct, self.slot, self.stream, self.keep = direct, slot, stream, keep
+
+    def wait(self):
+        self.direct.wait(self.slot, stream=self.stream)      # every rank's copies — this rank's own included — have landed
+        self.keep = None
+        return True
+
+
+def _copy_begin(backend, produce, m, log_chunks):
+    """The copy-engine transport's counterpart of _exchange_begin: produce(k, send piece k) into a local send buffer, each
+    piece handed to the handle's copy stream as soon as it has been enqueued."""
+    d, st = backend.direct, backend.stream
+    K = 1 << log_chunks
+    assert m % (K * d.n_ranks) == 0, "too many chunks for this transform"
+    like = produce(None, None)
+    send = torch.empty((m, 4), dtype=like.dtype, device=like.device)
+    slot = d.next_slot()
+    step = m // K
+    for k in range(K):
+        produce(k, send[k * step:(k + 1) * step])
+        d.copy(slot, send, log_chunks, k, stream=st)
+    return d.recv[slot], [_CopyWait(d, slot, st, send)], (lambda: d.release(slot, stream=st))
+
+
 def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
     """First half of sixstep_forward: the column transforms, chunk by chunk, each chunk's all-to-all started
     behind it.  The caller may enqueue unrelated work (the other half of another transform) before
     sixstep_forward_end, which waits for the exchange and runs the row transforms."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
-    if getattr(backend, "direct", None) is not None:
+    if getattr(backend, "direct", None) is not None and not getattr(backend, "direct_copy", False):
         d = backend.direct
         recv, works, release = _direct_begin(
             backend, lambda slot, k: d.columns(a, slot, log_n1, log_n2, omega, log_chunks, k, stream=backend.stream), log_chunks)
@@ -230,6 +259,10 @@ def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log
         if k is None:
             return a
         backend.columns(a, log_n1, log_n2, log_p, rank, omega, False, log_chunks, k, out=out)
+
+    if getattr(backend, "direct", None) is not None:
+        recv, works, release = _copy_begin(backend, produce, a.shape[0], log_chunks)
+        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
     recv, works = _exchange_begin(produce, a.shape[0], world, group, log_chunks, getattr(backend, "exchange", None),
                                   getattr(backend, "stream", None))
@@ -255,7 +288,7 @@ def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log
     """First half of sixstep_inverse: the inverse row transforms chunk by chunk with their all-to-alls."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
-    if getattr(backend, "direct", None) is not None:
+    if getattr(backend, "direct", None) is not None and not getattr(backend, "direct_copy", False):
         d = backend.direct
         recv, works, release = _direct_begin(
             backend, lambda slot, k: d.rows(b, slot, log_n1, log_n2, omega, log_chunks, k, stream=backend.stream), log_chunks)
@@ -265,6 +298,10 @@ def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log
         if k is None:
             return b
         backend.rows(b, log_n1, log_n2, log_p, rank, omega, True, log_chunks, k, out=out)
+
+    if getattr(backend, "direct", None) is not None:
+        recv, works, release = _copy_begin(backend, produce, b.shape[0], log_chunks)
+        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
     recv, works = _exchange_begin(produce, b.shape[0], world, group, log_chunks, getattr(backend, "exchange", None),
                                   getattr(backend, "stream", None))

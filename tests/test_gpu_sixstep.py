@@ -566,6 +566,127 @@ def test_direct_exchange_between_two_processes_sharing_the_gpu():
     assert "direct" in line["exchange"]["transport"]
 
 
+# ---------------------------------------------------------------- copy-engine transport (the direct handle, chunked schedule)
+@pytest.mark.parametrize("world,log_n,log_chunks", [(1, 12, 0), (1, 14, 2), (2, 12, 1), (4, 14, 2), (8, 16, 1), (8, 21, 3)])
+def test_copy_engine_exchange_with_played_ranks(gpu_ctxs, oracles, world, log_n, log_chunks):
+    """hodor_exchange_direct_copy_dev: the chunked schedule's local send pieces, copied into the peers' mapped receive
+    buffers on the handle's own stream, chunk 0 behind the slot's release, the `arrived` flags behind the last chunk.
+    Ranks played in one process (the peers' buffers are other allocations of this device): every receive buffer equals
+    the hand-made all-to-all, the consumers give layout B and layout A back, three generations per slot."""
+    import torch
+    import hodor_amd
+    from hodor_amd.sixstep import HipBackend, split_logs
+    from sixstep_ref import layout_a, layout_b
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    hip = HipBackend(ctx)
+    log_n1, log_n2 = split_logs(log_n)
+    log_p = world.bit_length() - 1
+    n = 1 << log_n
+    m = n // world
+    K = 1 << log_chunks
+    step = m // K
+    full = O.random_elements(n, 4190 + log_n)
+    _, k, w = O.domain(n)
+    spec = full.copy()
+    O.best_fft(spec, w, k)
+    xs = [hodor_amd.DirectExchange(ctx, world, r, m, n_slots=2) for r in range(world)]
+    hodor_amd.DirectExchange.connect_local(xs)
+
+    def exchange_chunks(send):
+        recv = [torch.empty_like(send[0]) for _ in range(world)]
+        sl = step // world
+        for c in range(K):
+            for t in range(world):
+                for s_ in range(world):
+                    recv[t][c * step + s_ * sl:c * step + (s_ + 1) * sl] = send[s_][c * step + t * sl:c * step + (t + 1) * sl]
+        return recv
+
+    a = [_dev(layout_a(full, log_n, r, world)) for r in range(world)]
+    for rnd in range(3):
+        slot = rnd % 2
+        send = []
+        for r in range(world):                       # producers: chunk by chunk, each chunk handed to the copy stream
+            buf = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+            for c in range(K):
+                hip.columns(a[r], log_n1, log_n2, log_p, r, w, False, log_chunks, c, out=buf[c * step:(c + 1) * step])
+                xs[r].copy(slot, buf, log_chunks, c)
+            send.append(buf)
+        want = exchange_chunks(send)
+        b = []
+        for r in range(world):
+            xs[r].wait(slot)
+            ctx.synchronize()
+            assert torch.equal(xs[r].recv[slot], want[r]), ("forward slabs", rnd, r)
+            b.append(hip.rows(xs[r].recv[slot], log_n1, log_n2, log_p, r, w, False, log_chunks, 0))
+            xs[r].release(slot)
+        ctx.synchronize()
+        for r in range(world):
+            assert np.array_equal(_host(b[r]), layout_b(spec, log_n, r, world)), ("rows", rnd, r)
+        slot2 = 1 - slot
+        send = []
+        for r in range(world):
+            buf = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+            for c in range(K):
+                hip.rows(b[r], log_n1, log_n2, log_p, r, w, True, log_chunks, c, out=buf[c * step:(c + 1) * step])
+                xs[r].copy(slot2, buf, log_chunks, c)
+            send.append(buf)
+        want = exchange_chunks(send)
+        for r in range(world):
+            xs[r].wait(slot2)
+            ctx.synchronize()
+            assert torch.equal(xs[r].recv[slot2], want[r]), ("inverse slabs", rnd, r)
+            a2 = hip.columns(xs[r].recv[slot2], log_n1, log_n2, log_p, r, w, True, log_chunks, 0)
+            xs[r].release(slot2)
+            ctx.synchronize()
+            assert torch.equal(a2, a[r]), ("columns^-1", rnd, r)
+    for x in xs:
+        x.close()
+
+
+def test_copy_engine_exchange_through_the_schedule_at_world_1(gpu_ctxs):
+    """sixstep_forward / sixstep_inverse with HipBackend(direct=..., direct_copy=True), 4 chunks, at 2^24 points: the CPU
+    oracle's committed digest forward, the input back."""
+    import torch
+    import hodor_amd
+    from hodor_amd.sixstep import HipBackend, sixstep_forward, sixstep_inverse, split_logs
+    ctx = gpu_ctxs["bn256"]
+    log_n = 24
+    n = 1 << log_n
+    e = FULL["ntt"][str(log_n)]
+    a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a, 0, n, e["seed"])
+    w = ctx.domain(n)[2]
+    x = hodor_amd.DirectExchange(ctx, 1, 0, n, n_slots=2)
+    hodor_amd.DirectExchange.connect_local([x])
+    hip = HipBackend(ctx, direct=x, direct_copy=True)
+    for _ in range(3):
+        b = sixstep_forward(hip, a, log_n, w, 0, 1, log_chunks=2)
+        c = sixstep_inverse(hip, b, log_n, w, 0, 1, log_chunks=2)
+    l1, l2 = split_logs(log_n)
+    nat = hip.transpose(b, 1 << l1, 1 << l2)
+    ctx.synchronize()
+    assert hashlib.blake2s(memoryview(nat.cpu().numpy()).cast("B"), digest_size=32).hexdigest() == e["fft"]
+    assert torch.equal(c, a)
+    x.close()
+
+
+def test_copy_engine_exchange_between_two_processes_sharing_the_gpu():
+    """Two processes, hipIpc-mapped receive buffers and flag blocks, bench.py's pipelined 4-step steps with --exchange copy
+    (4 chunks per exchange): the line needs the round trip and the CPU oracle's digest of the gathered 2^22-point transform."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("HODOR_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--exchange",
+                          "copy", "--log-n", "21", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra",
+                          "--launch-timeout", "600"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["mode"] == "sixstep" and line["scaling"] == "weak", line
+    assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
+    assert "copy engines" in line["exchange"]["transport"] and line["collective_on_data_path"] is False
+
+
 def test_bare_bench_launch_with_two_ranks_spawns_its_own_torchrun():
     """`python3 bench.py --gpus 2 ...` from a clean environment — the exact shape of the driver's command, no torchrun, no
     RANK — re-executes itself under torch.distributed.run and relays ONE JSON line (here with the ranks sharing the one
