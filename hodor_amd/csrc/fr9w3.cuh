@@ -18,7 +18,8 @@
 //
 // Bounds (p < 2^255): with x normalized (limbs 0..7 < 2^29, value < 2^261) every X_c < 2^87, so
 // T < 3 * 2^87 p and r < 4p, normalized.  Column sums: at most 9 data terms (< 2^29 * 2^29 when x is
-// normalized, < 2^31.5 * 2^29 tolerated) + 3 reduction terms < 2^64.
+// normalized; lazy limbs are tolerated as long as the nine of them sum below 60 * 2^29, see fr9_normalize_groups)
+// + 3 reduction terms < 2^64.
 #pragma once
 #ifndef HODOR_HOST_TEST
 #include "fr9.cuh"
@@ -45,8 +46,11 @@ __device__ __forceinline__ uint32_t fr9_mont_digit(uint32_t lo, const Fr9Params 
 
 // group-wise carry propagation: enough for fr9_mul3, whose bound only needs every 87-bit GROUP below 2^87
 // (limbs 2 and 5 carried into 3 and 6; the top group is bounded by the value itself).  For x with lazy limbs
-// < 2^31.5 and value < 2^261: X_0, X_1 < 2^87 (1 + 2^-26), X_2 < 2^87, column sums of the product
-// <= 9 * 2^31.5 * 2^29 + 3 * 2^58 < 2^64, and the product stays < (4 + 2^-25) p — 6 instructions instead of 24.
+// < 7 * 2^29 (what k_ntt_pass hands it: a stored sum < 5 * 2^29 plus one offset subtraction) and value < 2^261:
+// X_0, X_1 < 2^87 (1 + 2^-26), X_2 < 2^87; a column of the product takes every data limb at most once, seven of them
+// < 7 * 2^29 and limbs 2 and 5 < 2^29 after the carry, each times a table limb < 2^29: <= 51 * 2^58, + 3 * 2^58 of
+// reduction terms + the carry < 2^64; the product stays < (4 + 2^-25) p — 6 instructions instead of 24
+// (replayed with the worst limbs in tests/test_lazy_step_bounds_cpu.py).
 __device__ __forceinline__ void fr9_normalize_groups(Fr9 &a)
 {
     a.v[3] += a.v[2] >> 29;
