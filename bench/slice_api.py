@@ -28,6 +28,32 @@ for log_n in (20, 24):
     print("slice poly_fft 2^%d, pinned buffer: %.3f ms  (%.2e elems/s, %.1f GB/s over PCIe both ways)" %
           (log_n, best * 1e3, n / best, 2 * n * 32 / best / 1e9))
 
+# where the time of ONE call goes: the two copies alone (torch pageable / pinned host tensors over the same link) and the
+# device-resident transform between them — a call can overlap neither copy with the other (every output depends on every
+# input), only the transform with them
+import torch
+log_n = 24
+n = 1 << log_n
+host = torch.from_numpy(rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64).view(np.int64))
+dev = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+out = torch.empty_like(dev)
+for pin in (False, True):
+    h = host.pin_memory() if pin else host
+    back = torch.empty_like(h).pin_memory() if pin else torch.empty_like(h)
+    ups, downs = [], []
+    for _ in range(4):
+        torch.cuda.synchronize(); t = time.perf_counter(); dev.copy_(h); torch.cuda.synchronize(); ups.append(time.perf_counter() - t)
+        torch.cuda.synchronize(); t = time.perf_counter(); back.copy_(dev); torch.cuda.synchronize(); downs.append(time.perf_counter() - t)
+    print("2^24 elements (512 MiB), %s host memory: upload %.2f ms (%.1f GB/s), download %.2f ms (%.1f GB/s)" %
+          ("pinned" if pin else "pageable", min(ups) * 1e3, n * 32 / min(ups) / 1e9, min(downs) * 1e3, n * 32 / min(downs) / 1e9))
+ctx.poly_fft_dev(dev, out, log_n)
+ctx.synchronize()
+t = time.perf_counter()
+for _ in range(10):
+    ctx.poly_fft_dev(dev, out, log_n)
+ctx.synchronize()
+print("2^24 transform, device-resident: %.2f ms" % ((time.perf_counter() - t) / 10 * 1e3))
+
 # concurrent callers on one context (the reference calls best_fft from several scoped threads,
 # src/arp/per_register/mod.rs:43-49): uploads, kernels and downloads of different callers overlap
 import threading
