@@ -60,6 +60,23 @@ EXPORTS = [
     "hodor_sixstep_rows_direct_dev",
     "hodor_exchange_available", "hodor_exchange_unique_id", "hodor_exchange_create", "hodor_exchange_adopt",
     "hodor_exchange_destroy", "hodor_sixstep_exchange_dev", "hodor_sixstep_exchange_wait_dev",
+    # round 5: proof_from_lde_through_coefficients and the handle API (device-resident Polynomial / IOP)
+    "hodor_ctx_host_round_trips", "hodor_ctx_pool_stats", "hodor_ctx_reset_host_round_trips", "hodor_ctx_stream",
+    "hodor_ctx_trim", "hodor_fri_commit_h", "hodor_fri_commit_through_coefficients",
+    "hodor_fri_commit_through_coefficients_dev", "hodor_fri_commitment_h", "hodor_fri_intermediate_values_h",
+    "hodor_fri_produce_proof_h", "hodor_fri_verify_prototype_h", "hodor_iop_create_batch_h", "hodor_iop_create_h",
+    "hodor_iop_free_h", "hodor_iop_nodes_h", "hodor_iop_query_h", "hodor_iop_root_h", "hodor_iop_roots_h",
+    "hodor_iop_size_h", "hodor_poly_add_assign_scaled_h", "hodor_poly_add_constant_h", "hodor_poly_as_ref_h",
+    "hodor_poly_batch_inversion_h", "hodor_poly_binary_h", "hodor_poly_clone_h",
+    "hodor_poly_coset_fft_for_generator_h", "hodor_poly_coset_fft_h", "hodor_poly_degree_one_on_domain_h",
+    "hodor_poly_dev_ptr_h", "hodor_poly_distribute_powers_h", "hodor_poly_elem_op_h", "hodor_poly_equal_h",
+    "hodor_poly_evaluate_at_h", "hodor_poly_fft_h", "hodor_poly_form_h", "hodor_poly_free_h",
+    "hodor_poly_from_dev_h", "hodor_poly_from_host_h", "hodor_poly_gen_h", "hodor_poly_icoset_fft_for_generator_h",
+    "hodor_poly_icoset_fft_h", "hodor_poly_ifft_h", "hodor_poly_info_h", "hodor_poly_lde_batch_h",
+    "hodor_poly_lde_h", "hodor_poly_negate_h", "hodor_poly_new_for_size_h", "hodor_poly_pad_by_factor_h",
+    "hodor_poly_pad_to_size_h", "hodor_poly_pow_h", "hodor_poly_quotient_term_h", "hodor_poly_read_h",
+    "hodor_poly_scale_h", "hodor_poly_size_h", "hodor_poly_square_h", "hodor_poly_trim_to_degree_h",
+    "hodor_poly_write_h",
 ]
 
 
@@ -640,11 +657,13 @@ class Context:
                                           C.c_size_t(len(path)), C.c_size_t(tree_index), C.byref(ok)))
         return bool(ok.value)
 
-    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, combiner=TRIVIAL):
+    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, combiner=TRIVIAL, through_coefficients=False):
+        """proof_from_lde_by_values (src/fri/fri_on_values.rs:11-159), or — through_coefficients —
+        proof_from_lde_through_coefficients (src/fri/mod.rs:156-248)."""
         h = C.c_void_p()
-        self._chk(self.L.hodor_fri_commit_combined(self.h, _hptr(lde_values), C.c_size_t(len(lde_values)),
-                                                   C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one),
-                                                   C.c_int(combiner), C.byref(h)))
+        fn = self.L.hodor_fri_commit_through_coefficients if through_coefficients else self.L.hodor_fri_commit_combined
+        self._chk(fn(self.h, _hptr(lde_values), C.c_size_t(len(lde_values)), C.c_size_t(lde_factor),
+                     C.c_size_t(out_deg_plus_one), C.c_int(combiner), C.byref(h)))
         return FriPrototype(self, h)
 
     # ---- the tree format as a parameter (HODOR_COMBINER_COSET2: leaf k = value[k] || value[k + n/2])
@@ -858,11 +877,13 @@ class Context:
                                              path.ctypes.data_as(C.c_void_p), C.byref(cnt)))
         return _to_int(value.l), path[:cnt.value]
 
-    def fri_commit_dev(self, lde_values, n, lde_factor, out_deg_plus_one, stream=None, combiner=TRIVIAL):
+    def fri_commit_dev(self, lde_values, n, lde_factor, out_deg_plus_one, stream=None, combiner=TRIVIAL,
+                       through_coefficients=False):
         h = C.c_void_p()
-        self._chk(self.L.hodor_fri_commit_combined_dev(self.h, C.c_void_p(stream), _dptr(lde_values), C.c_size_t(n),
-                                                       C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one),
-                                                       C.c_int(combiner), C.byref(h)))
+        fn = (self.L.hodor_fri_commit_through_coefficients_dev if through_coefficients
+              else self.L.hodor_fri_commit_combined_dev)
+        self._chk(fn(self.h, C.c_void_p(stream), _dptr(lde_values), C.c_size_t(n), C.c_size_t(lde_factor),
+                     C.c_size_t(out_deg_plus_one), C.c_int(combiner), C.byref(h)))
         return FriPrototype(self, h)
 
     def iop_create_batch_combined_dev(self, leafs, n, batch, combiner, nodes, stream=None):

@@ -432,8 +432,8 @@ int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *
 
 // lde / coset_lde: one zero-padded transform of size n*factor — identical output to the
 // reference's per-coset schedule (asserted by its own tests, src/polynomials/mod.rs:1026-1031)
-static int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
-                         uint32_t log_n, size_t factor, int coset, uint32_t batch = 1)
+int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst,
+                  uint32_t log_n, size_t factor, int coset, uint32_t batch)
 {
     if (!is_pow2(factor)) { set_err(ctx, "lde factor must be a power of two"); return HODOR_ERR_SIZE; }
     uint32_t log_big = log_n + log2u(factor);
@@ -520,6 +520,7 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
         if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
         if (ctx->fri_slab) (void)hipFree(ctx->fri_slab);
+        pool_drain(ctx);
         for (auto &L : ctx->lanes) {
             for (int i = 0; i < 2; i++)
                 if (L.buf[i]) (void)hipFree(L.buf[i]);
@@ -589,6 +590,7 @@ extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *de
 {
     NEED_DEVICE();
     HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    note_round_trip(ctx);
     return HODOR_OK;
 }
 
@@ -902,6 +904,7 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     HIPCHK(hipMemcpyAsync(top_prod, base + top.prod_off, top.T * 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    note_round_trip(ctx);
     if (host_flag) {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
         set_err(ctx, "batch_inversion: zero element");
         return HODOR_ERR_INVALID;
@@ -961,6 +964,7 @@ extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const h
     }
     HIPCHK(hipMemcpyAsync(out, res, 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    note_round_trip(ctx);
     return HODOR_OK;
 }
 

@@ -176,6 +176,7 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
     std::vector<uint8_t> small(64 * (num_steps + 1) + 32 * out_deg);
     FRICHK(hipMemcpyAsync(small.data(), d_small, small.size(), hipMemcpyDeviceToHost, stream));
     FRICHK(hipStreamSynchronize(stream));
+    note_round_trip(ctx);
     p->roots.assign(small.begin() + 32 * (num_steps + 1), small.begin() + 64 * (num_steps + 1));
     p->challenges.resize(num_steps);
     memcpy(p->challenges.data(), small.data(), 32 * num_steps);
@@ -185,6 +186,146 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
 #undef FRICHK
     *out = p;
     return HODOR_OK;
+}
+
+// NaiveFriIop::proof_from_lde_through_coefficients (src/fri/mod.rs:156-248) on the device: l0 commit (:162), ONE
+// inverse transform of the codeword (:171; truncation :173 = the first n / lde_factor entries of its output), then
+// per round the challenge from the previous tree's root (:178, :213 — k_challenge, never on the host), the
+// coefficient fold a_2i + beta a_(2i+1) (:190-205, k_fri_fold_coeffs), Polynomial::lde of the folded coefficients
+// (:208-209: one zero-padded transform, = the reference's per-coset schedule) and the tree over it (:210).  The
+// prototype has the layout of the by-values one (same accessors, same bytes — the reference asserts the two equal,
+// :338-343); the coefficient ping-pong buffers live in the same slab, behind the small block.
+extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values,
+                                                         size_t n, size_t lde_factor, size_t out_deg, int combiner,
+                                                         hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (combiner != HODOR_COMBINER_TRIVIAL && combiner != HODOR_COMBINER_COSET2) return HODOR_ERR_INVALID;
+    const bool comb = combiner == HODOR_COMBINER_COSET2;
+    if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;   // asserts :165-166
+    const size_t initial_degree_plus_one = n / lde_factor;                                        // :168
+    if (initial_degree_plus_one < 2 * out_deg) {   // num_steps == 0: the reference panics at roots.pop() (:226)
+        set_err(ctx, "fri_commit_through_coefficients: needs at least one folding step");
+        return HODOR_ERR_SIZE;
+    }
+    const size_t num_steps = log2u(initial_degree_plus_one / out_deg);                            // :169
+    if ((n >> num_steps) < (comb ? 4u : 2u)) {
+        set_err(ctx, comb ? "fri_commit_through_coefficients: COSET2 needs lde_factor * out_deg >= 4"
+                          : "fri_commit_through_coefficients: the last tree needs two leaves");
+        return HODOR_ERR_SIZE;
+    }
+    const uint32_t log_n = log2u(n);
+    HFr omega;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = poly_domain(ctx, log_n, &omega);
+    if (rc) return rc;
+    hipStream_t stream = pick_stream(ctx, stream_);
+
+    hodor_fri_proto *p = new (std::nothrow) hodor_fri_proto();
+    if (!p) return HODOR_ERR_INVALID;
+    p->ctx = ctx;
+    p->n = n;
+    p->num_steps = num_steps;
+    p->lde_factor = lde_factor;
+    p->out_deg = out_deg;
+    p->initial_degree_plus_one = initial_degree_plus_one;
+    p->combiner = combiner;
+    auto release = [&](hodor_fri_proto *q) {   // error path: the ctx mutex is already held
+        if (q->slab) (void)hipFree(q->slab);
+        delete q;
+    };
+#define FRICHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            (void)hipGetLastError();                                                   \
+            set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));             \
+            release(p);                                                                \
+            return HODOR_ERR_DEVICE;                                                   \
+        }                                                                              \
+    } while (0)
+
+    // slab: l0 tree | per step: values, tree | small block (challenges, roots) | coefficients A (n) | B (deg / 2)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t small_bytes = 64 * (num_steps + 1);
+    size_t need = up(n * 32) + up(small_bytes) + up(n * 32) + up(initial_degree_plus_one * 16);
+    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
+    if (ctx->fri_slab && ctx->fri_slab_bytes >= need) {
+        p->slab = ctx->fri_slab;
+        p->slab_bytes = ctx->fri_slab_bytes;
+        ctx->fri_slab = nullptr;
+        ctx->fri_slab_bytes = 0;
+    } else {
+        FRICHK(hipMalloc(&p->slab, need));
+        p->slab_bytes = need;
+    }
+    uint8_t *cursor = (uint8_t *)p->slab;
+    auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
+    p->l0_nodes = carve(n * 32);
+    for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) {
+        p->inter_values.push_back(carve(sz * 32));
+        p->inter_nodes.push_back(carve(sz * 32));
+        p->inter_sizes.push_back(sz);
+    }
+    uint8_t *d_small = (uint8_t *)carve(small_bytes);
+    uint4 *d_chal = (uint4 *)d_small;
+    uint4 *d_roots = (uint4 *)(d_small + 32 * (num_steps + 1));
+    uint4 *coef_a = (uint4 *)carve(n * 32);
+    uint4 *coef_b = (uint4 *)carve(initial_degree_plus_one * 16);
+    const uint32_t shave = 256 - ctx->F.capacity;
+    const Fr r2 = to_dev(ctx->F.r2);
+
+    FRICHK(merkle_build_launch(stream, (const uint4 *)lde_values, (uint4 *)p->l0_nodes, n, ctx->mid, 1, nullptr, nullptr,
+                               comb));                                                                       // :162
+    if ((rc = poly_transform(ctx, stream, (const uint4 *)lde_values, coef_a, log_n, OP_IFFT))) { release(p); return rc; }   // :171
+    const uint4 *coeffs = coef_a;                      // its first initial_degree_plus_one entries (:173)
+    uint4 *spare = coef_b;
+    const uint4 *prev_nodes = (const uint4 *)p->l0_nodes;
+    size_t next_len = initial_degree_plus_one / 2;                                                           // :180
+    for (size_t i = 0; i < num_steps; i++, next_len >>= 1) {                                                 // :185
+        FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, r2, shave, ctx->P));    // :178 / :213
+        FRICHK(fri_fold_coeffs_launch(stream, coeffs, spare, next_len, d_chal + 2 * i, ctx->P));             // :190-205
+        if ((rc = poly_lde_exec(ctx, stream, spare, (uint4 *)p->inter_values[i], log2u(next_len), lde_factor, 0))) {   // :208-209
+            release(p);
+            return rc;
+        }
+        FRICHK(merkle_build_launch(stream, (const uint4 *)p->inter_values[i], (uint4 *)p->inter_nodes[i],
+                                   next_len * lde_factor, ctx->mid, 1, nullptr, nullptr, comb));             // :210
+        prev_nodes = (const uint4 *)p->inter_nodes[i];
+        uint4 *t = (uint4 *)coeffs;                    // the buffer just consumed takes the next round's output
+        coeffs = spare;
+        spare = t;
+    }
+    FRICHK(challenge_launch(stream, prev_nodes, d_chal + 2 * num_steps, d_roots + 2 * num_steps, r2, shave, ctx->P));   // the root :212; its challenge is popped :224
+
+    std::vector<uint8_t> small(small_bytes);
+    p->final_coeffs.resize(out_deg);                                                                         // :232-234
+    FRICHK(hipMemcpyAsync(small.data(), d_small, small_bytes, hipMemcpyDeviceToHost, stream));
+    FRICHK(hipMemcpyAsync(p->final_coeffs.data(), coeffs, 32 * out_deg, hipMemcpyDeviceToHost, stream));
+    FRICHK(hipStreamSynchronize(stream));
+    note_round_trip(ctx);
+    p->roots.assign(small.begin() + 32 * (num_steps + 1), small.end());
+    p->challenges.resize(num_steps);
+    memcpy(p->challenges.data(), small.data(), 32 * num_steps);
+    memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);                                             // roots.pop() :226
+#undef FRICHK
+    *out = p;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_fri_commit_through_coefficients(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n,
+                                                     size_t lde_factor, size_t out_deg, int combiner,
+                                                     hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
+    DevBuf dv;
+    HIPCHK(hipMalloc(&dv.p, n * 32));
+    HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
+    return hodor_fri_commit_through_coefficients_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor,
+                                                     out_deg, combiner, out);
 }
 
 extern "C" int hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
@@ -226,6 +367,7 @@ extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr
     std::vector<uint8_t> host(entries * 32);
     HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    note_round_trip(ctx);
     memcpy(value, host.data(), 32);
     memcpy(path, host.data() + 32, (entries - 1) * 32);
     *path_len = entries - 1;
@@ -253,6 +395,7 @@ extern "C" int hodor_iop_query_combined_dev(hodor_ctx *ctx, void *stream_, const
     std::vector<uint8_t> host(entries * 32);
     HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    note_round_trip(ctx);
     memcpy(values, host.data(), 64);
     memcpy(path, host.data() + 64, (entries - 2) * 32);
     *path_len = entries - 2;
@@ -323,6 +466,7 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     if (hipMemcpyAsync(host.data(), stage.p, stage_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return 0;
+    note_round_trip(ctx);
     size_t o = 0, h = 0;
     auto put64 = [&](uint64_t v) { memcpy(buf + o, &v, 8); o += 8; };
     put64(q_index.size());

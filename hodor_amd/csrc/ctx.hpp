@@ -7,6 +7,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -40,6 +41,8 @@ hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const Fr
 hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
 hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
 hipError_t unary_launch(hipStream_t, uint4 *a, uint64_t n, int op, const Fr &c, uint64_t e, const FrParams &);
+hipError_t store_elems_launch(hipStream_t, uint4 *dst, const Fr *v, uint32_t count);   // count <= 4
+hipError_t count_diff_launch(hipStream_t, const uint4 *a, const uint4 *b, uint64_t n, uint32_t *flag);
 hipError_t quotient_term_launch(hipStream_t, uint4 *acc, const uint4 *f, const uint4 *dinv, uint64_t n, const Fr &value,
                                 const Fr *alpha, bool accumulate, const FrParams &);
 hipError_t batchinv_forward_launch(hipStream_t, const uint4 *a, uint64_t n, uint64_t T, uint4 *prefix, uint4 *prod,
@@ -69,6 +72,8 @@ hipError_t fri_round_table_launch(hipStream_t, const uint4 *nodes, uint4 *chal_o
 hipError_t fri_tail_launch(hipStream_t, const FriTailArgs &, const Fr9 &c16, const Fr &r2, const B2Mid &,
                            const Fr9Params &, const FrParams &, bool comb = false);
 hipError_t fri_fold_launch(hipStream_t, const FoldArgs &, const Fr9Params &);
+hipError_t fri_fold_coeffs_launch(hipStream_t, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *chal,
+                                  const FrParams &);
 
 static inline Fr to_dev(const HFr &a)
 {
@@ -171,6 +176,15 @@ struct hodor_ctx {
     uint32_t min_log_c = 2;    // fewest tile columns per pass (2^2 x 32 B = 128-byte runs)
     uint32_t tw_hi_max_log = 17;   // largest `hi` half (log2 entries) for which the second pass gets a hi-only
                                    // twiddle split (one product instead of two, for a table that outgrows L2)
+    // device memory pool of the handle API (abi_poly.hip).  Everything a handle does is enqueued on ctx->stream, so a
+    // block one handle gives back may be handed to the next at once (stream order makes the reuse safe) and a chain of
+    // Polynomial operations with temporaries never meets hipMalloc / hipFree (which synchronise the device).
+    std::multimap<size_t, void *> pool_free;
+    size_t pool_cached = 0, pool_live = 0;
+    std::mutex pool_mu;
+    // device -> host results handed out so far (roots, evaluations, query answers, prototypes, as_ref() copies): every one
+    // of them stalls the queue, so a device-resident prover counts them (hodor_ctx_host_round_trips)
+    std::atomic<uint64_t> host_round_trips{0};
     std::string err;           // written through set_err() only (entry points run concurrently)
     mutable std::mutex err_mu;
 };
@@ -242,6 +256,12 @@ static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
     return (hipStream_t)stream;   // NULL selects the HIP default (null) stream, as for any HIP API
 }
 
+// abi_poly.hip: the handle API's device pool (pool_drain: hodor_ctx_destroy / hodor_ctx_trim; it synchronises the device)
+int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got);
+void pool_release(hodor_ctx *ctx, void *p, size_t bytes);
+void pool_drain(hodor_ctx *ctx);
+static inline void note_round_trip(hodor_ctx *ctx) { ctx->host_round_trips.fetch_add(1, std::memory_order_relaxed); }
+
 // defined in abi.hip (caller holds ctx->mu)
 int trim_table_cache(hodor_ctx *ctx);
 int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,
@@ -292,3 +312,6 @@ int poly_domain(hodor_ctx *ctx, uint32_t log_n, HFr *omega);
 enum PolyOp { OP_FFT, OP_COSET_FFT, OP_IFFT, OP_ICOSET_FFT };
 int poly_transform(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, PolyOp op,
                    const HFr *gen = nullptr);   // gen: the coset generator (OP_COSET_FFT) / its inverse (OP_ICOSET_FFT) instead of the field's
+// lde / coset_lde of 2^log_n coefficients into 2^log_n * factor values (caller holds ctx->mu)
+int poly_lde_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, size_t factor,
+                  int coset, uint32_t batch = 1);

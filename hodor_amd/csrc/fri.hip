@@ -58,6 +58,18 @@ k_fri_fold(FoldArgs F, Fr9Params Q)
         fr_store(F.dst + 2 * i, fri_fold_one(F, i, Q));
 }
 
+// The coefficient fold of NaiveFriIop::proof_from_lde_through_coefficients
+// (/root/reference/src/fri/mod.rs:194-203): next[i] = a[2i] + beta * a[2i+1], beta read from device memory
+// (the challenge the previous tree's root gave, R-form) so the chain of rounds never visits the host.
+__global__ void __launch_bounds__(256)
+k_fri_fold_coeffs(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *chal, FrParams P)
+{
+    const Fr beta = fr_load(chal);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
+        fr_store(dst + 2 * i, fr_add(fr_load(src + 4 * i), fr_mul(fr_load(src + 4 * i + 2), beta, P), P));
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_fri_tail: all remaining rounds of the commit loop once a round's output fits one workgroup
 // (<= 512 values).  Below that size a round is a chain of ~log2(size) + 3 dependent steps (fold,
@@ -186,6 +198,15 @@ hipError_t fri_round_table_launch(hipStream_t s, const uint4 *nodes, uint4 *chal
 {
     hipLaunchKernelGGL(k_fri_round_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, nodes, chal_out,
                        root_out, hi, hi_out, count, c16, r2, shave, Q, P);
+    return hipGetLastError();
+}
+
+hipError_t fri_fold_coeffs_launch(hipStream_t s, const uint4 *src, uint4 *dst, uint64_t half, const uint4 *chal,
+                                  const FrParams &P)
+{
+    uint64_t blocks = (half + 255) / 256;
+    unsigned grid = (unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
+    hipLaunchKernelGGL(k_fri_fold_coeffs, dim3(grid), dim3(256), 0, s, src, dst, half, chal, P);
     return hipGetLastError();
 }
 

@@ -160,6 +160,13 @@ int  hodor_fri_commit(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size
  * output_coeffs_at_degree_plus_one >= 4 (two combined leaves in the last tree) */
 int  hodor_fri_commit_combined(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
                                size_t output_coeffs_at_degree_plus_one, int combiner, hodor_fri_proto **out);
+/* NaiveFriIop::proof_from_lde_through_coefficients — src/fri/mod.rs:156-248: the same prototype by another route
+ * (ifft of the codeword, coefficient folds a_2i + beta a_(2i+1), Polynomial::lde + commit per round); the
+ * reference's test_one_fri_step asserts it equal to proof_from_lde_by_values field for field (:338-343), and so do
+ * this library's tests.  `combiner` as above (the reference: HODOR_COMBINER_TRIVIAL). */
+int  hodor_fri_commit_through_coefficients(hodor_ctx *ctx, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                                           size_t output_coeffs_at_degree_plus_one, int combiner,
+                                           hodor_fri_proto **out);
 int  hodor_fri_combiner(const hodor_fri_proto *p);   /* HODOR_COMBINER_* of the prototype's trees */
 void hodor_fri_free(hodor_fri_proto *p);   /* before hodor_ctx_destroy of the context it came from */
 size_t hodor_fri_num_steps(const hodor_fri_proto *p);
@@ -472,6 +479,129 @@ int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_value
 int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
                                   size_t lde_factor, size_t output_coeffs_at_degree_plus_one, int combiner,
                                   hodor_fri_proto **out);
+int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *stream, const hodor_fr *lde_values, size_t n,
+                                              size_t lde_factor, size_t output_coeffs_at_degree_plus_one,
+                                              int combiner, hodor_fri_proto **out);
+
+/* ===================== handle API: device-resident Polynomial / IOP behind the reference's surface =====================
+ * `hodor_poly` IS the reference's `Polynomial<F, P>` (src/polynomials/mod.rs:26-34: coeffs, exp, omega, omegainv, geninv,
+ * minv) with `coeffs: Vec<F>` living in HBM; `hodor_iop` is `TrivialBlake2sIOP` / `Blake2sIopTree`
+ * (src/iop/blake2s_trivial_iop.rs:106-339) with its `nodes` in HBM.  Every method src/arp, src/ali and src/prover call on
+ * those types (:37-137 generic, :139-712 Coefficients, :715-955 Values; IOP::create / get_root / query,
+ * src/iop/mod.rs:79-92) is one entry point below, so a Rust `struct Polynomial` that wraps the handle keeps the
+ * callers' source unchanged and nothing but roots, evaluations, query answers and proofs crosses PCIe.
+ *
+ * Rules of the handles:
+ *   - every operation is ENQUEUED on the context's own compute stream (hodor_ctx_stream) and returns at once; the
+ *     calls that hand a result to the host (as_ref / read, evaluate_at, batch_inversion's zero check, roots, queries,
+ *     prototypes) wait for it and are counted (hodor_ctx_host_round_trips);
+ *   - device memory comes from a per-context pool: creating, cloning and freeing handles never calls hipMalloc /
+ *     hipFree once the pool is warm (hodor_ctx_trim gives the cached blocks back to HIP);
+ *   - a handle is not thread-safe (it is a `&mut self` object); different handles of one context may be used from
+ *     different threads — their work is serialised on the one stream;
+ *   - free every handle before hodor_ctx_destroy of its context;
+ *   - the form (HODOR_FORM_*) is the Rust type parameter P: calling a Values method on a Coefficients handle is the
+ *     type error the Rust compiler refuses — here HODOR_ERR_INVALID. */
+typedef struct hodor_poly hodor_poly;
+typedef struct hodor_iop hodor_iop;
+enum { HODOR_FORM_COEFFICIENTS = 0, HODOR_FORM_VALUES = 1 };
+typedef struct { uint32_t exp; hodor_fr omega, omegainv, geninv, minv; } hodor_poly_info;   /* :28-33 */
+
+void    *hodor_ctx_stream(hodor_ctx *ctx);                    /* hipStream_t of the handle API, for `_dev` calls beside it */
+uint64_t hodor_ctx_host_round_trips(const hodor_ctx *ctx);    /* device -> host results handed out since creation / reset */
+void     hodor_ctx_reset_host_round_trips(hodor_ctx *ctx);
+int      hodor_ctx_trim(hodor_ctx *ctx);                      /* cached pool blocks back to HIP (synchronises the device) */
+int      hodor_ctx_pool_stats(const hodor_ctx *ctx, size_t *cached_bytes, size_t *live_bytes);
+
+/* Polynomial::from_coeffs / from_values (:146-166, :722-742): `len` host elements, zero-padded to the next power of
+ * two (Domain::new_for_size; HODOR_ERR_SIZE beyond the field's two-adicity).  new_for_size (:140-144, :716-720): zeros. */
+int hodor_poly_from_host_h(hodor_ctx *ctx, int form, const hodor_fr *host, size_t len, hodor_poly **out);
+int hodor_poly_new_for_size_h(hodor_ctx *ctx, int form, size_t size, hodor_poly **out);
+/* the same from a device buffer produced on `producer_stream` (a hipStream_t; the copy is ordered behind it) */
+int hodor_poly_from_dev_h(hodor_ctx *ctx, int form, const hodor_fr *dev_src, size_t len, void *producer_stream,
+                          hodor_poly **out);
+/* elements [first_index, first_index + count) of the synthetic stream `seed` (hodor_gen_elements_dev) as a polynomial */
+int hodor_poly_gen_h(hodor_ctx *ctx, int form, uint64_t first_index, size_t count, uint64_t seed, hodor_poly **out);
+int hodor_poly_clone_h(const hodor_poly *p, hodor_poly **out);                       /* #[derive(Clone)] :25 */
+void hodor_poly_free_h(hodor_poly *p);
+size_t hodor_poly_size_h(const hodor_poly *p);                                      /* size() :38 */
+int hodor_poly_form_h(const hodor_poly *p);
+int hodor_poly_info_h(const hodor_poly *p, hodor_poly_info *out);
+void *hodor_poly_dev_ptr_h(hodor_poly *p);   /* the device buffer (size * 32 bytes); order your own work on hodor_ctx_stream */
+/* as_ref() :42 — a host copy materialised on first use and kept until the polynomial is next modified; *host stays
+ * valid until then (or until the handle is freed).  read: as_ref()[first .. first + count] without materialising the
+ * rest; write: as_mut()[first ..] = in (:46); elem_op: as_mut()[index].op(c) on the device (HODOR_UN_*; e for POW). */
+int hodor_poly_as_ref_h(hodor_poly *p, const hodor_fr **host);
+int hodor_poly_read_h(hodor_poly *p, size_t first, size_t count, hodor_fr *out);
+int hodor_poly_write_h(hodor_poly *p, size_t first, size_t count, const hodor_fr *in);
+int hodor_poly_elem_op_h(hodor_poly *p, size_t index, int op, const hodor_fr *c, uint64_t e);
+/* derive(PartialEq) :24 without moving either vector: *equal = 1 when form, size and every element agree */
+int hodor_poly_equal_h(const hodor_poly *a, const hodor_poly *b, int *equal);
+/* generic methods (:54-137); pad_* return HODOR_ERR_SIZE where the reference returns Err(SynthesisError::Error) */
+int hodor_poly_distribute_powers_h(hodor_poly *p, const hodor_fr *g);
+int hodor_poly_scale_h(hodor_poly *p, const hodor_fr *g);
+int hodor_poly_negate_h(hodor_poly *p);
+int hodor_poly_pad_by_factor_h(hodor_poly *p, size_t factor);
+int hodor_poly_pad_to_size_h(hodor_poly *p, size_t new_size);
+int hodor_poly_trim_to_degree_h(hodor_poly *p, size_t degree);
+/* Coefficients -> Values in place (:611-638); the handle changes its form like the Rust value changes its type */
+int hodor_poly_fft_h(hodor_poly *p);
+int hodor_poly_coset_fft_h(hodor_poly *p);
+int hodor_poly_coset_fft_for_generator_h(hodor_poly *p, const hodor_fr *gen);
+/* Values -> Coefficients in place (:773-815) */
+int hodor_poly_ifft_h(hodor_poly *p);
+int hodor_poly_icoset_fft_h(hodor_poly *p);
+int hodor_poly_icoset_fft_for_generator_h(hodor_poly *p, const hodor_fr *geninv);
+/* lde / coset_lde (:343-349, also what filtering_lde / coset_filtering_lde :355-368, :484-499 compute): a NEW Values
+ * handle of size * factor; `p` is left as it is (the Rust method consumes self: free it if you mean that).  batch:
+ * all registers at once (src/prover/mod.rs:73-80) — `count` polynomials of one size; the outputs share one slab. */
+int hodor_poly_lde_h(const hodor_poly *p, size_t factor, int coset, hodor_poly **out);
+int hodor_poly_lde_batch_h(const hodor_poly *const *ps, size_t count, size_t factor, int coset, hodor_poly **outs);
+/* add_assign / sub_assign / mul_assign / add_assign_scaled (:640-683, :817-887).  Coefficients: other may be shorter
+ * (assert self.len >= other.len, the first other.len entries change); Values: equal sizes (assert_eq); mul_assign is
+ * Values only.  op = HODOR_OP_*. */
+int hodor_poly_binary_h(hodor_poly *a, const hodor_poly *b, int op);
+int hodor_poly_add_assign_scaled_h(hodor_poly *a, const hodor_poly *b, const hodor_fr *scaling);
+int hodor_poly_evaluate_at_h(hodor_poly *p, const hodor_fr *g, hodor_fr *out);     /* :685-711 (Coefficients) */
+/* (coset_)evaluate_at_domain_for_degree_one (:229-290) of q(x) = c + alpha x on the size-n domain: a Values handle */
+int hodor_poly_degree_one_on_domain_h(hodor_ctx *ctx, size_t n, const hodor_fr *alpha, const hodor_fr *c, int coset,
+                                      hodor_poly **out);
+/* Values: pow / square / add_constant / batch_inversion (:744-771, :831-841, :889-954) */
+int hodor_poly_pow_h(hodor_poly *p, uint64_t e);
+int hodor_poly_square_h(hodor_poly *p);
+int hodor_poly_add_constant_h(hodor_poly *p, const hodor_fr *c);
+int hodor_poly_batch_inversion_h(hodor_poly *p);
+/* one DEEP quotient term in one pass (hodor_poly_quotient_term_dev): acc = (accumulate ? acc : 0) + alpha (f - value) dinv */
+int hodor_poly_quotient_term_h(hodor_poly *acc, const hodor_poly *f, const hodor_poly *divisor_inv, const hodor_fr *value,
+                               const hodor_fr *alpha, int accumulate);
+
+/* IOP::create(values.as_ref()) (src/iop/blake2s_trivial_iop.rs:282-300 -> Blake2sIopTree::create :131-219) over a
+ * device-resident polynomial; batch: one launch sequence for all registers' oracles (src/prover/mod.rs:77-79). */
+int hodor_iop_create_h(const hodor_poly *values, int combiner, hodor_iop **out);
+int hodor_iop_create_batch_h(const hodor_poly *const *values, size_t count, int combiner, hodor_iop **outs);
+void hodor_iop_free_h(hodor_iop *t);
+size_t hodor_iop_size_h(const hodor_iop *t);                     /* number of committed values */
+int hodor_iop_root_h(hodor_iop *t, uint8_t root[32]);            /* get_root :221 (32 bytes, fetched once) */
+int hodor_iop_roots_h(hodor_iop *const *ts, size_t count, uint8_t *roots /* count x 32 */);   /* many roots, one wait */
+int hodor_iop_nodes_h(hodor_iop *t, uint8_t *nodes);             /* the whole heap array (tests; n or n/2 entries) */
+/* IOP::query(natural_index, values.as_ref()) :324-338: value(s) + path; COSET2 returns both members of the coset */
+int hodor_iop_query_h(hodor_iop *t, const hodor_poly *values, size_t natural_index, hodor_fr *values_out, uint8_t *path,
+                      size_t *path_len);
+
+/* FriIop::proof_from_lde(&lde_values, ..) (src/fri/mod.rs:43-54) on a handle; through_coefficients != 0 selects
+ * proof_from_lde_through_coefficients (:156-248).  prototype_into_proof / produce_proof (src/fri/query_producer.rs:10-53)
+ * and verify_prototype (src/fri/verifier.rs:10-129) against the handle the prototype was committed from. */
+int hodor_fri_commit_h(const hodor_poly *lde_values, size_t lde_factor, size_t output_coeffs_at_degree_plus_one,
+                       int combiner, int through_coefficients, hodor_fri_proto **out);
+size_t hodor_fri_produce_proof_h(hodor_fri_proto *p, const hodor_poly *lde_values, size_t natural_first_element_index,
+                                 uint8_t *buf, size_t cap);
+int hodor_fri_verify_prototype_h(hodor_fri_proto *p, const hodor_poly *lde_values, size_t natural_element_index,
+                                 int *valid);
+/* l0_commitment (step = -1) / intermediate_commitments[step] (src/fri/mod.rs:107-109) as an IOP object: a VIEW of the
+ * prototype's tree (valid while the prototype lives, freed with hodor_iop_free_h; the root needs no round trip) */
+int hodor_fri_commitment_h(hodor_fri_proto *p, int step, hodor_iop **out);
+/* intermediate_values[step] (src/fri/mod.rs:110) as a Values handle of its own (a device copy) */
+int hodor_fri_intermediate_values_h(hodor_fri_proto *p, size_t step, hodor_poly **out);
 
 #ifdef __cplusplus
 }

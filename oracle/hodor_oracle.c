@@ -1234,6 +1234,88 @@ int o_fri_commit_combined(const ofield *f, const ofr *lde_values, size_t n, size
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * NaiveFriIop::proof_from_lde_through_coefficients — src/fri/mod.rs:156-248.  The reference's cross-check of
+ * the commit phase: interpolate once (ifft :171, truncate to the degree bound :173), fold the COEFFICIENTS
+ * a_2i + beta a_(2i+1) (:194-203) and re-extend every round with Polynomial::lde (:210-211).  Its own test asserts
+ * the prototype equal to proof_from_lde_by_values field for field (:338-343).  `combiner` as for
+ * o_fri_commit_combined (the reference has TRIVIAL only).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { const ofield *f; const ofr *old; ofr *next; ofr challenge; } cfold_ctx;
+static void cfold_chunk(void *vctx, size_t ci, size_t start, size_t len)
+{
+    (void)ci;
+    cfold_ctx *c = (cfold_ctx *)vctx;
+    for (size_t i = start; i < start + len; i++) {
+        ofr tmp = c->old[2 * i + 1];                 /* :196-201: tmp = old[1] * challenge + old[0] */
+        ofr_mul(c->f, &tmp, &c->challenge);
+        ofr_add(c->f, &tmp, &c->old[2 * i]);
+        c->next[i] = tmp;
+    }
+}
+
+int o_fri_commit_through_coefficients(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
+                                      size_t out_deg_plus_one, int combiner, uint32_t cpus, ofri_proto **outp)
+{
+    if (combiner != O_COMBINER_TRIVIAL && combiner != O_COMBINER_COSET2) return -1;
+    const size_t min_tree = combiner == O_COMBINER_COSET2 ? 4 : 2;
+    if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg_plus_one)) return -1;   /* asserts :165-166 */
+    odomain d;
+    if (odomain_new_for_size(f, n, &d)) return -1;
+    size_t initial_degree_plus_one = n / lde_factor;                                  /* :168 */
+    if (initial_degree_plus_one < 2 * out_deg_plus_one) return -1;   /* num_steps >= 1, else roots.pop() panics (:226) */
+    size_t num_steps = log2_floor(initial_degree_plus_one / out_deg_plus_one);        /* :169 */
+    if ((n >> num_steps) < min_tree) return -1;
+
+    ofri_proto *p = (ofri_proto *)calloc(1, sizeof(ofri_proto));
+    p->num_steps = num_steps;
+    p->initial_degree_plus_one = initial_degree_plus_one;
+    p->output_coeffs_at_degree_plus_one = out_deg_plus_one;
+    p->lde_factor = lde_factor;
+    p->l0_nodes = (uint8_t *)malloc(n * 32);
+    tree_create(combiner, lde_values, n, p->l0_nodes, cpus);                          /* :162 */
+
+    ofr *all = (ofr *)malloc(n * sizeof(ofr));
+    memcpy(all, lde_values, n * sizeof(ofr));
+    o_poly_ifft(f, all, n, cpus);                                                     /* :171 */
+    size_t len = initial_degree_plus_one;                                             /* truncate :173 */
+    ofr *coeffs = (ofr *)malloc(len * sizeof(ofr));
+    memcpy(coeffs, all, len * sizeof(ofr));
+    free(all);
+
+    p->inter_nodes = (uint8_t **)calloc(num_steps, sizeof(uint8_t *));
+    p->inter_values = (ofr **)calloc(num_steps, sizeof(ofr *));
+    p->inter_sizes = (size_t *)calloc(num_steps, sizeof(size_t));
+    p->challenges = (ofr *)calloc(num_steps + 1, sizeof(ofr));
+    ofr challenge;
+    o_interpret_hash(f, p->l0_nodes + 32, &challenge);                                /* :178-179 */
+    p->challenges[0] = challenge;
+    size_t next_len = len / 2;                                                        /* :180 */
+    for (size_t i = 0; i < num_steps; i++) {                                          /* :185 */
+        ofr *next = (ofr *)malloc(next_len * sizeof(ofr));
+        cfold_ctx cc = {f, coeffs, next, challenge};
+        worker_scope(cpus, next_len, cfold_chunk, &cc);                               /* :190-205 */
+        size_t vsize = next_len * lde_factor;
+        ofr *values = (ofr *)malloc(vsize * sizeof(ofr));
+        o_poly_lde(f, next, next_len, lde_factor, 0, values, cpus);                   /* :208-209 from_coeffs + lde */
+        uint8_t *nodes = (uint8_t *)malloc(vsize * 32);
+        tree_create(combiner, values, vsize, nodes, cpus);                            /* :210 */
+        o_interpret_hash(f, nodes + 32, &challenge);                                  /* :213 */
+        p->challenges[i + 1] = challenge;
+        p->inter_nodes[i] = nodes;
+        p->inter_values[i] = values;
+        p->inter_sizes[i] = vsize;
+        free(coeffs);
+        coeffs = next;                                                                /* :221 */
+        next_len >>= 1;
+    }
+    /* challenges.pop() :224; final_root = roots.pop() :226 */
+    memcpy(p->final_root, p->inter_nodes[num_steps - 1] + 32, 32);
+    p->final_coeffs = coeffs;                                                         /* :232-234: len == out_deg_plus_one */
+    *outp = p;
+    return 0;
+}
+
 void o_fri_free(ofri_proto *p)
 {
     if (!p) return;

@@ -151,6 +151,11 @@ int  o_fri_commit(const ofield *f, const ofr *lde_values, size_t n, size_t lde_f
  * prototype hold (size/2)*32 bytes.  Every committed vector needs >= 4 values (lde_factor * out_deg >= 4). */
 int  o_fri_commit_combined(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
                            size_t out_deg_plus_one, int combiner, uint32_t cpus, ofri_proto **out);
+/* NaiveFriIop::proof_from_lde_through_coefficients — src/fri/mod.rs:156-248: the same prototype via ifft ->
+ * coefficient folds a_2i + beta a_(2i+1) -> lde per round (the reference asserts it equal to the by-values
+ * prototype, :338-343). */
+int  o_fri_commit_through_coefficients(const ofield *f, const ofr *lde_values, size_t n, size_t lde_factor,
+                                       size_t out_deg_plus_one, int combiner, uint32_t cpus, ofri_proto **out);
 void o_fri_free(ofri_proto *p);
 /* canonical prototype encoding (defined by this build, the reference has none — SURVEY F10):
  * u64le num_steps | roots[num_steps+1] (l0 + intermediates, 32 B each) | challenges[num_steps]

@@ -375,13 +375,17 @@ class Oracle:
                                                C.c_size_t(len(path)), C.c_size_t(leaf_index)))
 
     # ---- FRI
-    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, cpus=None, combiner=0):
+    def fri_commit(self, lde_values, lde_factor, out_deg_plus_one, cpus=None, combiner=0, through_coefficients=False):
         """Returns dict(serialized=bytes, roots, challenges (Montgomery ints), final_root,
-        final_coeffs (n,4), inter_values [arrays]).  combiner: 0 TRIVIAL (the reference's), 1 COSET2."""
+        final_coeffs (n,4), inter_values [arrays]).  combiner: 0 TRIVIAL (the reference's), 1 COSET2.
+        through_coefficients: proof_from_lde_through_coefficients (src/fri/mod.rs:156-248) instead of
+        proof_from_lde_by_values (src/fri/fri_on_values.rs:11-159)."""
         pp = C.POINTER(OFriProto)()
-        rc = self.L.o_fri_commit_combined(C.byref(self.f), _ptr(lde_values), C.c_size_t(len(lde_values)),
-                                          C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.c_int(combiner),
-                                          C.c_uint32(cpus or self.cpus), C.byref(pp))
+        fn = self.L.o_fri_commit_through_coefficients if through_coefficients else self.L.o_fri_commit_combined
+        fn.restype = C.c_int
+        rc = fn(C.byref(self.f), _ptr(lde_values), C.c_size_t(len(lde_values)),
+                C.c_size_t(lde_factor), C.c_size_t(out_deg_plus_one), C.c_int(combiner),
+                C.c_uint32(cpus or self.cpus), C.byref(pp))
         if rc != 0:
             raise ValueError("o_fri_commit failed")
         p = pp.contents

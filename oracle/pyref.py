@@ -311,6 +311,34 @@ def fri_fold_coeffs(F, coeffs, beta):
     return [(coeffs[2 * i] + beta * coeffs[2 * i + 1]) % F.p for i in range(len(coeffs) // 2)]
 
 
+def fri_commit_through_coefficients(F, lde_values, lde_factor, out_deg_plus_one, combiner=TRIVIAL):
+    """src/fri/mod.rs:156-248: l0 commit (:162), ifft + truncate (:171-173), then per round fold the COEFFICIENTS
+    (:190-205), from_coeffs + lde (:208-209), commit (:210), challenge (:213).  Same dict as fri_commit; the
+    reference's test asserts the two prototypes equal (:338-343)."""
+    n = len(lde_values)
+    initial_degree_plus_one = n // lde_factor
+    num_steps = (initial_degree_plus_one // out_deg_plus_one).bit_length() - 1
+    assert num_steps >= 1
+    nodes = _tree(combiner, [F.to_mont(v) for v in lde_values])
+    roots = [nodes[1]]
+    challenge = interpret_hash(F, nodes[1])
+    challenges = [challenge]
+    coeffs = poly_ifft(F, list(lde_values))[:initial_degree_plus_one]
+    inter = []
+    for _ in range(num_steps):
+        coeffs = fri_fold_coeffs(F, coeffs, challenge)
+        values = poly_lde(F, coeffs, lde_factor)
+        nodes = _tree(combiner, [F.to_mont(v) for v in values])
+        roots.append(nodes[1])
+        challenge = interpret_hash(F, nodes[1])
+        challenges.append(challenge)
+        inter.append(values)
+    challenges.pop()
+    assert len(coeffs) == out_deg_plus_one
+    return dict(roots=roots, challenges=challenges, final_root=roots[-1],
+                final_coeffs=coeffs, inter_values=inter)
+
+
 def fri_serialize(F, proto):
     """Canonical prototype encoding defined by this build (same layout as o_fri_serialize)."""
     out = len(proto["challenges"]).to_bytes(8, "little")

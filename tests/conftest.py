@@ -7,26 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Before the HIP runtime is loaded: let it PRINT an error before it gives up.  Twice in round 4 the long -m gpu run died
-# with a bare SIGABRT raised by a native runtime thread (the main thread sat in a device-to-host copy of a 64-element
-# test; nothing on stderr, never under a debugger, with serialized kernels or with this variable set — 2 of 5 plain runs,
-# 0 of 14 others): with error logging on, a repeat at least says what the runtime objected to.
-os.environ.setdefault("AMD_LOG_LEVEL", "1")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-@pytest.fixture(autouse=True)
-def _gpu_test_boundary(request):
-    """Every GPU test ends with the device idle: whatever a test left in flight (a transform on a side stream, a pending
-    free in the caching allocator) surfaces in THAT test, not in a later one that merely happened to synchronize."""
-    yield
-    if request.node.get_closest_marker("gpu") is not None:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
 
 
 FIELDS = {

@@ -46,18 +46,17 @@ static void test_fft_inverse_identity(const Field &F)
     Domain domain = Domain::new_for_size(F, a.size());
     CHECK(F.pow(domain.generator, a.size()) == F.one());
     auto values = fft(from_coeffs(F, a));
-    CHECK(values.coeffs != a);
+    CHECK(values.as_ref() != a);
     auto back = ifft(std::move(values));
-    CHECK(back.coeffs == a);
+    CHECK(back.as_ref() == a);
     auto cv = coset_fft(from_coeffs(F, a));
-    CHECK(icoset_fft(std::move(cv)).coeffs == a);
+    CHECK(icoset_fft(std::move(cv)).as_ref() == a);
     // any coset generator (coset_fft_for_generator / icoset_fft_for_generator, :633-638, :809-815); with the
     // field's own generator it is coset_fft
     const Fr gen = rand_fr(rng, BN256_FR, 1);
     auto gv = coset_fft_for_generator(from_coeffs(F, a), gen);
-    CHECK(icoset_fft_for_generator(std::move(gv), F.inverse(gen)).coeffs == a);
-    CHECK(coset_fft_for_generator(from_coeffs(F, a), F.multiplicative_generator()).coeffs ==
-          coset_fft(from_coeffs(F, a)).coeffs);
+    CHECK(icoset_fft_for_generator(std::move(gv), F.inverse(gen)).as_ref() == a);
+    CHECK(coset_fft_for_generator(from_coeffs(F, a), F.multiplicative_generator()) == coset_fft(from_coeffs(F, a)));
 }
 
 // test_lde_correctness / test_various_ldes (src/polynomials/mod.rs:988-1130):
@@ -74,14 +73,14 @@ static void test_lde_correctness(const Field &F)
     std::vector<Fr> padded = coeffs;
     padded.resize(N * LDE_FACTOR, F.zero());
     auto naive = fft(from_coeffs(F, padded));
-    CHECK(multi.coeffs == filtering.coeffs);
-    CHECK(multi.coeffs == naive.coeffs);
+    CHECK(multi == filtering);
+    CHECK(multi == naive);
     // coset variant evaluates on g * <Omega>: index 0 is P(g)
     auto cl = coset_lde(poly, LDE_FACTOR);
     Fr g = F.multiplicative_generator(), x = F.one(), acc = F.zero();
     for (size_t i = 0; i < N; i++) { acc = F.add(acc, F.mul(coeffs[i], x)); x = F.mul(x, g); }
-    CHECK(cl.coeffs[0] == acc);
-    CHECK(coset_filtering_lde(from_coeffs(F, coeffs), LDE_FACTOR).coeffs == cl.coeffs);   // :484-499 == :349
+    CHECK(cl.at(0) == acc);
+    CHECK(coset_filtering_lde(from_coeffs(F, coeffs), LDE_FACTOR) == cl);   // :484-499 == :349
     bool threw = false;
     try { lde(poly, 3); } catch (const SynthesisError &) { threw = true; }
     CHECK(threw);
@@ -116,7 +115,7 @@ static void test_make_small_iop_coset2(const Field &F)
     for (size_t i = 0; i < SIZE; i++) { inputs.push_back(f); f = F.add(f, f); }
     auto iop = Coset2Blake2sIOP::create(F, inputs);
     auto root = iop.get_root();
-    CHECK(iop.nodes.size() == SIZE / 2 * 32);
+    CHECK(iop.nodes().size() == SIZE / 2 * 32);
     CHECK(!(root == TrivialBlake2sIOP::create(F, inputs).get_root()));
     for (size_t i = 0; i < SIZE; i++) {
         size_t t = Coset2Combiner::natural_index_into_tree_index(i, SIZE);
@@ -148,7 +147,7 @@ static void test_one_fri_step(const Field &F)
     Fr divisor = F.pow(lde_values.omegainv, coset_index);
     Fr two_inv = F.inverse(F.from_u64(2));
     Fr challenge = proto.challenges[0];
-    Fr value_at_omega = lde_values.coeffs[coset_index], value_at_minus_omega = lde_values.coeffs[coset_pair_index];
+    Fr value_at_omega = lde_values.at(coset_index), value_at_minus_omega = lde_values.at(coset_pair_index);
     Fr t0 = F.add(value_at_omega, value_at_minus_omega);
     Fr t1 = F.mul(F.mul(F.sub(value_at_omega, value_at_minus_omega), divisor), challenge);
     t0 = F.mul(F.add(t0, t1), two_inv);
@@ -158,14 +157,25 @@ static void test_one_fri_step(const Field &F)
         new_coeffs.push_back(F.add(F.mul(lde_coeffs[i + 1], challenge), lde_coeffs[i]));
     CHECK(proto.final_coefficients == new_coeffs);
     auto next_lde = lde(from_coeffs(F, new_coeffs), lde_factor);
-    CHECK(next_lde.coeffs[coset_index] == t0);
-    CHECK(proto.intermediate_values.size() == 1);
-    CHECK(proto.intermediate_values[0].coeffs == next_lde.coeffs);
+    CHECK(next_lde.at(coset_index) == t0);
+    CHECK(proto.num_steps() == 1);
+    CHECK(proto.intermediate_values(0) == next_lde);
     // commitments are the trees of the vectors they commit to; final_root is the last root
-    CHECK(proto.l0_commitment == TrivialBlake2sIOP::create(F, lde_values.coeffs));
-    CHECK(proto.intermediate_commitments[0] == TrivialBlake2sIOP::create(F, next_lde.coeffs));
+    CHECK(proto.l0_commitment() == TrivialBlake2sIOP::create(F, lde_values));
+    CHECK(proto.l0_commitment().nodes() == TrivialBlake2sIOP::create(F, lde_values).nodes());
+    CHECK(proto.intermediate_commitment(0) == TrivialBlake2sIOP::create(F, next_lde));
     CHECK(proto.final_root == proto.get_roots().back());
-    CHECK(proto.challenges[0] == proto.l0_commitment.get_challenge_scalar_from_root());
+    CHECK(proto.challenges[0] == proto.l0_commitment().get_challenge_scalar_from_root());
+    // proof_from_lde_through_coefficients (:156-248): the reference's own assertion, every field equal (:338-343)
+    auto by_coeffs = NaiveFriIop::proof_from_lde_through_coefficients(lde_values, lde_factor, output_at_degree_plus_one);
+    CHECK(by_coeffs.final_coefficients == proto.final_coefficients);
+    CHECK(by_coeffs.final_root == proto.final_root);
+    CHECK(by_coeffs.intermediate_values(0) == proto.intermediate_values(0));
+    CHECK(by_coeffs.challenges == proto.challenges);
+    CHECK(by_coeffs.l0_commitment() == proto.l0_commitment());
+    CHECK(by_coeffs.intermediate_commitment(0) == proto.intermediate_commitment(0));
+    CHECK(by_coeffs.serialized() == proto.serialized());
+    for (size_t i = 1; i < lde_values.size(); i += 2) CHECK(NaiveFriIop::verify_prototype(by_coeffs, lde_values, i));   // :345-349
 }
 
 // from_coeffs pads ragged input to the next power of two with zeros (src/polynomials/mod.rs:146-166);
@@ -177,15 +187,15 @@ static void test_ragged_and_empty_inputs(const Field &F)
     for (auto &v : five) v = rand_fr(rng, BN256_FR, 1);
     auto p = from_coeffs(F, five);
     CHECK(p.size() == 8 && p.exp == 3);
-    CHECK(p.coeffs[5] == F.zero() && p.coeffs[7] == F.zero());
+    CHECK(p.as_ref()[5] == F.zero() && p.at(7) == F.zero());
     std::vector<Fr> padded = five;
     padded.resize(8, F.zero());
-    CHECK(fft(p).coeffs == fft(from_coeffs(F, padded)).coeffs);
+    CHECK(fft(std::move(p)) == fft(from_coeffs(F, padded)));
     auto e = from_coeffs(F, {});
-    CHECK(e.size() == 1 && e.coeffs[0] == F.zero());
-    CHECK(fft(e).coeffs[0] == F.zero());                       // a 1-point transform is the identity
+    CHECK(e.size() == 1 && e.at(0) == F.zero());
+    CHECK(fft(std::move(e)).at(0) == F.zero());                // a 1-point transform is the identity
     auto one = from_coeffs(F, std::vector<Fr>{five[0]});
-    CHECK(lde(one, 4).coeffs == std::vector<Fr>(4, five[0]));  // constant polynomial
+    CHECK(lde(one, 4).as_ref() == std::vector<Fr>(4, five[0]));  // constant polynomial
 }
 
 static void test_domain_errors(const Field &F)
@@ -209,18 +219,19 @@ static void test_fri_proof_and_verifier(const Field &F)
     const size_t lde_factor = 8;
     auto lde_values = lde(from_coeffs(F, coeffs), lde_factor);
     auto proto = NaiveFriIop::proof_from_lde(lde_values, lde_factor, 1);
-    CHECK(proto.intermediate_values.size() == 6 && proto.final_coefficients.size() == 1);
+    CHECK(proto.num_steps() == 6 && proto.final_coefficients.size() == 1);
     for (size_t index : {size_t(1), size_t(77), lde_values.size() - 1}) {
         FRIProof proof = produce_proof(proto, lde_values, index);
         CHECK(proof.queries.size() == 2 * proof.roots.size() && proof.roots.size() == 7);
-        CHECK(NaiveFriIop::verify_proof(F, proof, index, lde_values.coeffs[index]));
-        CHECK(!NaiveFriIop::verify_proof(F, proof, index, F.add(lde_values.coeffs[index], F.one())));
+        CHECK(proof.to_bytes() == produce_proof_bytes(proto, lde_values, index));      // parse / re-encode round trip
+        CHECK(NaiveFriIop::verify_proof(F, proof, index, lde_values.at(index)));
+        CHECK(!NaiveFriIop::verify_proof(F, proof, index, F.add(lde_values.at(index), F.one())));
         FRIProof bad = proof;
         bad.queries[3].value_ = F.add(bad.queries[3].value_, F.one());
-        CHECK(!NaiveFriIop::verify_proof(F, bad, index, lde_values.coeffs[index]));
+        CHECK(!NaiveFriIop::verify_proof(F, bad, index, lde_values.at(index)));
     }
     bool threw = false;   // Err: a point of the half-size sub-domain
-    try { NaiveFriIop::verify_proof(F, produce_proof(proto, lde_values, 2), 2, lde_values.coeffs[2]); }
+    try { NaiveFriIop::verify_proof(F, produce_proof(proto, lde_values, 2), 2, lde_values.at(2)); }
     catch (const SynthesisError &) { threw = true; }
     CHECK(threw);
 }
@@ -253,14 +264,138 @@ static void test_padding_helpers(const Field &F)
     CHECK(!p.pad_by_factor(3) && !p.pad_to_size(100) && !p.pad_to_size(32));
     CHECK(p.pad_by_factor(1) && p.size() == 64);
     CHECK(p.pad_by_factor(4) && p.size() == 256 && p.exp == 8);
-    for (size_t i = 64; i < 256; i++) CHECK(p.coeffs[i] == F.zero());
-    auto padded = fft(p);
+    { auto v = p.as_ref(); for (size_t i = 64; i < 256; i++) CHECK(v[i] == F.zero()); }
+    auto padded = fft(std::move(p));
     auto direct = lde(from_coeffs(F, c), 4);
     CHECK(padded.as_ref() == direct.as_ref());
     auto q = from_coeffs(F, c);
     CHECK(q.pad_to_size(128) && q.size() == 128 && q.exp == 7);
     q.trim_to_degree(9);
-    for (size_t i = 0; i < 128; i++) CHECK(i < 10 ? q.coeffs[i] == c[i] : q.coeffs[i] == F.zero());
+    { auto v = q.as_ref(); for (size_t i = 0; i < 128; i++) CHECK(i < 10 ? v[i] == c[i] : v[i] == F.zero()); }
+}
+
+
+// The value-form surface ALI calls (src/polynomials/mod.rs:54-83, :640-711, :744-771, :817-954) on device-resident
+// polynomials, each against the same operation done element by element on the host field
+static void test_value_form_methods(const Field &F)
+{
+    XorShiftRng rng;
+    const size_t N = 1u << 9;
+    std::vector<Fr> a(N), b(N);
+    for (auto &v : a) v = rand_fr(rng, BN256_FR, 1);
+    for (auto &v : b) v = rand_fr(rng, BN256_FR, 1);
+    const Fr s = rand_fr(rng, BN256_FR, 1);
+    auto expect = [&](const Polynomial<Values> &p, auto fn) {
+        auto v = p.as_ref();
+        for (size_t i = 0; i < N; i++) CHECK(v[i] == fn(i));
+    };
+    auto pa = from_values(F, a), pb = from_values(F, b);
+    { auto t = pa.clone(); t.add_assign(pb); expect(t, [&](size_t i) { return F.add(a[i], b[i]); }); }
+    { auto t = pa.clone(); t.sub_assign(pb); expect(t, [&](size_t i) { return F.sub(a[i], b[i]); }); }
+    { auto t = pa.clone(); t.mul_assign(pb); expect(t, [&](size_t i) { return F.mul(a[i], b[i]); }); }
+    { auto t = pa.clone(); t.add_assign_scaled(pb, s); expect(t, [&](size_t i) { return F.add(a[i], F.mul(b[i], s)); }); }
+    { auto t = pa.clone(); t.scale(s); expect(t, [&](size_t i) { return F.mul(a[i], s); }); }
+    { auto t = pa.clone(); t.negate(); expect(t, [&](size_t i) { return F.negate(a[i]); }); }
+    { auto t = pa.clone(); t.square(); expect(t, [&](size_t i) { return F.mul(a[i], a[i]); }); }
+    { auto t = pa.clone(); t.pow(5); expect(t, [&](size_t i) { return F.pow(a[i], 5); }); }
+    { auto t = pa.clone(); t.pow(2); expect(t, [&](size_t i) { return F.mul(a[i], a[i]); }); }    // :746-748
+    { auto t = pa.clone(); t.add_constant(s); expect(t, [&](size_t i) { return F.add(a[i], s); }); }
+    { auto t = pa.clone(); t.distribute_powers(s); Fr x = F.one(); auto v = t.as_ref();
+      for (size_t i = 0; i < N; i++) { CHECK(v[i] == F.mul(a[i], x)); x = F.mul(x, s); } }
+    {   // test_batch_inversion (:959-985)
+        auto t = pa.clone();
+        CHECK(t.batch_inversion());
+        expect(t, [&](size_t i) { return F.inverse(a[i]); });
+        auto z = pa.clone();
+        z.set(17, F.zero());
+        CHECK(!z.batch_inversion());                  // Err(SynthesisError::Error), data untouched (:909)
+        CHECK(z.at(16) == a[16] && z.at(17) == F.zero());
+    }
+    {   // evaluate_at (:685-711) and the degree-one divisor of calculate_deep (deep.rs:58-72)
+        auto c = from_coeffs(F, a);
+        Fr x = F.one(), acc = F.zero();
+        for (size_t i = 0; i < N; i++) { acc = F.add(acc, F.mul(a[i], x)); x = F.mul(x, s); }
+        CHECK(c.evaluate_at(s) == acc);
+        auto q = Polynomial<Coefficients>::new_for_size(F, 2);
+        q.set(1, F.one());                            // q_poly.as_mut()[1] = F::one()        deep.rs:61
+        q.sub_assign_at(0, s);                        // q_poly.as_mut()[0].sub_assign(&root) deep.rs:62
+        const uint64_t before = F.host_round_trips();
+        auto d = evaluate_at_domain_for_degree_one(q, N);
+        CHECK(F.host_round_trips() == before);        // built on the host, evaluated on the device: nothing came back
+        Domain dom = Domain::new_for_size(F, N);
+        Fr u = F.one();
+        auto v = d.as_ref();
+        for (size_t i = 0; i < N; i++) { CHECK(v[i] == F.sub(u, s)); u = F.mul(u, dom.generator); }
+        auto dc = evaluate_at_domain_for_degree_one(q, N, true);
+        CHECK(dc.at(0) == F.sub(F.multiplicative_generator(), s));
+    }
+    {   // Coefficients: the other operand may be shorter (:641), Values: sizes must agree (:818)
+        auto big = from_coeffs(F, a);
+        std::vector<Fr> small_v(b.begin(), b.begin() + 64);
+        auto small_p = from_coeffs(F, small_v);
+        big.add_assign(small_p);
+        auto v = big.as_ref();
+        for (size_t i = 0; i < N; i++) CHECK(v[i] == (i < 64 ? F.add(a[i], b[i]) : a[i]));
+        bool threw = false;
+        try { small_p.add_assign(big); } catch (const SynthesisError &) { threw = true; }
+        CHECK(threw);
+        auto vs = from_values(F, small_v);
+        threw = false;
+        try { pa.add_assign(vs); } catch (const SynthesisError &) { threw = true; }
+        CHECK(threw);
+    }
+    {   // from_roots (:168-227) against the product of the linear factors evaluated at a point
+        std::vector<Fr> roots(b.begin(), b.begin() + 13);
+        auto z = from_roots(F, roots);
+        CHECK(z.size() == 16);
+        Fr prod = F.one();
+        for (auto &r : roots) prod = F.mul(prod, F.sub(s, r));
+        CHECK(z.evaluate_at(s) == prod);
+        CHECK(z.evaluate_at(roots[5]) == F.zero());
+    }
+    {   // the fused quotient term == the five passes it replaces (deep.rs:74-84)
+        auto inv = pb.clone();
+        CHECK(inv.batch_inversion());
+        auto t = pa.clone();
+        t.add_constant(F.negate(a[3]));
+        t.scale(s);
+        t.mul_assign(inv);
+        auto acc = Polynomial<Values>::new_for_size(F, N);
+        auto sum = acc.clone();
+        sum.add_assign(t);
+        quotient_term(acc, pa, inv, a[3], &s, true);
+        CHECK(acc == sum);
+    }
+}
+
+// Prover::prove's use of the types (src/prover/mod.rs:73-95, :142-151): every register's LDE and oracle in one call
+// each, roots in one wait, queries from the device-resident oracles; equal to the one-by-one calls
+static void test_batched_ldes_and_oracles(const Field &F)
+{
+    XorShiftRng rng;
+    const size_t N = 1u << 8, LDE_FACTOR = 8, REGS = 3;
+    std::vector<Polynomial<Coefficients>> ws;
+    for (size_t r = 0; r < REGS; r++) {
+        std::vector<Fr> c(N);
+        for (auto &v : c) v = rand_fr(rng, BN256_FR, 1);
+        ws.push_back(from_coeffs(F, c));
+    }
+    auto f_ldes = lde_all(ws, LDE_FACTOR);
+    auto f_oracles = TrivialBlake2sIOP::create_all(F, f_ldes);
+    auto roots = TrivialBlake2sIOP::get_roots(F, f_oracles);
+    for (size_t r = 0; r < REGS; r++) {
+        auto single = lde(ws[r], LDE_FACTOR);
+        CHECK(f_ldes[r] == single);
+        auto tree = TrivialBlake2sIOP::create(F, single);
+        CHECK(tree.get_root() == roots[r] && tree.nodes() == f_oracles[r].nodes());
+        auto q = f_oracles[r].query(77, f_ldes[r]);
+        CHECK(q.value() == single.at(77) && TrivialBlake2sIOP::verify_query(F, q, roots[r]));
+    }
+    // an in-place method on one of the views leaves its siblings alone
+    auto keep = f_ldes[1].clone();
+    f_ldes[0].scale(F.from_u64(3));
+    auto back = ifft(std::move(f_ldes[2]));
+    CHECK(back.size() == N * LDE_FACTOR && f_ldes[1] == keep);
 }
 
 // The multi-GPU building blocks from compiled host code (what a Rust process per GPU binds): P = 2 ranks
@@ -341,6 +476,8 @@ int main()
     test_fri_proof_and_verifier(F);
     test_sixstep_two_ranks(F);
     test_padding_helpers(F);
+    test_value_form_methods(F);
+    test_batched_ldes_and_oracles(F);
     printf("host_cpp: all tests passed\n");
     return 0;
 }

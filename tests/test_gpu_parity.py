@@ -360,6 +360,57 @@ def test_fri_by_values_equals_through_coefficients_on_device(gpu_ctxs, oracles, 
     proto.free()
 
 
+@pytest.mark.parametrize("log_deg,lde_factor,out_deg", [(2, 4, 2), (3, 4, 1), (4, 2, 1), (5, 32, 2), (6, 8, 1), (8, 16, 2),
+                                                        (9, 4, 8), (10, 2, 1), (11, 8, 1), (13, 8, 4), (15, 4, 1),
+                                                        (18, 8, 1)])
+def test_fri_commit_through_coefficients_matches_oracle(gpu_ctxs, oracles, field_name, log_deg, lde_factor, out_deg):
+    """proof_from_lde_through_coefficients (src/fri/mod.rs:156-248) as an entry point of its own
+    (hodor_fri_commit_through_coefficients): field by field equal to the CPU oracle's restatement of that function
+    AND to the by-values prototype of the device — the reference's own assertion (:338-343).  (2, 4, 2) with the
+    coefficients 1, 2, 4, 8 is test_one_fri_step's shape (:270-285)."""
+    import torch
+    ctx, O, F = gpu_ctxs[field_name], oracles[field_name], PYF[field_name]
+    if log_deg == 2:
+        coeffs = np.ascontiguousarray(np.array([[(F.to_mont(1 << k) >> (64 * i)) & (2**64 - 1) for i in range(4)]
+                                                for k in range(4)], dtype=np.uint64))
+    else:
+        coeffs = O.random_elements(1 << log_deg, 77 + log_deg)
+    lde = O.poly_lde(coeffs, lde_factor)
+    n = len(lde)
+    for combiner in (0, 1):
+        if combiner == 1 and lde_factor * out_deg < 4:
+            continue
+        exp = O.fri_commit(lde, lde_factor, out_deg, combiner=combiner, through_coefficients=True)
+        d_lde = torch.from_numpy(lde.view(np.int64)).cuda()
+        got = ctx.fri_commit_dev(d_lde, n, lde_factor, out_deg, combiner=combiner, through_coefficients=True)
+        by_values = ctx.fri_commit_dev(d_lde, n, lde_factor, out_deg, combiner=combiner)
+        for proto in (got, by_values):
+            assert proto.num_steps == exp["num_steps"]
+            assert proto.roots == exp["roots"]
+            assert proto.challenges == exp["challenges"]
+            assert proto.final_root == exp["final_root"]
+            assert np.array_equal(proto.final_coeffs, exp["final_coeffs"])
+            assert proto.serialized == exp["serialized"]
+        tree_div = 2 if combiner == 1 else 1
+        for i in range(got.num_steps):
+            sz = n >> (i + 1)
+            assert np.array_equal(got.intermediate_values(i, sz), exp["inter_values"][i]), i
+            assert np.array_equal(got.tree_nodes(i, sz // tree_div), by_values.tree_nodes(i, sz // tree_div)), i
+        assert np.array_equal(got.tree_nodes(-1, n // tree_div), by_values.tree_nodes(-1, n // tree_div))
+        # the query phase and the folding verifier work on this prototype like on the other (:345-349)
+        for index in (1, n - 1):
+            assert got.verify_prototype(d_lde, index) is True
+            assert got.produce_proof(d_lde, index)["raw"] == by_values.produce_proof(d_lde, index)["raw"]
+        got.free()
+        by_values.free()
+    if log_deg <= 8:   # the slice entry point, host memory in
+        h = ctx.fri_commit(lde, lde_factor, out_deg, through_coefficients=True)
+        assert h.serialized == O.fri_commit(lde, lde_factor, out_deg)["serialized"]
+        h.free()
+    with pytest.raises(Exception):
+        ctx.fri_commit(lde, lde_factor, 1 << log_deg, through_coefficients=True)     # no folding step (:226 panics)
+
+
 @pytest.mark.parametrize("log_code", [22, 26])
 def test_fri_commit_benchmark_size_is_accepted_by_the_verifiers(gpu_ctxs, oracles, log_code):
     """BASELINE config[3]: 2^26 codeword = lde(8) of 2^23 coefficients, 23 rounds.  No CPU run of that size;

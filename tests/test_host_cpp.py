@@ -33,6 +33,61 @@ def test_reference_tests_in_cpp(tmp_path):
     assert "all tests passed" in out.stdout
 
 
+# ---------------------------------------------------------------- Prover::prove's shape through hodor.hpp only
+PS_SRC = os.path.join(ROOT, "tests", "host_cpp", "prove_shape.cpp")
+
+
+def _build_prove_shape(tmp_path):
+    import hodor_amd
+    hodor_amd.build()
+    exe = str(tmp_path / "prove_shape")
+    libdir = os.path.join(ROOT, "hodor_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", PS_SRC, "-L" + libdir, "-lhodor_gpu",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_prove_shape_replay_compiles_against_the_host_mirror(tmp_path):
+    """CPU: the prover-shaped replay uses nothing but hodor.hpp (no `_dev` entry point, device pointer or stream in its
+    source) and links against the C ABI alone."""
+    assert os.path.exists(_build_prove_shape(tmp_path))
+    src = open(PS_SRC).read()
+    code = "\n".join(l.split("//")[0] for l in src.splitlines())
+    assert "_dev(" not in code and "hipStream" not in code and "dev_ptr" not in code
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_rows,registers,lde_factor,combiner", [(6, 2, 4, 0), (10, 4, 16, 0), (12, 3, 8, 0), (10, 4, 16, 1)])
+def test_prove_shape_from_cpp_is_byte_identical_to_the_cpu_port(tmp_path, oracles, log_rows, registers, lde_factor, combiner):
+    """The phases of Prover::prove (src/prover/mod.rs:66-174; cubic_vdf.rs:288-354) driven from C++ through the
+    device-resident Polynomial / IOP / FRI objects of hodor.hpp: the assembled proof bytes equal the bytes the CPU
+    oracle assembles for the same synthetic instance (tests/prove_shape_ref.py), and the library counted no more
+    host round trips than the schedule has results to hand over."""
+    import json
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import prove_shape_ref as ps
+    from oracle import pyref as P
+    exe = _build_prove_shape(tmp_path)
+    out_bin = str(tmp_path / "proof.bin")
+    run = subprocess.run([exe, str(log_rows), str(registers), str(lde_factor), str(combiner), out_bin, "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    O = oracles["bn256"]
+    trace, prep = ps.make_trace(O, log_rows, registers)
+    exp, _, _ = ps.prove(ps.OracleProver(O, P.BN256, combiner=combiner), trace, prep, lde_factor)
+    got = open(out_bin, "rb").read()
+    assert len(got) == line["proof_bytes"] == len(exp)
+    assert got == exp
+    # roots (1 wait for all f oracles + 1 for g), 4 evaluations, 3 batch inversions, 2 prototypes, 2 FRI proofs,
+    # registers + 1 oracle queries
+    assert 0 < line["host_round_trips"] <= 2 + 4 + 3 + 2 + 2 + registers + 1
+    assert set(line["phases_ms"]) == set(ps.PHASES)
+
+
 # ---------------------------------------------------------------- plain C (the boundary is a C ABI)
 C_SRC = os.path.join(ROOT, "tests", "host_c", "test_abi.c")
 

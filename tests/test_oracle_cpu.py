@@ -191,6 +191,38 @@ def test_fri_by_values_equals_through_coefficients(oracles, field_name):
     assert r["final_root"] == r["roots"][-1]
 
 
+def test_fri_through_coefficients_prototype_equals_by_values(oracles, field_name):
+    """proof_from_lde_through_coefficients (src/fri/mod.rs:156-248) restated in C and in Python: the reference's own
+    assertion — every field of the two prototypes equal (:338-343) — on its test shape (4 coefficients 1, 2, 4, 8,
+    lde_factor 4, output_at_degree_plus_one 2, :270-285) and on wider ones, both tree formats."""
+    O, F = oracles[field_name], PYF[field_name]
+    shapes = [(None, 4, 2), (16, 4, 1), (64, 8, 1), (32, 2, 4), (8, 16, 2)]
+    for deg, f, outd in shapes:
+        coeffs = mont_array(F, [1, 2, 4, 8]) if deg is None else O.random_elements(deg, 31 + deg)
+        lde = O.poly_lde(coeffs, f)
+        for combiner in (0, 1):
+            if combiner == 1 and f * outd < 4:
+                continue
+            a = O.fri_commit(lde, f, outd, combiner=combiner)
+            b = O.fri_commit(lde, f, outd, combiner=combiner, through_coefficients=True)
+            assert a["serialized"] == b["serialized"] and a["roots"] == b["roots"]
+            assert a["challenges"] == b["challenges"] and a["final_root"] == b["final_root"]
+            assert np.array_equal(a["final_coeffs"], b["final_coeffs"])
+            assert len(a["inter_values"]) == len(b["inter_values"])
+            assert all(np.array_equal(x, y) for x, y in zip(a["inter_values"], b["inter_values"]))
+            if len(lde) <= 256:     # the independent Python twin, small cases
+                py = P.fri_commit_through_coefficients(F, canon_list(F, lde), f, outd, combiner=combiner)
+                assert P.fri_serialize(F, py) == b["serialized"]
+                assert [canon_list(F, v) for v in b["inter_values"]] == py["inter_values"]
+    # the verdict of the reference's test body (:287-330): one fold of the coefficients IS the final polynomial
+    lde = O.poly_lde(mont_array(F, [1, 2, 4, 8]), 4)
+    r = O.fri_commit(lde, 4, 2, through_coefficients=True)
+    beta = F.from_mont(r["challenges"][0])
+    assert canon_list(F, r["final_coeffs"]) == [(1 + beta * 2) % F.p, (4 + beta * 8) % F.p]
+    with pytest.raises(ValueError):
+        O.fri_commit(lde, 4, 4, through_coefficients=True)      # no folding step: roots.pop() panics (:226)
+
+
 def test_value_form_ops_against_bigint(oracles, field_name):
     """test_batch_inversion (src/polynomials/mod.rs:959-985): batch inverse == per-element inverse;
     pointwise ops against Python big-int arithmetic."""
