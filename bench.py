@@ -58,7 +58,7 @@ WARM_MS = 150.0           # clocks settle after ~100 ms of load: warm up by time
 FIXTURES = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
 KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_MIN_LOG_C", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TW_SUB", "HODOR_NTT_W9", "HODOR_NTT_P1",
              "HODOR_MERKLE_TAIL_LOG", "HODOR_MERKLE_LAT_LOG", "HODOR_FRI_TAIL", "HODOR_FRI_FUSE_FOLD",
-             "HODOR_BATCHINV_SEQ", "HODOR_TABLE_CACHE", "HODOR_DBG", "HODOR_LIB")
+             "HODOR_BATCHINV_SEQ", "HODOR_TABLE_CACHE", "HODOR_POOL_CACHE_GIB", "HODOR_DBG", "HODOR_LIB")
 
 
 def digest(t):

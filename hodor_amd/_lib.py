@@ -56,7 +56,7 @@ EXPORTS = [
     "hodor_fri_verify_proof_strict_combined",
     "hodor_ipc_export", "hodor_ipc_import", "hodor_ipc_close", "hodor_exchange_create_direct", "hodor_exchange_direct_flags",
     "hodor_exchange_direct_set_peers", "hodor_exchange_direct_begin_dev", "hodor_exchange_direct_signal_dev",
-    "hodor_exchange_direct_wait_dev", "hodor_exchange_direct_release_dev", "hodor_sixstep_columns_direct_dev",
+    "hodor_exchange_direct_wait_dev", "hodor_exchange_direct_release_dev", "hodor_exchange_direct_status", "hodor_sixstep_columns_direct_dev",
     "hodor_sixstep_rows_direct_dev",
     "hodor_exchange_available", "hodor_exchange_unique_id", "hodor_exchange_create", "hodor_exchange_adopt",
     "hodor_exchange_destroy", "hodor_sixstep_exchange_dev", "hodor_sixstep_exchange_wait_dev",
@@ -491,6 +491,18 @@ class DirectExchange:
             pass
 
 
+_LIVE_CONTEXTS = weakref.WeakSet()
+
+
+def trim_all():
+    """Every live context gives its idle pool blocks back to HIP (tests that need most of the HBM for themselves)."""
+    for c in list(_LIVE_CONTEXTS):
+        try:
+            c.trim()
+        except HodorError:
+            pass
+
+
 class Context:
     """hodor_ctx: one prime field + one device (device=-1: host-only helpers, no compute)."""
 
@@ -503,7 +515,8 @@ class Context:
         rc = self.L.hodor_ctx_create(mod, C.c_uint64(generator), C.c_int(device), C.byref(self.h))
         if rc != OK:
             raise HodorError(rc, "hodor_ctx_create")
-        self.modulus = modulus
+        self.modulus, self.device = modulus, device
+        _LIVE_CONTEXTS.add(self)
         info = _FieldInfo()
         self._chk(self.L.hodor_ctx_field_info(self.h, C.byref(info)))
         self.S, self.num_bits, self.capacity = int(info.s), int(info.num_bits), int(info.capacity)
@@ -511,8 +524,23 @@ class Context:
         self.generator = _to_int(info.generator.l)
         self.root_of_unity = _to_int(info.root_of_unity.l)
 
+    def trim(self):
+        """Idle blocks of the context's device pool (FRI prototypes, handles) back to HIP."""
+        if self.h and self.device >= 0:
+            self._chk(self.L.hodor_ctx_trim(self.h))
+
+    def pool_stats(self):
+        cached, live = C.c_size_t(), C.c_size_t()
+        self._chk(self.L.hodor_ctx_pool_stats(self.h, C.byref(cached), C.byref(live)))
+        return cached.value, live.value
+
+    def host_round_trips(self):
+        self.L.hodor_ctx_host_round_trips.restype = C.c_uint64
+        return int(self.L.hodor_ctx_host_round_trips(self.h))
+
     def close(self):
         if self.h:
+            _LIVE_CONTEXTS.discard(self)
             for proto in list(self._protos):
                 proto.free()
             for x in list(self._exchanges):

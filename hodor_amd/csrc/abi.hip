@@ -495,6 +495,7 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
         ctx->tw_hi_max_log = (uint32_t)k.tw_hi_max_log;
         ctx->tile_log = (uint32_t)k.tile_log;
         ctx->min_log_c = (uint32_t)k.min_log_c;
+        ctx->pool_cache_cap = (size_t)k.pool_cache_gib << 30;
         if (ctx->max_log_r > ctx->tile_log) ctx->max_log_r = ctx->tile_log;
     }
     *out = ctx;
@@ -519,7 +520,6 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         for (int i = 0; i < 2; i++)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
         if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
-        if (ctx->fri_slab) (void)hipFree(ctx->fri_slab);
         pool_drain(ctx);
         for (auto &L : ctx->lanes) {
             for (int i = 0; i < 2; i++)

@@ -509,9 +509,11 @@ extern "C" int hodor_exchange_direct_begin_dev(hodor_exchange *x, void *stream, 
     std::lock_guard<std::mutex> lk(x->mu);
     int rc = direct_ready(x, slot);
     if (rc) return rc;
-    const uint32_t g = ++x->slots[slot].produced;
+    const uint32_t g = x->slots[slot].produced + 1;
     // every peer must have finished reading what this rank put into the slot last time
-    return g > 1 ? direct_wait(x, (hipStream_t)stream, slot, 1, g - 1) : HODOR_OK;
+    if (g > 1 && (rc = direct_wait(x, (hipStream_t)stream, slot, 1, g - 1))) return rc;
+    x->slots[slot].produced = g;   // the generation opens only once its wait is in the queue
+    return HODOR_OK;
 }
 
 extern "C" int hodor_exchange_direct_signal_dev(hodor_exchange *x, void *stream, uint32_t slot)
@@ -534,8 +536,24 @@ extern "C" int hodor_exchange_direct_wait_dev(hodor_exchange *x, void *stream, u
     std::lock_guard<std::mutex> lk(x->mu);
     int rc = direct_ready(x, slot);
     if (rc) return rc;
-    const uint32_t g = ++x->slots[slot].consumed;
-    return direct_wait(x, (hipStream_t)stream, slot, 0, g);
+    const uint32_t g = x->slots[slot].consumed + 1;
+    if ((rc = direct_wait(x, (hipStream_t)stream, slot, 0, g))) return rc;
+    x->slots[slot].consumed = g;
+    return HODOR_OK;
+}
+
+// A wait that gave up (~10 s without its peers) lets the stream run on: what the consumer transform then reads — or the
+// producer overwrites — is UNDEFINED for that generation.  The flag it leaves behind is host-visible; call this after
+// synchronising the stream the generation ran on (hodor_amd/sixstep.py does in every *_end) before using the result.
+// HODOR_ERR_DEVICE: some wait on this handle has timed out; every later call on the handle fails the same way.
+extern "C" int hodor_exchange_direct_status(hodor_exchange *x)
+{
+    if (!x || !x->ctx || !x->d_err) return HODOR_ERR_INVALID;
+    if (*(volatile uint32_t *)x->d_err) {
+        set_err(x->ctx, "exchange (direct): a wait for a peer timed out; the results of that generation are undefined");
+        return HODOR_ERR_DEVICE;
+    }
+    return HODOR_OK;
 }
 
 extern "C" int hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream, uint32_t slot)
@@ -578,8 +596,9 @@ extern "C" int hodor_exchange_direct_copy_dev(hodor_exchange *x, void *stream, u
     HIPCHK(hipEventRecord(x->ready, (hipStream_t)stream));
     HIPCHK(hipStreamWaitEvent(x->comm_stream, x->ready, 0));
     if (chunk == 0) {
-        const uint32_t g = ++x->slots[slot].produced;
+        const uint32_t g = x->slots[slot].produced + 1;
         if (g > 1 && (rc = direct_wait(x, x->comm_stream, slot, 1, g - 1))) return rc;
+        x->slots[slot].produced = g;
     } else if (x->slots[slot].produced == 0) {
         set_err(ctx, "exchange (copy): chunk 0 opens a generation");
         return HODOR_ERR_INVALID;

@@ -2,27 +2,17 @@
 // proof bytes, the two verifiers and the prototype accessors.
 #include "ctx.hpp"
 
-// The prototype's device buffers (l0 tree, every intermediate vector and tree, the small result block)
-// are carved from ONE slab; a freed slab is parked on the context and reused by the next commit of a
-// size that fits, so a prover committing polynomial after polynomial pays hipMalloc once.
+// The prototype's device buffers (l0 tree, every intermediate vector and tree, the small result block) are carved
+// from ONE slab out of the context's device pool (abi_poly.hip): a prover committing polynomial after polynomial
+// meets hipMalloc once per size.  (Rounds 1-4 parked one freed slab on the context and paid hipMalloc + hipFree for
+// every other: 6 GB allocated while the queue is busy stalled the free-running proof run of round 5 by ~190 ms.)
+// Every entry point that enqueues work on the slab synchronises before it returns, so a slab is idle when it is
+// released and the next commit may use it on any stream.
 extern "C" void hodor_fri_free(hodor_fri_proto *p)
 {
     if (!p) return;
     hodor_ctx *ctx = p->ctx;
-    if (ctx && ctx->device >= 0 && p->slab) {
-        (void)hipSetDevice(ctx->device);
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (!ctx->fri_slab) {
-            ctx->fri_slab = p->slab;
-            ctx->fri_slab_bytes = p->slab_bytes;
-        } else if (p->slab_bytes > ctx->fri_slab_bytes) {
-            (void)hipFree(ctx->fri_slab);
-            ctx->fri_slab = p->slab;
-            ctx->fri_slab_bytes = p->slab_bytes;
-        } else {
-            (void)hipFree(p->slab);
-        }
-    }
+    if (ctx && p->slab) pool_release(ctx, p->slab, p->slab_bytes);
     delete p;
 }
 
@@ -90,18 +80,13 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
     size_t need = up(n * 32) + up(small_bytes);
     for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
     auto fri_release = [&](hodor_fri_proto *q) {   // error path: the ctx mutex is already held
-        if (q->slab) (void)hipFree(q->slab);
+        if (q->slab) {
+            (void)hipStreamSynchronize(stream);    // whatever was enqueued on the slab before the error
+            pool_release(ctx, q->slab, q->slab_bytes);
+        }
         delete q;
     };
-    if (ctx->fri_slab && ctx->fri_slab_bytes >= need) {
-        p->slab = ctx->fri_slab;
-        p->slab_bytes = ctx->fri_slab_bytes;
-        ctx->fri_slab = nullptr;
-        ctx->fri_slab_bytes = 0;
-    } else {
-        FRICHK(hipMalloc(&p->slab, need));
-        p->slab_bytes = need;
-    }
+    if ((rc = pool_alloc(ctx, need, &p->slab, &p->slab_bytes))) { delete p; return rc; }
     uint8_t *cursor = (uint8_t *)p->slab;
     auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
     p->l0_nodes = carve(n * 32);
@@ -232,7 +217,10 @@ extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *s
     p->initial_degree_plus_one = initial_degree_plus_one;
     p->combiner = combiner;
     auto release = [&](hodor_fri_proto *q) {   // error path: the ctx mutex is already held
-        if (q->slab) (void)hipFree(q->slab);
+        if (q->slab) {
+            (void)hipStreamSynchronize(stream);
+            pool_release(ctx, q->slab, q->slab_bytes);
+        }
         delete q;
     };
 #define FRICHK(expr)                                                                   \
@@ -251,15 +239,7 @@ extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *s
     const size_t small_bytes = 64 * (num_steps + 1);
     size_t need = up(n * 32) + up(small_bytes) + up(n * 32) + up(initial_degree_plus_one * 16);
     for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
-    if (ctx->fri_slab && ctx->fri_slab_bytes >= need) {
-        p->slab = ctx->fri_slab;
-        p->slab_bytes = ctx->fri_slab_bytes;
-        ctx->fri_slab = nullptr;
-        ctx->fri_slab_bytes = 0;
-    } else {
-        FRICHK(hipMalloc(&p->slab, need));
-        p->slab_bytes = need;
-    }
+    if ((rc = pool_alloc(ctx, need, &p->slab, &p->slab_bytes))) { delete p; return rc; }
     uint8_t *cursor = (uint8_t *)p->slab;
     auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
     p->l0_nodes = carve(n * 32);

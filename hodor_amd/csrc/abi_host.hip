@@ -187,6 +187,14 @@ extern "C" int hodor_iop_verify_combined(const hodor_ctx *ctx, const uint8_t roo
     if (combiner != HODOR_COMBINER_COSET2 || !ctx || !root || !values || (!path && path_len) || !ok)
         return HODOR_ERR_INVALID;
     if (!is_pow2(n) || n < 4 || natural_index >= n) return HODOR_ERR_SIZE;
+    *ok = 0;
+    // COSET2 is this build's own format and its leaf compresses like a node (64 bytes, t = 128): what tells a leaf
+    // from an interior node is its DEPTH.  A path of any other length than log2(n) - 1 would let a prover open the two
+    // child digests of an interior node as a "coset value pair" — refused here, for every caller (the FRI walks
+    // included).  The same for values that are not canonical residues: two byte strings must not open as one element.
+    if (path_len != (size_t)log2u(n) - 1) return HODOR_OK;
+    for (int k = 0; k < 2; k++)
+        if (HostField::geq(values[k].l, ctx->F.p)) return HODOR_OK;
     uint8_t h[32], t[32];
     host_hash_pair(ctx, values, values + 1, h);
     size_t idx = natural_index % (n / 2);
@@ -299,6 +307,7 @@ static Knobs read_knobs()
     k.fri_fuse_fold = get("HODOR_FRI_FUSE_FOLD", 1, 0, 2);
     k.batchinv_seq = get("HODOR_BATCHINV_SEQ", 8, 2, 64);
     k.table_cache = get("HODOR_TABLE_CACHE", 40, 1, 1000);
+    k.pool_cache_gib = get("HODOR_POOL_CACHE_GIB", 64, 0, 4096);
     return k;
 }
 const Knobs &knobs()

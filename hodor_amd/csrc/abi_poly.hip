@@ -65,10 +65,25 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got)
 void pool_release(hodor_ctx *ctx, void *p, size_t bytes)
 {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(ctx->pool_mu);
-    ctx->pool_live -= bytes;
-    ctx->pool_free.emplace(bytes, p);
-    ctx->pool_cached += bytes;
+    std::vector<void *> spill;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        ctx->pool_live -= bytes;
+        ctx->pool_free.emplace(bytes, p);
+        ctx->pool_cached += bytes;
+        // over the cap: the largest idle blocks go back to HIP (a process that has walked through many sizes — a test
+        // suite — must not sit on all of them; a prover repeating one shape never gets here)
+        while (ctx->pool_cached > ctx->pool_cache_cap && !ctx->pool_free.empty()) {
+            auto it = std::prev(ctx->pool_free.end());
+            ctx->pool_cached -= it->first;
+            spill.push_back(it->second);
+            ctx->pool_free.erase(it);
+        }
+    }
+    if (!spill.empty()) {
+        (void)hipDeviceSynchronize();   // a spilled block may still be read by work enqueued before its release
+        for (void *q : spill) (void)hipFree(q);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -169,8 +169,6 @@ struct hodor_ctx {
     std::mutex lane_mu;
     std::condition_variable lane_cv;
     std::atomic<int> live_exchanges{0};   // hodor_exchange handles that point at this context (abi_exchange.hip)
-    void *fri_slab = nullptr;  // parked FRI prototype slab (see hodor_fri_free)
-    size_t fri_slab_bytes = 0;
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
     uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
     uint32_t min_log_c = 2;    // fewest tile columns per pass (2^2 x 32 B = 128-byte runs)
@@ -181,6 +179,7 @@ struct hodor_ctx {
     // Polynomial operations with temporaries never meets hipMalloc / hipFree (which synchronise the device).
     std::multimap<size_t, void *> pool_free;
     size_t pool_cached = 0, pool_live = 0;
+    size_t pool_cache_cap = (size_t)64 << 30;   // idle bytes kept before blocks go back to HIP (HODOR_POOL_CACHE_GIB)
     std::mutex pool_mu;
     // device -> host results handed out so far (roots, evaluations, query answers, prototypes, as_ref() copies): every one
     // of them stalls the queue, so a device-resident prover counts them (hodor_ctx_host_round_trips)

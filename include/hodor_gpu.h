@@ -54,8 +54,8 @@ typedef struct {
  * `modulus` must be an odd prime with 2^239 < p < 2^255 (4-limb ff_ce field, R = 2^256; the reference's
  * two 4-limb fields have 255 and 252 bits). */
 int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
-/* Destroy after every prototype obtained from this context has been freed (hodor_fri_free hands the
- * prototype's device slab back to its context), every hodor_exchange created on it has been destroyed (the call
+/* Destroy after every prototype and handle obtained from this context has been freed (they hand their device memory
+ * back to the context's pool), every hodor_exchange created on it has been destroyed (the call
  * is refused otherwise: the context stays alive) and no call on it is in flight. */
 void hodor_ctx_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
@@ -63,7 +63,8 @@ const char *hodor_last_error(const hodor_ctx *ctx);
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
 /* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
  * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_MIN_LOG_C, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TW_SUB, HODOR_NTT_W9, HODOR_NTT_P1,
- * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ, HODOR_TABLE_CACHE.
+ * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ, HODOR_TABLE_CACHE,
+ * HODOR_POOL_CACHE_GIB.
  * They are read once per process, change schedules only (never results), and a benchmark must echo
  * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
 const char *hodor_knobs_set(void);
@@ -201,7 +202,7 @@ size_t hodor_bytes_to_challenge_index(const uint8_t *bytes, size_t len, size_t l
  * All work is enqueued in stream order; nothing synchronises with the host unless stated.
  * Ordering rules of one context:
  *   - it owns ONE scratch pool (the ping-pong buffers of multi-pass transforms; batch_inversion,
- *     evaluate_at and fri_commit use it too), one twiddle-table cache and one parked FRI slab;
+ *     evaluate_at and fri_commit use it too), one twiddle-table cache and one device-memory pool (FRI prototypes, handles);
  *   - the slice API runs on streams the context creates itself (one non-blocking compute stream + three
  *     copy lanes, invisible to the caller) and is internally serialised on them;
  *   - `_dev` calls of one context on DIFFERENT streams are ordered on the scratch pool by the library (the
@@ -395,6 +396,10 @@ int  hodor_exchange_direct_begin_dev(hodor_exchange *x, void *stream, uint32_t s
 int  hodor_exchange_direct_signal_dev(hodor_exchange *x, void *stream, uint32_t slot);
 int  hodor_exchange_direct_wait_dev(hodor_exchange *x, void *stream, uint32_t slot);
 int  hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream, uint32_t slot);
+/* A flag wait that gave up (~10 s without its peers) lets the stream run on: the results of that generation are UNDEFINED.
+ * Call after synchronising the stream a generation ran on, before using its output: HODOR_ERR_DEVICE when any wait on
+ * this handle has timed out (the handle is dead from then on: every later call returns the same). */
+int  hodor_exchange_direct_status(hodor_exchange *x);
 /* Copy-engine variant on the same handle and flags: the CHUNKED schedule's local send piece (written by
  * hodor_sixstep_columns_dev / _rows_dev as for hodor_sixstep_exchange_dev) is copied into the peers' mapped receive buffers
  * by n_ranks device-to-device copies on the handle's own stream (SDMA between devices: no CU taken from the transforms,

@@ -260,7 +260,9 @@ int main(int argc, char **argv)
                log_rows, registers, lde_factor, combiner, proof.size(), reps, sync_phases ? "true" : "false", med.first,
                runs[0].first, (unsigned long long)trips, (double)(cached + live) / (1ull << 30));
         for (size_t i = 0; i < 9; i++) printf("%s\"%s\": %.3f", i ? ", " : "", PHASES[i], med.second[PHASES[i]]);
-        printf("}}\n");
+        printf("}, \"runs_ms\": [");
+        for (size_t i = 0; i < runs.size(); i++) printf("%s%.3f", i ? ", " : "", runs[i].first);
+        printf("]}\n");
     } catch (const SynthesisError &e) {
         fprintf(stderr, "SynthesisError(%d): %s\n", e.code, e.what());
         return 1;

@@ -153,6 +153,46 @@ def test_coset2_verifiers_refuse_tampered_and_truncated_proofs():
     ctx.close()
 
 
+def test_coset2_opening_binds_the_depth_and_canonical_values():
+    """A COSET2 leaf compresses like an interior node (64 bytes, t = 128), so only its depth tells the two apart: the
+    two child digests of an interior node, presented as a "coset value pair" with the path shortened by one level,
+    hash their way to the root — hodor_iop_verify_combined must refuse every path whose length is not log2(n) - 1
+    (round-4 advisor finding), and values that are not canonical residues."""
+    F = P.BN256
+    ctx = hodor_amd.Context(F.p, F.g, device=-1)
+    n = 64
+    vals = [F.to_mont(pow(3, i, F.p)) for i in range(n)]
+    nodes = P.iop_create_coset2(vals)                     # heap array of the tree over n/2 leaves
+    root = nodes[1]
+    honest = P.iop_path_coset2(nodes, vals, 5)
+    assert ctx.iop_verify_combined(root, [vals[5], vals[5 + n // 2]], honest, 5, n, C2) is True
+    # the forgery: the interior node at heap index 8 + j (level of width 8); its children nodes[16 + 2j], nodes[17 + 2j]
+    # are presented as the two "values" of a leaf
+    j = 3
+    left, right = nodes[2 * (8 + j)], nodes[2 * (8 + j) + 1]
+    as_values = [int.from_bytes(left, "little"), int.from_bytes(right, "little")]
+    short_path, idx = [], 8 + j
+    while idx > 1:
+        short_path.append(nodes[idx ^ 1])
+        idx >>= 1
+    assert len(short_path) == len(honest) - 2
+    # the walk itself reaches the root (the point of the finding) ...
+    h = P.hash_node(left, right)
+    k = j
+    for sib in short_path:
+        h = P.hash_node(h, sib) if k % 2 == 0 else P.hash_node(sib, h)
+        k >>= 1
+    assert h == root
+    # ... and the library refuses it: wrong depth (and, for most digests, non-canonical "values")
+    assert ctx.iop_verify_combined(root, as_values, short_path, j, n, C2) is False
+    assert ctx.iop_verify_combined(root, [vals[5], vals[5 + n // 2]], honest[:-1], 5, n, C2) is False
+    assert ctx.iop_verify_combined(root, [vals[5], vals[5 + n // 2]], honest + [bytes(32)], 5, n, C2) is False
+    # a non-canonical encoding of a committed value (v + p still fits 256 bits for this field) must not open
+    assert vals[5] + F.p < 1 << 256
+    assert ctx.iop_verify_combined(root, [vals[5] + F.p, vals[5 + n // 2]], honest, 5, n, C2) is False
+    ctx.close()
+
+
 def test_coset2_has_no_cpu_fallback_and_checks_sizes():
     F = P.BN256
     ctx = hodor_amd.Context(F.p, F.g, device=-1)

@@ -8,8 +8,13 @@
  * and re-raises with the default action, so the exit status and a core dump are what they would have been.
  * Python's faulthandler, installed later, chains to the previous handler — this one — on the same thread.
  *
- *   gcc -O1 -g -fPIC -shared bench/abrt_trace.c -o bench/libabrt_trace.so
- *   LD_PRELOAD=$PWD/bench/libabrt_trace.so python -m pytest ...
+ * And because a test runner's fd-level capture swallows what native code printed just before it died (pytest points
+ * descriptor 2 at an unlinked temporary file), the handler also copies the TAIL of whatever descriptor 2 is now to the
+ * original stderr: the runtime's own last words ("Memory access fault by GPU node ...", a queue error, a glibc heap
+ * check) survive the crash.
+ *
+ *   gcc -O1 -g -fPIC -shared tests/tools/abrt_trace.c -o tests/tools/libabrt_trace.so
+ *   loaded by tests/conftest.py (ctypes) before pytest enables faulthandler, or LD_PRELOAD=... for any other process
  */
 #define _GNU_SOURCE
 #include <execinfo.h>
@@ -45,6 +50,20 @@ static void handler(int sig, siginfo_t *si, void *uc)
             name[k] = 0;
             put("thread name: ");
             put(name);
+        }
+    }
+    /* the last words of this process on its CURRENT stderr, if that is a file we can read back (a capture file) */
+    {
+        off_t end = lseek(2, 0, SEEK_CUR);
+        if (end > 0 && out_fd != 2) {
+            static char tail[8192];
+            off_t from = end > (off_t)sizeof tail ? end - (off_t)sizeof tail : 0;
+            ssize_t k = pread(2, tail, (size_t)(end - from), from);
+            if (k > 0) {
+                put("---- tail of the captured stderr ----\n");
+                (void)!write(out_fd, tail, (size_t)k);
+                put("\n---- end of captured stderr ----\n");
+            }
         }
     }
     put("==== abrt_trace: end ====\n");
