@@ -58,7 +58,7 @@ WARM_MS = 150.0           # clocks settle after ~100 ms of load: warm up by time
 FIXTURES = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
 KNOB_VARS = ("HODOR_MAX_LOG_R", "HODOR_TILE_LOG", "HODOR_MIN_LOG_C", "HODOR_TW_HI_MAX_LOG", "HODOR_NTT_THREADS", "HODOR_NTT_TW_SUB", "HODOR_NTT_W9", "HODOR_NTT_P1",
              "HODOR_MERKLE_TAIL_LOG", "HODOR_MERKLE_LAT_LOG", "HODOR_FRI_TAIL", "HODOR_FRI_FUSE_FOLD",
-             "HODOR_BATCHINV_SEQ", "HODOR_TABLE_CACHE", "HODOR_POOL_CACHE_GIB", "HODOR_DBG", "HODOR_LIB")
+             "HODOR_BATCHINV_SEQ", "HODOR_TABLE_CACHE", "HODOR_POOL_CACHE_GIB", "HODOR_SLICE_SERIAL", "HODOR_DBG", "HODOR_LIB")
 
 
 def digest(t):
@@ -817,7 +817,8 @@ def main():
         torch.cuda.empty_cache()
         extra = {}
         try:
-            extra["lde_commit"] = extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_reduce_scalar, barrier)
+            extra["lde_commit"] = extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_reduce_scalar, barrier,
+                                                               be if args.mode == "sixstep" else None)
         except SystemExit:
             raise
         except Exception as exc:   # noqa: BLE001
@@ -911,7 +912,7 @@ def extra_lde_commit(ctx, torch, stream):
 XGMI_PEAK_GBS_PER_RANK = 7 * 153.0     # seven xGMI links per GPU, one to every peer of the node (MI355X_MICROARCH.md)
 
 
-def extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_reduce_scalar, barrier):
+def extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_reduce_scalar, barrier, transports=None):
     """config[2] across the node — the second half of BASELINE's metric at N > 1: LDE x8 of the 2^22-coefficient
     polynomial + IOP Merkle commit with the cosets dealt to the ranks (the reference's own LDE schedule,
     /root/reference/src/polynomials/mod.rs:446-460, interleave :466-479 = ONE all-to-all) and the tree built by
@@ -928,7 +929,12 @@ def extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_redu
     coeffs = torch.empty((n, 4), dtype=torch.int64, device="cuda")       # replicated: 1/8 of the output
     ctx.gen_elements_dev(coeffs, 0, n, fx["seed"], stream=stream)
     omega_big = ctx.domain(big)[2]
-    nb, tb = HipBackend(ctx, stream=stream), HipTreeBackend(ctx, stream=stream)
+    # with a library transport on the step's backend (--exchange native / direct / copy) the whole job is the library's own
+    # schedule: hodor_dist_lde_by_cosets_dev + hodor_dist_commit_dev (csrc/abi_dist.hip); torch.distributed otherwise
+    x_native = getattr(transports, "exchange", None)
+    x_direct = getattr(transports, "direct", None)
+    nb = HipBackend(ctx, stream=stream, exchange=x_native, direct=x_direct, direct_copy=getattr(transports, "direct_copy", False))
+    tb = HipTreeBackend(ctx, stream=stream, exchange=x_direct if x_direct is not None else x_native)
 
     def run():
         return lde_commit_by_cosets_distributed(nb, tb, coeffs, LDE_LOG_N, LDE_FACTOR, omega_big, rank, world)
@@ -985,6 +991,8 @@ def extra_lde_commit_distributed(ctx, torch, dist, stream, rank, world, all_redu
             "lde_commit_gib_per_s": alg_bytes / 2**30 / (ms * 1e-3),
             "hbm_frac_per_rank": alg_bytes / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "bytes_sent_per_rank": big * 32 / world * (world - 1) / world,
+            "schedule": "library (hodor_dist_lde_by_cosets_dev + hodor_dist_commit_dev)" if (x_native is not None or x_direct is not None)
+                        else "hodor_amd/distributed.py over torch.distributed",
             "root": bytes(root).hex(), "root_equals_cpu_oracle": True}
 
 

@@ -22,11 +22,12 @@ EXPERIMENTS_FR_MODULUS = 3618502788666131213697322783095070105623107215331596699
 EXPERIMENTS_FR_GENERATOR = 3
 
 OK, ERR_SIZE, ERR_INVALID, ERR_DEVICE = 0, 1, 2, 3
+ABI_VERSION = 5          # HODOR_ABI_VERSION of include/hodor_gpu.h this binding was written against
 TRIVIAL, COSET2 = 0, 1   # HODOR_COMBINER_*: the tree format (CosetCombiner, src/iop/mod.rs:22-34)
 
 # every symbol include/hodor_gpu.h declares
 EXPORTS = [
-    "hodor_ctx_create", "hodor_ctx_destroy", "hodor_ctx_field_info", "hodor_last_error",
+    "hodor_abi_version", "hodor_ctx_try_destroy", "hodor_ctx_create", "hodor_ctx_destroy", "hodor_ctx_field_info", "hodor_last_error",
     "hodor_ctx_synchronize", "hodor_knobs_set",
     "hodor_fr_mul", "hodor_fr_add", "hodor_fr_sub", "hodor_fr_pow", "hodor_fr_inverse",
     "hodor_fr_from_repr", "hodor_fr_into_repr", "hodor_domain_new_for_size",
@@ -60,6 +61,10 @@ EXPORTS = [
     "hodor_sixstep_rows_direct_dev",
     "hodor_exchange_available", "hodor_exchange_unique_id", "hodor_exchange_create", "hodor_exchange_adopt",
     "hodor_exchange_destroy", "hodor_sixstep_exchange_dev", "hodor_sixstep_exchange_wait_dev",
+    # round 5: the multi-GPU schedules inside the library (csrc/abi_dist.hip)
+    "hodor_dist_split", "hodor_dist_set_transport", "hodor_dist_ntt_forward_dev", "hodor_dist_ntt_inverse_dev",
+    "hodor_dist_ntt_begin_dev", "hodor_dist_ntt_end_dev", "hodor_dist_ntt_natural_dev", "hodor_dist_lde_by_cosets_dev",
+    "hodor_dist_commit_dev", "hodor_dist_lde_commit_dev", "hodor_exchange_direct_alloc_recv",
     # round 5: proof_from_lde_through_coefficients and the handle API (device-resident Polynomial / IOP)
     "hodor_ctx_host_round_trips", "hodor_ctx_pool_stats", "hodor_ctx_reset_host_round_trips", "hodor_ctx_stream",
     "hodor_ctx_trim", "hodor_fri_commit_h", "hodor_fri_commit_through_coefficients",
@@ -129,6 +134,9 @@ def lib():
         except ImportError:
             pass
         _lib = C.CDLL(_LIB)
+        if _lib.hodor_abi_version() != ABI_VERSION:
+            raise ImportError("libhodor_gpu.so speaks ABI revision %d, this binding %d: rebuild (hodor_amd.build())"
+                              % (_lib.hodor_abi_version(), ABI_VERSION))
         _lib.hodor_last_error.restype = C.c_char_p
         _lib.hodor_knobs_set.restype = C.c_char_p
         _lib.hodor_fri_num_steps.restype = C.c_size_t
@@ -303,7 +311,60 @@ class Transcript:
             pass
 
 
-class Exchange:
+RCCL, DIRECT, COPY = 0, 1, 2   # HODOR_TRANSPORT_*
+
+
+class _DistCalls:
+    """The multi-GPU schedules inside the library (csrc/abi_dist.hip) on an exchange handle: one call per distributed
+    transform / commit, over whichever transport the handle carries.  Tensors are (m, 4) int64 on the handle's device."""
+
+    def set_transport(self, transport=-1, force_collectives=False):
+        self.ctx._chk(self.ctx.L.hodor_dist_set_transport(self.h, C.c_int(transport), C.c_int(1 if force_collectives else 0)))
+
+    def dist_begin(self, src, log_n, omega, inverse=False, log_chunks=0, stream=None):
+        op = C.c_void_p()
+        w = _fr(omega)
+        self.ctx._chk(self.ctx.L.hodor_dist_ntt_begin_dev(self.h, C.c_void_p(stream), _dptr(src), C.c_size_t(src.shape[0]),
+                                                          C.c_uint32(log_n), C.byref(w), C.c_int(1 if inverse else 0),
+                                                          C.c_uint32(log_chunks), C.byref(op)))
+        return {"op": op, "src": src}     # src must outlive the exchange
+
+    def dist_end(self, h, dst):
+        self.ctx._chk(self.ctx.L.hodor_dist_ntt_end_dev(h["op"], _dptr(dst)))
+        h["op"], h["src"] = None, None
+        return dst
+
+    def dist_forward(self, a, b, log_n, omega, log_chunks=0, stream=None):
+        return self.dist_end(self.dist_begin(a, log_n, omega, False, log_chunks, stream), b)
+
+    def dist_inverse(self, b, a, log_n, omega, log_chunks=0, stream=None):
+        return self.dist_end(self.dist_begin(b, log_n, omega, True, log_chunks, stream), a)
+
+    def dist_natural(self, src, dst, log_n, omega, inverse=False, stream=None):
+        w = _fr(omega)
+        self.ctx._chk(self.ctx.L.hodor_dist_ntt_natural_dev(self.h, C.c_void_p(stream), _dptr(src), _dptr(dst),
+                                                            C.c_size_t(src.shape[0]), C.c_uint32(log_n), C.byref(w),
+                                                            C.c_int(1 if inverse else 0)))
+        return dst
+
+    def dist_lde_by_cosets(self, coeffs, log_n, factor, lde_block, coset=False, paired=False, stream=None):
+        self.ctx._chk(self.ctx.L.hodor_dist_lde_by_cosets_dev(self.h, C.c_void_p(stream), _dptr(coeffs), C.c_uint32(log_n),
+                                                              C.c_size_t(factor), C.c_int(1 if coset else 0),
+                                                              C.c_int(1 if paired else 0), _dptr(lde_block)))
+        return lde_block
+
+    def dist_commit(self, leafs_block, local_nodes, combiner=TRIVIAL, stream=None):
+        """-> (root bytes, dict global node index -> bytes for 1 <= i < 2 P)"""
+        P = self.n_ranks
+        top = np.zeros((2 * P, 32), dtype=np.uint8)
+        root = (C.c_uint8 * 32)()
+        self.ctx._chk(self.ctx.L.hodor_dist_commit_dev(self.h, C.c_void_p(stream), _dptr(leafs_block),
+                                                       C.c_size_t(leafs_block.shape[0]), C.c_int(combiner),
+                                                       _dptr(local_nodes), top.ctypes.data_as(C.c_void_p), root))
+        return bytes(root), {i: bytes(top[i]) for i in range(1, 2 * P)}
+
+
+class Exchange(_DistCalls):
     """hodor_exchange: the all-to-all of the 4-step transform on a communicator and a communication stream the
     library owns (csrc/abi_exchange.hip: grouped ncclSend/ncclRecv, RCCL bound at run time).  The unique id has to
     reach every rank by a channel of the caller's: `Exchange.over_process_group` uses torch.distributed for that one
@@ -369,7 +430,7 @@ class _RawDeviceArray:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
-class DirectExchange:
+class DirectExchange(_DistCalls):
     """The direct transport of the 4-step exchange (csrc/abi_exchange.hip): every rank maps every rank's receive
     buffers and the producing transform's last pass stores each slab straight into the buffer of the rank it is for —
     no communicator, no copy, no chunks.  One instance per rank; `n_slots` receive buffers of `n_local` elements
@@ -378,21 +439,20 @@ class DirectExchange:
       * x.connect_processes(group)                        one process per rank: hipIpc handles travel once over
                                                           torch.distributed (all_gather_object on `group`)"""
 
-    def __init__(self, ctx, n_ranks, rank, n_local, n_slots=4):
+    def __init__(self, ctx, n_ranks, rank, n_local, n_slots=4, coarse=False):
         import torch
         self.ctx, self.n_ranks, self.rank, self.n_local, self.n_slots = ctx, n_ranks, rank, n_local, n_slots
         self.h = C.c_void_p()
         ctx._chk(ctx.L.hodor_exchange_create_direct(ctx.h, C.c_uint32(n_ranks), C.c_uint32(rank), C.c_uint32(n_slots),
                                                     C.byref(self.h)))
         ctx._exchanges.add(self)
-        # the receive buffers are hipMalloc allocations of their own (not pieces of torch's caching allocator): an IPC
-        # handle names a whole allocation, and the peers must find the buffer at its start
-        self._raw, self.recv = [], []
-        for _ in range(n_slots):
-            p = C.c_void_p()
-            ctx._chk(ctx.L.hodor_buf_alloc(ctx.h, C.c_size_t(n_local * 32), C.byref(p)))
-            self._raw.append(p.value)
-            self.recv.append(torch.as_tensor(_RawDeviceArray(p.value, (n_local, 4)), device="cuda"))
+        # the receive buffers are allocations of the library's own (hodor_exchange_direct_alloc_recv: FINE-GRAINED device
+        # memory unless `coarse`, freed with the handle): an IPC handle names a whole allocation, the peers must find the
+        # buffer at its start, and the memory model of the transport is argued for uncached receive buffers (DESIGN §6)
+        ptrs = (C.c_void_p * n_slots)()
+        ctx._chk(ctx.L.hodor_exchange_direct_alloc_recv(self.h, C.c_size_t(n_local), C.c_int(1 if coarse else 0), ptrs))
+        self._raw = [ptrs[i] for i in range(n_slots)]
+        self.recv = [torch.as_tensor(_RawDeviceArray(p, (n_local, 4)), device="cuda") for p in self._raw]
         fp, fb = C.c_void_p(), C.c_size_t()
         ctx._chk(ctx.L.hodor_exchange_direct_flags(self.h, C.byref(fp), C.byref(fb)))
         self.flags_ptr, self.flags_bytes = fp.value, fb.value
@@ -480,9 +540,7 @@ class DirectExchange:
                 self.ctx.L.hodor_ipc_close(self.ctx.h, C.c_void_p(p))
             self._imported = []
             self.recv = []
-            for p in self._raw:
-                self.ctx.L.hodor_buf_free(self.ctx.h, C.c_void_p(p))
-            self._raw = []
+            self._raw, self.recv = [], []      # (the receive buffers went with the handle)
 
     def __del__(self):
         try:
@@ -545,7 +603,11 @@ class Context:
                 proto.free()
             for x in list(self._exchanges):
                 x.close()
-            self.L.hodor_ctx_destroy(self.h)
+            rc = self.L.hodor_ctx_try_destroy(self.h)
+            if rc != OK:       # refused: something of this context is still alive — say so instead of leaking silently
+                msg = self.L.hodor_last_error(self.h).decode()
+                self.h = None
+                raise HodorError(rc, "hodor_ctx_try_destroy: " + msg)
             self.h = None
 
     def __del__(self):

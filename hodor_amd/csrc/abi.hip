@@ -502,15 +502,25 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
     return HODOR_OK;
 }
 
-extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
+extern "C" int hodor_abi_version(void) { return HODOR_ABI_VERSION; }
+
+extern "C" void hodor_ctx_destroy(hodor_ctx *ctx) { (void)hodor_ctx_try_destroy(ctx); }
+
+extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
 {
-    if (!ctx) return;
+    if (!ctx) return HODOR_OK;
     if (ctx->live_exchanges.load() != 0) {
         // a hodor_exchange keeps a pointer to its context (error reporting, device): destroying the context under it
         // would leave that pointer dangling.  Refuse — the handle stays valid, the caller destroys the exchanges
         // first (header: "Destroy the handle before its context") and calls again.
         set_err(ctx, "hodor_ctx_destroy: exchanges created on this context are still alive; destroy them first");
-        return;
+        return HODOR_ERR_INVALID;
+    }
+    if (ctx->live_handles.load() != 0) {
+        // polynomial / IOP handles and FRI prototypes give their device memory back to THIS context's pool when freed
+        set_err(ctx, "hodor_ctx_destroy: " + std::to_string(ctx->live_handles.load()) +
+                         " polynomial / IOP handles or FRI prototypes of this context are still alive; free them first");
+        return HODOR_ERR_INVALID;
     }
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
@@ -531,6 +541,7 @@ extern "C" void hodor_ctx_destroy(hodor_ctx *ctx)
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
+    return HODOR_OK;
 }
 
 extern "C" int hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out)
@@ -1023,9 +1034,15 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         if ((e = lane_prepare(L, 1, (n_out ? n_out : 1) * 32)) != hipSuccess) return fail(e, "slice staging (out)");
         dptr_out = L->buf[1];
     }
-    if ((e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, L->stream)) != hipSuccess ||
-        (e = hipEventRecord(L->uploaded, L->stream)) != hipSuccess)
-        return fail(e, "slice upload");
+    const bool serial = knobs().slice_serial != 0;
+    {
+        std::unique_lock<std::mutex> up(ctx->up_mu, std::defer_lock);
+        if (serial) up.lock();
+        if ((e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, L->stream)) != hipSuccess ||
+            (e = hipEventRecord(L->uploaded, L->stream)) != hipSuccess ||
+            (serial && (e = hipStreamSynchronize(L->stream)) != hipSuccess))   // the link is free for the next upload
+            return fail(e, "slice upload");
+    }
     int rc;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1036,10 +1053,17 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
     }
     if (rc) { (void)hipStreamSynchronize(L->stream); lane_release(ctx, L); return rc; }
     if (e != hipSuccess) return fail(e, "slice compute");
-    if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess ||
-        (e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
-        (e = hipStreamSynchronize(L->stream)) != hipSuccess)
-        return fail(e, "slice download");
+    {
+        std::unique_lock<std::mutex> down(ctx->down_mu, std::defer_lock);
+        if (serial) {
+            if ((e = hipEventSynchronize(L->computed)) != hipSuccess) return fail(e, "slice compute");   // wait OUTSIDE the lock
+            down.lock();
+        }
+        if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess ||
+            (e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(L->stream)) != hipSuccess)
+            return fail(e, "slice download");
+    }
     lane_release(ctx, L);
     return HODOR_OK;
 }

@@ -20,9 +20,8 @@
 //                                                  call reads the receive buffer.
 // The caller keeps send and receive buffers alive and untouched from the exchange call to the wait.
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: every function is resolved with dlsym
 
-#include "ctx.hpp"
+#include "exchange.hpp"
 
 namespace {
 
@@ -83,33 +82,6 @@ const Rccl &rccl()
 }
 
 }  // namespace
-
-struct hodor_exchange {
-    hodor_ctx *ctx = nullptr;
-    int device = -1;                // copied at creation: destroy must not depend on the context still being alive
-    ncclComm_t comm = nullptr;
-    bool owns_comm = false;
-    uint32_t n_ranks = 1, rank = 0;
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t ready = nullptr;     // recorded on the caller's stream: the chunk has been produced
-    static constexpr uint64_t RING = 64;
-    hipEvent_t done[RING] = {};     // done[t % RING]: recorded on comm_stream after exchange number t (tickets start at 1)
-    uint64_t issued = 0;            // number of exchanges enqueued so far = the latest ticket
-    bool counted = false;           // registered in ctx->live_exchanges (hodor_ctx_destroy refuses while any is alive)
-    std::mutex mu;
-    // ---- direct transport (no communicator, no copy: the producing pass stores into the peers' receive buffers)
-    struct Slot {
-        uint64_t *d_tab = nullptr;          // device array of n_ranks receive-buffer addresses (as mapped HERE)
-        uint64_t h_tab[HODOR_EXCHANGE_MAX_RANKS] = {};   // the same addresses on the host (copy-engine transport)
-        bool set = false;
-        uint32_t produced = 0, consumed = 0;   // generations this rank has started producing into / consuming from the slot
-    };
-    uint32_t n_slots = 0;
-    Slot *slots = nullptr;
-    uint32_t *my_flags = nullptr;           // this rank's flag block: per slot { arrived[n_ranks], released[n_ranks] }
-    uint32_t *peer_flags[HODOR_EXCHANGE_MAX_RANKS] = {};   // every rank's flag block as mapped HERE (own one included)
-    uint32_t *d_err = nullptr;              // pinned host word (device-visible): set by a flag wait that timed out
-};
 
 static_assert(HODOR_EXCHANGE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the unique id travels as opaque bytes");
 
@@ -234,6 +206,13 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
     }
     if (x->my_flags) (void)hipFree(x->my_flags);
     if (x->d_err) (void)hipHostFree(x->d_err);
+    (void)hipDeviceSynchronize();           // the work buffers and the library's own receive buffers may still be read
+    for (int i = 0; i < hodor_exchange::WORK; i++) {
+        if (x->work[i]) (void)hipFree(x->work[i]);
+        if (x->work_free[i]) (void)hipEventDestroy(x->work_free[i]);
+    }
+    for (auto &r : x->own_recv)
+        if (r) (void)hipFree(r);
     if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
     if (x->owns_comm && x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);
@@ -427,6 +406,36 @@ extern "C" int hodor_exchange_create_direct(hodor_ctx *ctx, uint32_t n_ranks, ui
     ctx->live_exchanges.fetch_add(1);
     x->counted = true;
     *out = x;
+    return HODOR_OK;
+}
+
+// The receive buffers of the direct transports as allocations of the library's own, one per slot, n_local elements
+// each.  `coarse` = 0 (the default of every caller in this repository): FINE-GRAINED device memory, like the flags —
+// never cached in this device's L2s and written through by the peers, so that neither a stale line of the previous
+// generation on the consumer's side nor a dirty line on the producer's can exist ("memory model of the
+// direct transport"); `coarse` = 1: plain hipMalloc, for the A/B on a node that shows the fine-grained form to cost
+// anything.  Export each pointer with hodor_ipc_export and pass every rank's to hodor_exchange_direct_set_peers.
+extern "C" int hodor_exchange_direct_alloc_recv(hodor_exchange *x, size_t n_local, int coarse, void **recv /* n_slots */)
+{
+    if (!x || !x->ctx || !x->slots || !recv) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = x->ctx;
+    NEED_DEVICE();
+    if (n_local == 0 || x->n_slots > 16) return HODOR_ERR_SIZE;
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->own_recv[0]) { set_err(ctx, "exchange (direct): the receive buffers exist already"); return HODOR_ERR_INVALID; }
+    for (uint32_t i = 0; i < x->n_slots; i++) {
+        hipError_t e = coarse ? hipMalloc(&x->own_recv[i], n_local * 32)
+                              : hipExtMallocWithFlags(&x->own_recv[i], n_local * 32, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (uint32_t k = 0; k < i; k++) { (void)hipFree(x->own_recv[k]); x->own_recv[k] = nullptr; }
+            x->own_recv[i] = nullptr;
+            set_err(ctx, std::string("exchange (direct): receive buffers: ") + hipGetErrorString(e));
+            return HODOR_ERR_DEVICE;
+        }
+        recv[i] = x->own_recv[i];
+    }
+    x->own_recv_bytes = n_local * 32;
     return HODOR_OK;
 }
 

@@ -13,6 +13,7 @@ extern "C" void hodor_fri_free(hodor_fri_proto *p)
     if (!p) return;
     hodor_ctx *ctx = p->ctx;
     if (ctx && p->slab) pool_release(ctx, p->slab, p->slab_bytes);
+    if (ctx) ctx->live_handles.fetch_sub(1);
     delete p;
 }
 
@@ -169,6 +170,7 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
     memcpy(p->final_coeffs.data(), small.data() + 64 * (num_steps + 1), 32 * out_deg);
     memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
 #undef FRICHK
+    ctx->live_handles.fetch_add(1);
     *out = p;
     return HODOR_OK;
 }
@@ -290,6 +292,7 @@ extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *s
     memcpy(p->challenges.data(), small.data(), 32 * num_steps);
     memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);                                             // roots.pop() :226
 #undef FRICHK
+    ctx->live_handles.fetch_add(1);
     *out = p;
     return HODOR_OK;
 }

@@ -307,6 +307,7 @@ static Knobs read_knobs()
     k.fri_fuse_fold = get("HODOR_FRI_FUSE_FOLD", 1, 0, 2);
     k.batchinv_seq = get("HODOR_BATCHINV_SEQ", 8, 2, 64);
     k.table_cache = get("HODOR_TABLE_CACHE", 40, 1, 1000);
+    k.slice_serial = get("HODOR_SLICE_SERIAL", 1, 0, 1);
     k.pool_cache_gib = get("HODOR_POOL_CACHE_GIB", 64, 0, 4096);
     return k;
 }

@@ -188,6 +188,7 @@ static int poly_make(hodor_ctx *ctx, int form, size_t padded, hodor_poly **out)
     int rc = poly_set_domain(ctx, p);
     if (!rc) p->slab = slab_new(ctx, padded * 32, &rc);
     if (rc) { delete p; return rc; }
+    ctx->live_handles.fetch_add(1);
     *out = p;
     return HODOR_OK;
 }
@@ -356,6 +357,7 @@ extern "C" void hodor_poly_free_h(hodor_poly *p)
 {
     if (!p) return;
     slab_unref(p->slab);   // back to the pool: whatever is still enqueued on it runs before the next user (stream order)
+    p->ctx->live_handles.fetch_sub(1);
     delete p;
 }
 
@@ -683,6 +685,7 @@ extern "C" int hodor_poly_lde_batch_h(const hodor_poly *const *ps, size_t count,
         q->slab = dst;
         q->off = i * big * 32;
         dst->refs.fetch_add(1);
+        ctx->live_handles.fetch_add(1);
         outs[i] = q;
     }
     slab_unref(dst);   // the views hold it now
@@ -837,6 +840,7 @@ extern "C" int hodor_iop_create_batch_h(const hodor_poly *const *vs, size_t coun
         t->off = i * entries * 32;
         t->entries = entries;
         nodes->refs.fetch_add(1);
+        ctx->live_handles.fetch_add(1);
         outs[i] = t;
     }
     slab_unref(nodes);
@@ -852,6 +856,7 @@ extern "C" void hodor_iop_free_h(hodor_iop *t)
 {
     if (!t) return;
     slab_unref(t->slab);
+    t->ctx->live_handles.fetch_sub(1);
     delete t;
 }
 extern "C" size_t hodor_iop_size_h(const hodor_iop *t) { return t ? t->n : 0; }
@@ -949,6 +954,7 @@ extern "C" int hodor_fri_commitment_h(hodor_fri_proto *p, int step, hodor_iop **
     t->raw = (uint8_t *)(step < 0 ? p->l0_nodes : p->inter_nodes[step]);
     memcpy(t->root, p->roots.data() + 32 * (size_t)(step + 1), 32);
     t->root_valid = true;
+    t->ctx->live_handles.fetch_add(1);
     *out = t;
     return HODOR_OK;
 }

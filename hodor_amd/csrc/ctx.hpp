@@ -164,11 +164,17 @@ struct hodor_ctx {
         size_t bytes[2] = {0, 0};
         bool busy = false;
     };
-    static constexpr int IO_LANES = 3;
+    static constexpr int IO_LANES = 4;
     IoLane lanes[IO_LANES];
     std::mutex lane_mu;
     std::condition_variable lane_cv;
+    // one upload and one download at a time (round 5): copies in the SAME direction share the link and — from pageable
+    // memory — the runtime's page pinning, so two of them side by side finish later than one after the other; copies in
+    // OPPOSITE directions overlap.  With these two mutexes N concurrent callers form a clean three-stage pipeline
+    // (upload | kernels | download) whose throughput is the slower direction's.
+    std::mutex up_mu, down_mu;
     std::atomic<int> live_exchanges{0};   // hodor_exchange handles that point at this context (abi_exchange.hip)
+    std::atomic<int> live_handles{0};     // hodor_poly / hodor_iop / hodor_fri_proto objects whose memory is this context's pool
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
     uint32_t tile_log = 10;    // elements per workgroup tile = 2^tile_log         } (bench/size_sweep.sh)
     uint32_t min_log_c = 2;    // fewest tile columns per pass (2^2 x 32 B = 128-byte runs)

@@ -20,6 +20,7 @@ struct Knobs {
     int fri_fuse_fold;    // HODOR_FRI_FUSE_FOLD   fold inside the tree's leaf launch: 0 never, 1 always, 2 small rounds only   1
     int batchinv_seq;     // HODOR_BATCHINV_SEQ    elements per lane and level in batch inversion        8
     int table_cache;      // HODOR_TABLE_CACHE     power tables kept per context before the cache is emptied    40
+    int slice_serial;     // HODOR_SLICE_SERIAL    slice API: one upload and one download at a time (0: every lane copies at will)   1
     int pool_cache_gib;   // HODOR_POOL_CACHE_GIB  idle device-pool bytes a context keeps before it frees the largest  64
     char set[256];        // "NAME=value ..." of the variables that were present in the environment
 };

@@ -29,14 +29,16 @@ one all-gather of P roots (`merkle_commit_distributed(..., combiner=COSET2)`).
 import torch
 import torch.distributed as dist
 
-from .sixstep import _all_to_all, sixstep_ntt
+from .sixstep import _all_to_all, _library_transport, sixstep_ntt
 
 
 class HipTreeBackend:
-    """Local subtree on the MI355X through the C ABI."""
+    """Local subtree on the MI355X through the C ABI.  `exchange`: a hodor_amd.Exchange / DirectExchange — the whole
+    commit (subtree, the 32-byte exchange of the subtree roots, the replicated top levels) is then ONE library call
+    (hodor_dist_commit_dev, csrc/abi_dist.hip) instead of this module's schedule over torch.distributed."""
 
-    def __init__(self, ctx, stream=None):
-        self.ctx, self.stream = ctx, stream
+    def __init__(self, ctx, stream=None, exchange=None):
+        self.ctx, self.stream, self.exchange = ctx, stream, exchange
 
     def tree(self, leafs, combiner=0):
         n = leafs.shape[0]
@@ -57,6 +59,12 @@ def merkle_commit_distributed(backend, leafs_local, rank, world, group=None, com
     combiner 1 (COSET2): `leafs_local` is this rank's PAIRED block (module docstring; B >= 4 values), local_nodes has
     B/2 rows and `global_node_index` applies with the halved level widths."""
     assert world & (world - 1) == 0, "power-of-two world size"
+    x = getattr(backend, "exchange", None)
+    if x is not None and hasattr(x, "dist_commit"):
+        n = leafs_local.shape[0]
+        local_nodes = torch.empty((n // 2 if combiner == 1 else n, 32), dtype=torch.uint8, device=leafs_local.device)
+        root, top = x.dist_commit(leafs_local, local_nodes, combiner, stream=backend.stream)
+        return root, local_nodes, top
     if combiner:
         assert leafs_local.shape[0] >= 4, "a COSET2 subtree needs at least two leaves"
         local_nodes = backend.tree(leafs_local, combiner)
@@ -115,6 +123,10 @@ def lde_by_cosets_distributed(backend, coeffs, log_n, factor, omega_big, rank, w
         interleave   hodor_transpose_dev([f][n/P] -> [n/P][f])             out[(k - k0)*f + i]  (:466-479)"""
     n, f, P = 1 << log_n, factor, world
     assert f % P == 0 and n % P == 0, "world size must divide the LDE factor and the polynomial size"
+    x = _library_transport(backend)
+    if x is not None and (coset_shift is None or coset_shift == backend.ctx.generator):
+        out = torch.empty((n * f // P, coeffs.shape[-1]), dtype=coeffs.dtype, device=coeffs.device)
+        return x.dist_lde_by_cosets(coeffs, log_n, f, out, coset=coset_shift is not None, paired=paired, stream=backend.stream)
     fp, kb = f // P, n // P
     log_fp, log_p = fp.bit_length() - 1, P.bit_length() - 1
     omega = backend.pow(omega_big, f)                    # generator of the size-n domain

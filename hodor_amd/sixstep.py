@@ -22,6 +22,13 @@ Per-rank layouts (row-major, x[n1*N2 + n2], r1 = N1/P, c2 = N2/P, rank q):
 
 The local steps go through a small backend interface so the same schedule runs on the HIP kernels
 (HipBackend) and, in the CPU tests, on the oracle.
+
+Round 5: with a library transport on the backend (`exchange` = hodor_amd.Exchange, RCCL behind the C ABI; `direct` =
+hodor_amd.DirectExchange, the direct stores or the copy engine) the schedule below is NOT used: sixstep_forward /
+_inverse (and their begin / end halves) are then one call each of the library's own schedule
+(csrc/abi_dist.hip: hodor_dist_ntt_begin_dev / _end_dev), which is what a Rust process per GPU binds.  The Python
+schedule remains for torch.distributed communicators — "nccl" process groups, and the "gloo" groups of the CPU tests
+and of ranks that share one GPU — and as the readable twin of the C++ one.
 """
 import torch
 import torch.distributed as dist
@@ -154,7 +161,7 @@ def _log_p(world):
     return log_p
 
 
-def _exchange_begin(produce, m, world, group, log_chunks, native=None, stream=None):
+def _exchange_begin(produce, m, world, group, log_chunks):
     """Runs produce(k, send_chunk_k) for k = 0 .. K-1 and puts each chunk on the wire as soon as it has been
     enqueued: the all-to-all of chunk k (asynchronous, on the communicator's own stream, ordered after the
     kernels that wrote the chunk) overlaps the arithmetic of chunk k+1 — and whatever the caller enqueues next.
@@ -170,25 +177,9 @@ def _exchange_begin(produce, m, world, group, log_chunks, native=None, stream=No
     step = m // K
     for k in range(K):
         produce(k, send[k * step:(k + 1) * step])
-        if collective and native is not None:
-            ticket = native.exchange(send, recv, log_chunks, k, stream=stream)
-        elif collective:
+        if collective:
             works.append(_all_to_all(recv[k * step:(k + 1) * step], send[k * step:(k + 1) * step], group, async_op=True))
-    if collective and native is not None:
-        # the communication stream reads `send` after this function has returned: the handle keeps it alive until
-        # the compute stream has been made to wait for the exchange (the allocator reuses memory in stream order)
-        works.append(_NativeWait(native, stream, send, ticket))
     return recv, works
-
-
-class _NativeWait:
-    def __init__(self, native, stream, keep, ticket):
-        self.native, self.stream, self.keep, self.ticket = native, stream, keep, ticket
-
-    def wait(self):
-        self.native.wait(stream=self.stream, ticket=self.ticket)    # this transform's last chunk, not another's
-        self.keep = None
-        return True
 
 
 def _exchange_end(works):
@@ -196,51 +187,17 @@ def _exchange_end(works):
         w.wait()                                     # the current stream waits for the exchange
 
 
-class _DirectWait:
-    def __init__(self, direct, slot, stream):
-        self.direct, self.slot, self.stream = direct, slot, stream
-
-    def wait(self):
-        self.direct.wait(self.slot, stream=self.stream)
-        return True
-
-
-def _direct_begin(backend, produce_direct, log_chunks):
-    """The direct transport's counterpart of _exchange_begin: claim a slot, wait until every peer has released it, run
-    the producing transform (its last pass writes into the peers' buffers), signal.  Returns the handle pieces."""
-    d, st = backend.direct, backend.stream
-    slot = d.next_slot()
-    d.begin(slot, stream=st)
-    for k in range(1 << log_chunks):
-        produce_direct(slot, k)
-    d.signal(slot, stream=st)
-    return d.recv[slot], [_DirectWait(d, slot, st)], (lambda: d.release(slot, stream=st))
-
-
-class _CopyWait:
-    def __init__(self, direct, slot, stream, keep):
-        self.direct, self.slot, self.stream, self.keep = direct, slot, stream, keep
-
-    def wait(self):
-        self.direct.wait(self.slot, stream=self.stream)      # every rank's copies — this rank's own included — have landed
-        self.keep = None
-        return True
-
-
-def _copy_begin(backend, produce, m, log_chunks):
-    """The copy-engine transport's counterpart of _exchange_begin: produce(k, send piece k) into a local send buffer, each
-    piece handed to the handle's copy stream as soon as it has been enqueued."""
-    d, st = backend.direct, backend.stream
-    K = 1 << log_chunks
-    assert m % (K * d.n_ranks) == 0, "too many chunks for this transform"
-    like = produce(None, None)
-    send = torch.empty((m, 4), dtype=like.dtype, device=like.device)
-    slot = d.next_slot()
-    step = m // K
-    for k in range(K):
-        produce(k, send[k * step:(k + 1) * step])
-        d.copy(slot, send, log_chunks, k, stream=st)
-    return d.recv[slot], [_CopyWait(d, slot, st, send)], (lambda: d.release(slot, stream=st))
+def _library_transport(backend):
+    """The exchange handle whose schedule lives in the library, or None (torch.distributed does the exchange)."""
+    d = getattr(backend, "direct", None)
+    if d is not None:
+        d.set_transport(2 if getattr(backend, "direct_copy", False) else 1, FORCE_COLLECTIVES)
+        return d
+    x = getattr(backend, "exchange", None)
+    if x is not None and hasattr(x, "dist_begin"):
+        x.set_transport(0, FORCE_COLLECTIVES)
+        return x
+    return None
 
 
 def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
@@ -249,33 +206,25 @@ def sixstep_forward_begin(backend, a, log_n, omega, rank, world, group=None, log
     sixstep_forward_end, which waits for the exchange and runs the row transforms."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
-    if getattr(backend, "direct", None) is not None and not getattr(backend, "direct_copy", False):
-        d = backend.direct
-        recv, works, release = _direct_begin(
-            backend, lambda slot, k: d.columns(a, slot, log_n1, log_n2, omega, log_chunks, k, stream=backend.stream), log_chunks)
-        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
+    x = _library_transport(backend)
+    if x is not None:      # the library's own schedule: producer + exchange enqueued, `a` kept alive by the handle
+        return {"lib": x, "op": x.dist_begin(a, log_n, omega, False, log_chunks, stream=backend.stream), "like": a}
 
     def produce(k, out):
         if k is None:
             return a
         backend.columns(a, log_n1, log_n2, log_p, rank, omega, False, log_chunks, k, out=out)
 
-    if getattr(backend, "direct", None) is not None:
-        recv, works, release = _copy_begin(backend, produce, a.shape[0], log_chunks)
-        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
-
-    recv, works = _exchange_begin(produce, a.shape[0], world, group, log_chunks, getattr(backend, "exchange", None),
-                                  getattr(backend, "stream", None))
+    recv, works = _exchange_begin(produce, a.shape[0], world, group, log_chunks)
     return {"recv": recv, "works": works, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
 
 def sixstep_forward_end(backend, h):
+    if "lib" in h:
+        return h["lib"].dist_end(h["op"], torch.empty_like(h["like"]))
     log_n1, log_n2, log_p, rank, omega, log_chunks = h["args"]
     _exchange_end(h["works"])
-    out = backend.rows(h["recv"], log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
-    if "release" in h:
-        h["release"]()                               # direct transport: the peers may overwrite the slot again
-    return out
+    return backend.rows(h["recv"], log_n1, log_n2, log_p, rank, omega, False, log_chunks, 0)
 
 
 def sixstep_forward(backend, a, log_n, omega, rank, world, group=None, log_chunks=0):
@@ -288,33 +237,25 @@ def sixstep_inverse_begin(backend, b, log_n, omega, rank, world, group=None, log
     """First half of sixstep_inverse: the inverse row transforms chunk by chunk with their all-to-alls."""
     log_n1, log_n2 = split_logs(log_n)
     log_p = _log_p(world)
-    if getattr(backend, "direct", None) is not None and not getattr(backend, "direct_copy", False):
-        d = backend.direct
-        recv, works, release = _direct_begin(
-            backend, lambda slot, k: d.rows(b, slot, log_n1, log_n2, omega, log_chunks, k, stream=backend.stream), log_chunks)
-        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
+    x = _library_transport(backend)
+    if x is not None:
+        return {"lib": x, "op": x.dist_begin(b, log_n, omega, True, log_chunks, stream=backend.stream), "like": b}
 
     def produce(k, out):
         if k is None:
             return b
         backend.rows(b, log_n1, log_n2, log_p, rank, omega, True, log_chunks, k, out=out)
 
-    if getattr(backend, "direct", None) is not None:
-        recv, works, release = _copy_begin(backend, produce, b.shape[0], log_chunks)
-        return {"recv": recv, "works": works, "release": release, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
-
-    recv, works = _exchange_begin(produce, b.shape[0], world, group, log_chunks, getattr(backend, "exchange", None),
-                                  getattr(backend, "stream", None))
+    recv, works = _exchange_begin(produce, b.shape[0], world, group, log_chunks)
     return {"recv": recv, "works": works, "args": (log_n1, log_n2, log_p, rank, omega, log_chunks)}
 
 
 def sixstep_inverse_end(backend, h):
+    if "lib" in h:
+        return h["lib"].dist_end(h["op"], torch.empty_like(h["like"]))
     log_n1, log_n2, log_p, rank, omega, log_chunks = h["args"]
     _exchange_end(h["works"])
-    out = backend.columns(h["recv"], log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
-    if "release" in h:
-        h["release"]()
-    return out
+    return backend.columns(h["recv"], log_n1, log_n2, log_p, rank, omega, True, log_chunks, 0)
 
 
 def sixstep_inverse(backend, b, log_n, omega, rank, world, group=None, log_chunks=0):
@@ -340,6 +281,9 @@ def b_to_natural(backend, b, log_n, rank, world, group=None):
 def sixstep_ntt(backend, x_local, log_n, omega, rank, world, group=None, scale=None):
     """Distributed natural->natural NTT (3 exchanges).  `x_local`: this rank's natural block, shape
     (n/world, 4).  `scale`: optional Montgomery scalar multiplied into every output."""
+    x = _library_transport(backend)
+    if x is not None and scale is None:
+        return x.dist_natural(x_local, torch.empty_like(x_local), log_n, omega, False, stream=backend.stream)
     a = natural_to_a(backend, x_local, log_n, rank, world, group)
     b = sixstep_forward(backend, a, log_n, omega, rank, world, group)
     if scale is not None:
@@ -350,6 +294,9 @@ def sixstep_ntt(backend, x_local, log_n, omega, rank, world, group=None, scale=N
 def sixstep_intt(backend, x_local, log_n, omega, rank, world, group=None):
     """Inverse natural->natural transform: omega^-1 and the n^-1 scale (Polynomial::ifft,
     src/polynomials/mod.rs:773-798)."""
+    x = _library_transport(backend)
+    if x is not None:
+        return x.dist_natural(x_local, torch.empty_like(x_local), log_n, omega, True, stream=backend.stream)
     winv = backend.inverse(omega)
     ninv = backend.inverse(backend.from_u64(1 << log_n))
     return sixstep_ntt(backend, x_local, log_n, winv, rank, world, group, scale=ninv)

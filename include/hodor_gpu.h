@@ -53,18 +53,30 @@ typedef struct {
  * src/experiments/mod.rs:18-21) + device state (streams, twiddle cache, scratch).
  * `modulus` must be an odd prime with 2^239 < p < 2^255 (4-limb ff_ce field, R = 2^256; the reference's
  * two 4-limb fields have 255 and 252 bits). */
+/* ABI revision of this header: bumped whenever an existing entry point changes its C signature or meaning (adding entry
+ * points does not bump it).  A caller built against another revision must not call into the library: check once.
+ *   4  hodor_fri_verify_proof_strict(_combined) take expected_lde_factor and expected_output_coeffs_at_degree_plus_one
+ *      BEFORE natural_element_index (round 4; the round-3 form had five value arguments)
+ *   5  hodor_iop_verify_combined (COSET2) refuses paths of any length but log2(n) - 1 and non-canonical values;
+ *      receive buffers of the direct transports are the library's (hodor_exchange_direct_alloc_recv) */
+#define HODOR_ABI_VERSION 5
+int  hodor_abi_version(void);
 int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
 /* Destroy after every prototype and handle obtained from this context has been freed (they hand their device memory
  * back to the context's pool), every hodor_exchange created on it has been destroyed (the call
  * is refused otherwise: the context stays alive) and no call on it is in flight. */
 void hodor_ctx_destroy(hodor_ctx *ctx);
+/* The same with a verdict: HODOR_OK = destroyed; HODOR_ERR_INVALID = REFUSED, the context is still alive (exchanges,
+ * handles or prototypes of it exist — hodor_last_error says which): free them and call again.  hodor_ctx_destroy is this
+ * call with the verdict dropped. */
+int  hodor_ctx_try_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
 const char *hodor_last_error(const hodor_ctx *ctx);
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
 /* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
  * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_MIN_LOG_C, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TW_SUB, HODOR_NTT_W9, HODOR_NTT_P1,
  * HODOR_MERKLE_TAIL_LOG, HODOR_MERKLE_LAT_LOG, HODOR_FRI_TAIL, HODOR_FRI_FUSE_FOLD, HODOR_BATCHINV_SEQ, HODOR_TABLE_CACHE,
- * HODOR_POOL_CACHE_GIB.
+ * HODOR_POOL_CACHE_GIB, HODOR_SLICE_SERIAL.
  * They are read once per process, change schedules only (never results), and a benchmark must echo
  * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
 const char *hodor_knobs_set(void);
@@ -414,6 +426,56 @@ int  hodor_sixstep_columns_direct_dev(hodor_ctx *ctx, void *stream, const hodor_
 int  hodor_sixstep_rows_direct_dev(hodor_ctx *ctx, void *stream, const hodor_fr *src, hodor_exchange *x, uint32_t slot,
                                    uint32_t log_n1, uint32_t log_n2, const hodor_fr *omega, uint32_t log_chunks,
                                    uint32_t chunk);
+/* The receive buffers of the direct transports as allocations of the library's own (one per slot, n_local elements):
+ * coarse = 0 -> FINE-GRAINED device memory (never held in this device's L2s, written through by the peers: the form
+ * the memory model of DESIGN.md §6 is argued for), coarse = 1 -> plain hipMalloc (an A/B aid).  Export each with
+ * hodor_ipc_export and hand every rank's pointers to hodor_exchange_direct_set_peers. */
+int  hodor_exchange_direct_alloc_recv(hodor_exchange *x, size_t n_local, int coarse, void **recv /* n_slots */);
+
+/* ---- the multi-GPU SCHEDULES inside the library (csrc/abi_dist.hip): one call per distributed transform / commit, over
+ * whichever transport the handle carries.  HODOR_TRANSPORT_RCCL — RCCL's all-to-all on the library's communication
+ * stream, chunked and overlapped — is THE DEFAULT of a handle with a communicator (hodor_exchange_create / _adopt) and
+ * what north_star names; the two transports that map peer memory (hodor_exchange_create_direct; DIRECT is that handle's
+ * default) are opt-in until a multi-GPU node has ranked the three.
+ *   hodor_dist_split            the N1 x N2 split every function below uses (N1 = 2^9 from 2^19 to 2^27 points, else balanced)
+ *   hodor_dist_set_transport    -1 = the handle's default; force_collectives: issue the exchange at world 1 too (testing)
+ *   hodor_dist_ntt_forward_dev  layout A (src) -> layout B (dst), ONE exchange cut into 2^log_chunks overlapped pieces;
+ *   hodor_dist_ntt_inverse_dev  layout B -> layout A, same omega (the library inverts it and folds n^-1 in);
+ *                               n_local = 2^log_n / n_ranks elements in every buffer, src != dst
+ *   hodor_dist_ntt_begin_dev /  the same in two halves (producer + exchange issued / wait + consumer), so that two
+ *   hodor_dist_ntt_end_dev      INDEPENDENT transforms interleave on one stream and each exchange hides behind the
+ *                               other's arithmetic; at most two in flight per handle; src must stay valid until end
+ *   hodor_dist_ntt_natural_dev  natural block in, natural block out (three exchanges); inverse != 0: ifft's omega^-1, n^-1
+ *   hodor_dist_lde_by_cosets_dev  Polynomial::lde / coset_lde by the reference's own coset schedule
+ *                               (src/polynomials/mod.rs:418-482, :544-609): `coeffs` = all 2^log_n coefficients on every
+ *                               rank, lde_block = this rank's natural block of the 2^log_n * factor values (paired != 0:
+ *                               its PAIRED block — natural values [d B/2, (d+1) B/2) then N/2 + the same — for COSET2)
+ *   hodor_dist_commit_dev       Blake2sIopTree::create over the ranks: subtree per rank (local_nodes: n_block x 32 bytes,
+ *                               COSET2 n_block / 2 x 32), the P subtree roots exchanged (32 bytes per rank), the top
+ *                               levels hashed by every rank: top = 2 P x 32 bytes, top[i] = global node i (top[1] = root)
+ *   hodor_dist_lde_commit_dev   both: BASELINE config[2] over the node
+ * All dist calls of one handle are serialised by the caller (one thread); buffers are the handle's own. */
+enum { HODOR_TRANSPORT_RCCL = 0, HODOR_TRANSPORT_DIRECT = 1, HODOR_TRANSPORT_COPY = 2 };
+typedef struct hodor_dist_op hodor_dist_op;
+void hodor_dist_split(uint32_t log_n, uint32_t *log_n1, uint32_t *log_n2);
+int  hodor_dist_set_transport(hodor_exchange *x, int transport, int force_collectives);
+int  hodor_dist_ntt_forward_dev(hodor_exchange *x, void *stream, const hodor_fr *a, hodor_fr *b, size_t n_local,
+                                uint32_t log_n, const hodor_fr *omega, uint32_t log_chunks);
+int  hodor_dist_ntt_inverse_dev(hodor_exchange *x, void *stream, const hodor_fr *b, hodor_fr *a, size_t n_local,
+                                uint32_t log_n, const hodor_fr *omega, uint32_t log_chunks);
+int  hodor_dist_ntt_begin_dev(hodor_exchange *x, void *stream, const hodor_fr *src, size_t n_local, uint32_t log_n,
+                              const hodor_fr *omega, int inverse, uint32_t log_chunks, hodor_dist_op **op);
+int  hodor_dist_ntt_end_dev(hodor_dist_op *op, hodor_fr *dst);
+int  hodor_dist_ntt_natural_dev(hodor_exchange *x, void *stream, const hodor_fr *src, hodor_fr *dst, size_t n_local,
+                                uint32_t log_n, const hodor_fr *omega, int inverse);
+int  hodor_dist_lde_by_cosets_dev(hodor_exchange *x, void *stream, const hodor_fr *coeffs, uint32_t log_n, size_t factor,
+                                  int coset, int paired, hodor_fr *lde_block);
+int  hodor_dist_commit_dev(hodor_exchange *x, void *stream, const hodor_fr *leafs_block, size_t n_block, int combiner,
+                           uint8_t *local_nodes, uint8_t *top, uint8_t *root);
+int  hodor_dist_lde_commit_dev(hodor_exchange *x, void *stream, const hodor_fr *coeffs, uint32_t log_n, size_t factor,
+                               int coset, int combiner, hodor_fr *lde_block, uint8_t *local_nodes, uint8_t *top,
+                               uint8_t *root);
+
 /* Synthetic input for tests and benchmarks: dst[r] = element first_index + r of the
  * index-addressable SplitMix64 stream `seed` — uniform canonical residues (rejection-sampled < p)
  * in Montgomery form, i.e. what the reference's tests draw with Fr::rand (src/fft/mod.rs:71-77), but

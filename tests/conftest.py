@@ -11,7 +11,9 @@ def _load_abort_trace():
     """tests/tools/abrt_trace.c: if this process ever dies of SIGABRT / SIGSEGV / SIGBUS, the raising thread's native
     frames and the tail of the captured stderr reach the real stderr (round 4 lost two suite runs to a bare SIGABRT
     from a runtime thread that left nothing to read).  A signal handler only: nothing runs until the signal does.
-    Loaded here — an initial conftest is imported before pytest enables faulthandler, which then chains to it."""
+    Loaded here — an initial conftest is imported before pytest enables faulthandler, which then chains to it.  pytest's
+    fd capture is already in place by then, so what the handler writes to "stderr" is captured too: its real output is
+    the file gpurun_out/abort_traces/abort_trace.<pid>.log (created empty, removed at exit when nothing happened)."""
     import ctypes
     import subprocess
     src = os.path.join(ROOT, "tests", "tools", "abrt_trace.c")
@@ -20,6 +22,9 @@ def _load_abort_trace():
         if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
             subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", src, "-o", lib],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        trace_dir = os.path.join(ROOT, "gpurun_out", "abort_traces")      # gpurun merges gpurun_out/ back
+        os.makedirs(trace_dir, exist_ok=True)
+        os.environ.setdefault("HODOR_ABORT_TRACE_DIR", trace_dir)
         ctypes.CDLL(lib)
     except Exception:
         pass      # a diagnostic aid: never a reason not to run the tests
@@ -27,6 +32,18 @@ def _load_abort_trace():
 
 if os.environ.get("HODOR_TEST_ABORT_TRACE", "1") != "0":
     _load_abort_trace()
+
+
+def pytest_unconfigure(config):
+    """A run that ends normally leaves no (empty) trace file behind."""
+    d = os.environ.get("HODOR_ABORT_TRACE_DIR")
+    if d:
+        f = os.path.join(d, "abort_trace.%d.log" % os.getpid())
+        try:
+            if os.path.exists(f) and os.path.getsize(f) == 0:
+                os.remove(f)
+        except OSError:
+            pass
 
 
 def pytest_configure(config):

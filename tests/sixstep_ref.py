@@ -148,3 +148,16 @@ def layout_b(spectrum, log_n, rank, world):
     r1 = (1 << log_n1) // world
     m = spectrum.reshape(1 << log_n2, 1 << log_n1, 4).transpose(1, 0, 2)      # [k1][k2]
     return np.ascontiguousarray(m[rank * r1:(rank + 1) * r1]).reshape(-1, 4)
+
+
+def layout_a_torch(full, log_n1, log_n2, rank, world):
+    """layout_a on a device tensor (n, 4): column block `rank` of the N1 x N2 matrix, contiguous."""
+    c2 = (1 << log_n2) // world
+    return full.view(1 << log_n1, 1 << log_n2, 4)[:, rank * c2:(rank + 1) * c2].contiguous().view(-1, 4)
+
+
+def layout_b_torch(spectrum, log_n1, log_n2, rank, world):
+    """layout_b on a device tensor: row block `rank` of the N1 x N2 matrix X[k1 + N1*k2]."""
+    r1 = (1 << log_n1) // world
+    m = spectrum.view(1 << log_n2, 1 << log_n1, 4).permute(1, 0, 2)            # [k1][k2]
+    return m[rank * r1:(rank + 1) * r1].contiguous().view(-1, 4)

@@ -72,3 +72,18 @@ def test_trees_fri_commits_and_inversions_are_schedule_independent(idx):
     out = subprocess.run([sys.executable, os.path.join(HERE, "commit_fuzz_worker.py"), logs], capture_output=True,
                          text=True, timeout=900, env=env)
     assert out.returncode == 0 and "COMMIT-FUZZ-OK" in out.stdout, (knobs, out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_pass_kernel_without_late_kernel_arguments():
+    """`make nolate`: k_ntt_pass with its store phase reading the argument struct the ordinary way instead of re-reading it
+    from the kernel-argument segment (ntt.hip: HODOR_NO_LATE_ARGS).  The default build rests on the struct sitting at
+    offset 0 of that segment; this build does not, and must give the same bytes — a compiler or code-object change that
+    broke the assumption would show up as a difference between the two (round-4 advisor finding)."""
+    root = os.path.dirname(HERE)
+    lib = os.path.join(root, "hodor_amd", "libhodor_gpu_nolate.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(root, "hodor_amd", "csrc"), "nolate"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, HODOR_LIB=lib)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "plan_fuzz_worker.py"), "1,5,9,10,13,16,17,20", "16:4:1,13:2:2"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "PLAN-FUZZ-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -120,3 +120,33 @@ def test_c_program_on_device(tmp_path):
     # a plain C process (no Python, no torch) binds RCCL at run time and runs the 4-step transform through
     # hodor_sixstep_exchange_dev on a one-rank communicator
     assert "through the library's exchange (one-rank RCCL) ok" in out.stdout, out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------- two plain-C processes over the library's own multi-GPU schedules
+D2_SRC = os.path.join(ROOT, "tests", "host_c", "test_dist2.c")
+
+
+def _build_dist2(tmp_path):
+    import hodor_amd
+    hodor_amd.build()
+    exe = str(tmp_path / "test_dist2")
+    libdir = os.path.join(ROOT, "hodor_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-O2", D2_SRC, "-L" + libdir, "-lhodor_gpu",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_two_process_c_program_compiles_as_c11(tmp_path):
+    assert os.path.exists(_build_dist2(tmp_path))
+
+
+@pytest.mark.gpu
+def test_two_c_processes_run_the_library_schedules_and_the_transport_soak(tmp_path):
+    """fork + hipIpc + the direct transports, no Python, no torch, no RCCL: hodor_dist_ntt_natural_dev,
+    hodor_dist_lde_commit_dev (both tree formats) and 10 000 generations of hodor_dist_ntt_forward_dev on alternating
+    payloads per transport, every generation compared with its payload's known answer (a stale line anywhere = a
+    mismatch).  On this box the two ranks share the one GPU; `test_dist2 G 0 1` is the same program between two devices."""
+    out = subprocess.run([_build_dist2(tmp_path), "10000"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "all tests passed" in out.stdout
+    assert out.stdout.count("0 mismatches") == 4, out.stdout

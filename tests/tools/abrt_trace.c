@@ -21,13 +21,20 @@
 #include <fcntl.h>
 #include <signal.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
-static int out_fd = 2;
+static int out_fd = 2;      /* the stderr of load time (under a runner that captures early this is ALREADY its capture file) */
+static int file_fd = -1;    /* $HODOR_ABORT_TRACE_DIR/abort_trace.<pid>.log: nobody redirects that */
 
-static void put(const char *s) { (void)!write(out_fd, s, strlen(s)); }
+static void put_n(const char *s, size_t n)
+{
+    (void)!write(out_fd, s, n);
+    if (file_fd >= 0) (void)!write(file_fd, s, n);
+}
+static void put(const char *s) { put_n(s, strlen(s)); }
 
 static void handler(int sig, siginfo_t *si, void *uc)
 {
@@ -39,6 +46,7 @@ static void handler(int sig, siginfo_t *si, void *uc)
              si ? si->si_code : 0, si ? si->si_addr : (void *)0, (long)syscall(SYS_gettid), (int)getpid());
     put(line);
     backtrace_symbols_fd(bt, n, out_fd);
+    if (file_fd >= 0) backtrace_symbols_fd(bt, n, file_fd);
     /* the thread's name says which runtime it belongs to */
     snprintf(line, sizeof line, "/proc/self/task/%ld/comm", (long)syscall(SYS_gettid));
     int fd = open(line, O_RDONLY);
@@ -55,13 +63,13 @@ static void handler(int sig, siginfo_t *si, void *uc)
     /* the last words of this process on its CURRENT stderr, if that is a file we can read back (a capture file) */
     {
         off_t end = lseek(2, 0, SEEK_CUR);
-        if (end > 0 && out_fd != 2) {
+        if (end > 0) {
             static char tail[8192];
             off_t from = end > (off_t)sizeof tail ? end - (off_t)sizeof tail : 0;
             ssize_t k = pread(2, tail, (size_t)(end - from), from);
             if (k > 0) {
                 put("---- tail of the captured stderr ----\n");
-                (void)!write(out_fd, tail, (size_t)k);
+                put_n(tail, (size_t)k);
                 put("\n---- end of captured stderr ----\n");
             }
         }
@@ -77,6 +85,12 @@ __attribute__((constructor)) static void abrt_trace_init(void)
     if (d >= 0) {
         out_fd = d;
         (void)fcntl(out_fd, F_SETFD, FD_CLOEXEC);
+    }
+    const char *dir = getenv("HODOR_ABORT_TRACE_DIR");
+    if (dir && *dir) {
+        char path[512];
+        snprintf(path, sizeof path, "%s/abort_trace.%d.log", dir, (int)getpid());
+        file_fd = open(path, O_WRONLY | O_CREAT | O_APPEND | O_CLOEXEC, 0644);   /* stays empty unless a signal arrives */
     }
     void *warm[4];
     (void)backtrace(warm, 4); /* loads libgcc's unwinder now, not inside the handler */
