@@ -238,12 +238,15 @@ def main():
                     help="N > 1, pipelined: number of steps of the strict-order (un-pipelined) timing reported beside it")
     ap.add_argument("--force-collectives", action="store_true",
                     help="testing aid: issue the RCCL all-to-alls even at world size 1 (needs a torchrun launch)")
+    ap.add_argument("--recv-coarse", action="store_true",
+                    help="--exchange direct / copy: receive buffers in plain (coarse-grained) device memory instead of the "
+                         "fine-grained memory the transport's memory model is argued for (an A/B aid, DESIGN.md §6)")
     ap.add_argument("--allow-knobs", action="store_true",
                     help="run although HODOR_* tuning variables are set (they are echoed in the JSON line)")
     ap.add_argument("--skip-checks", action="store_true",
                     help="ablation builds only (bench/ablate.sh): results are wrong by construction; needs "
                          "--allow-knobs and marks the line \"checks\": {\"skipped\": true}")
-    ap.add_argument("--soak-seconds", type=float, default=3.0,
+    ap.add_argument("--soak-seconds", type=float, default=6.0,
                     help="after the timed region: keep stepping for about this long (the same step, untimed for `value`), then "
                          "re-run the round-trip gate on what the LAST step left behind; reported as `soak` (sustained ms per "
                          "step once the part sits at its power limit, and a determinism check); 0 = skip")
@@ -346,6 +349,12 @@ def main():
                 if flag.item() > 0.5:
                     ctl["dev"], ctl["group"] = "cpu", g
 
+    # The CPU-baseline leg runs FIRST (round 5): ~10 s of host work in front of the GPU phase instead of behind it, so that
+    # the run ends with the GPU phases — timed region, soak, gates, extras — back to back and an outside sampler that looks
+    # at the part every few seconds meets it busy (round 4: the 3 s of GPU work fell between the driver's 5 s samples).
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline and not multi:
+        cpu_base = cpu_baseline()
     ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=local_rank)
     log_n = args.log_n
     n = 1 << log_n
@@ -389,7 +398,7 @@ def main():
                 torch.cuda.synchronize()
         direct = None
         if args.exchange in ("direct", "copy"):
-            direct = hodor_amd.DirectExchange(ctx, world, rank, n, n_slots=4)
+            direct = hodor_amd.DirectExchange(ctx, world, rank, n, n_slots=4, coarse=args.recv_coarse)
             if world == 1:
                 hodor_amd.DirectExchange.connect_local([direct])
             else:
@@ -808,8 +817,8 @@ def main():
             "ms_per_transform": avg_launch_ms * passes}
         if not args.no_extra and not multi:
             result["extra"] = extra_lde_commit(ctx, torch, stream)
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline()
+        if cpu_base is not None:
+            result["cpu_baseline"] = cpu_base
     if multi and not args.no_extra:
         # the other half of BASELINE's metric and config[4], every rank takes part (collectives inside)
         del b, c

@@ -10,6 +10,7 @@ for i in $(seq $R); do
   echo "single-device transform      : $(python bench.py $COMMON 2>/dev/null | ms)"
   echo "4-step, no exchange          : $(python bench.py --mode sixstep $COMMON 2>/dev/null | ms)"
   echo "4-step, direct transport     : $(python bench.py --mode sixstep --exchange direct $COMMON 2>/dev/null | ms)"
+  echo "  ... coarse-grained receive  : $(python bench.py --mode sixstep --exchange direct --recv-coarse $COMMON 2>/dev/null | ms)"
   echo "4-step, copy engines, 4 chunks: $(tr --mode sixstep --force-collectives --exchange copy --exchange-chunks 4 $COMMON)"
   echo "4-step, RCCL (torch), forced : $(tr --mode sixstep --force-collectives $COMMON)"
   echo "4-step, RCCL (native), forced: $(tr --mode sixstep --force-collectives --exchange native $COMMON)"

@@ -13,7 +13,7 @@ def _load_abort_trace():
     from a runtime thread that left nothing to read).  A signal handler only: nothing runs until the signal does.
     Loaded here — an initial conftest is imported before pytest enables faulthandler, which then chains to it.  pytest's
     fd capture is already in place by then, so what the handler writes to "stderr" is captured too: its real output is
-    the file gpurun_out/abort_traces/abort_trace.<pid>.log (created empty, removed at exit when nothing happened)."""
+    the file gpurun_out/abort_traces/abort_trace.<pid>.log, created when the signal arrives."""
     import ctypes
     import subprocess
     src = os.path.join(ROOT, "tests", "tools", "abrt_trace.c")
@@ -32,18 +32,6 @@ def _load_abort_trace():
 
 if os.environ.get("HODOR_TEST_ABORT_TRACE", "1") != "0":
     _load_abort_trace()
-
-
-def pytest_unconfigure(config):
-    """A run that ends normally leaves no (empty) trace file behind."""
-    d = os.environ.get("HODOR_ABORT_TRACE_DIR")
-    if d:
-        f = os.path.join(d, "abort_trace.%d.log" % os.getpid())
-        try:
-            if os.path.exists(f) and os.path.getsize(f) == 0:
-                os.remove(f)
-        except OSError:
-            pass
 
 
 def pytest_configure(config):

@@ -27,7 +27,8 @@
 #include <unistd.h>
 
 static int out_fd = 2;      /* the stderr of load time (under a runner that captures early this is ALREADY its capture file) */
-static int file_fd = -1;    /* $HODOR_ABORT_TRACE_DIR/abort_trace.<pid>.log: nobody redirects that */
+static int file_fd = -1;    /* $HODOR_ABORT_TRACE_DIR/abort_trace.<pid>.log: nobody redirects that; opened when the signal arrives */
+static char file_path[512];
 
 static void put_n(const char *s, size_t n)
 {
@@ -41,6 +42,7 @@ static void handler(int sig, siginfo_t *si, void *uc)
     (void)uc;
     char line[160];
     void *bt[96];
+    if (file_path[0]) file_fd = open(file_path, O_WRONLY | O_CREAT | O_APPEND | O_CLOEXEC, 0644);   /* async-signal-safe */
     int n = backtrace(bt, 96);
     snprintf(line, sizeof line, "\n==== abrt_trace: signal %d (si_code %d, addr %p) in tid %ld of pid %d ====\n", sig,
              si ? si->si_code : 0, si ? si->si_addr : (void *)0, (long)syscall(SYS_gettid), (int)getpid());
@@ -87,11 +89,7 @@ __attribute__((constructor)) static void abrt_trace_init(void)
         (void)fcntl(out_fd, F_SETFD, FD_CLOEXEC);
     }
     const char *dir = getenv("HODOR_ABORT_TRACE_DIR");
-    if (dir && *dir) {
-        char path[512];
-        snprintf(path, sizeof path, "%s/abort_trace.%d.log", dir, (int)getpid());
-        file_fd = open(path, O_WRONLY | O_CREAT | O_APPEND | O_CLOEXEC, 0644);   /* stays empty unless a signal arrives */
-    }
+    if (dir && *dir) snprintf(file_path, sizeof file_path, "%s/abort_trace.%d.log", dir, (int)getpid());
     void *warm[4];
     (void)backtrace(warm, 4); /* loads libgcc's unwinder now, not inside the handler */
     struct sigaction sa;
