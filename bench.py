@@ -215,8 +215,9 @@ def main():
                          "testing aid that stages every exchange through the host, so that several ranks can share "
                          "ONE GPU and the whole multi-rank path can be exercised on a single-GPU box (the line is "
                          "then marked \"backend\": \"gloo\" and is not a measurement)")
-    ap.add_argument("--exchange", choices=["torch", "native", "direct", "copy"], default="torch",
-                    help="who runs the all-to-alls of the 4-step schedule: 'torch' = torch.distributed (all_to_all_single, "
+    ap.add_argument("--exchange", choices=["auto", "torch", "native", "direct", "copy"], default="auto",
+                    help="who runs the all-to-alls of the 4-step schedule: 'auto' (default) = 'native' on RCCL when the library can "
+                         "bind it on every rank, 'torch' otherwise; 'torch' = torch.distributed (all_to_all_single, "
                          "async); 'native' = the library's own exchange behind the C ABI (hodor_sixstep_exchange_dev: "
                          "grouped ncclSend/ncclRecv on a communicator and communication stream it owns — what a Rust "
                          "caller links); needs RCCL and one GPU per rank; 'direct' = no all-to-all at all: every rank maps "
@@ -390,7 +391,25 @@ def main():
         assert 1 << (world.bit_length() - 1) == world, "sixstep needs a power-of-two world size"
         omega = ctx.domain(1 << log_total)[2]
         native = None
-        if args.exchange == "native" and (world > 1 or args.force_collectives):
+        if args.exchange == "auto":
+            # the library's own schedule over its own RCCL exchange (csrc/abi_dist.hip, abi_exchange.hip) is what a Rust
+            # prover links, so it is what a bare `bench.py --gpus N` measures — when EVERY rank can create the handle
+            want = args.backend == "nccl" and (world > 1 or args.force_collectives) and hodor_amd.Exchange.available()
+            args.exchange = "torch"
+            if want:
+                try:
+                    with quiet_stdout():
+                        native = hodor_amd.Exchange.over_process_group(ctx, rank, world, group=ctl["group"])
+                        torch.cuda.synchronize()
+                except Exception:   # noqa: BLE001 — librccl could not be bound / the communicator could not be created
+                    native = None
+                everyone = all_reduce_scalar(1.0 if native is not None else 0.0, dist.ReduceOp.MIN) > 0.5 if multi else native is not None
+                if everyone:
+                    args.exchange = "native"
+                elif native is not None:
+                    native.close()
+                    native = None
+        elif args.exchange == "native" and (world > 1 or args.force_collectives):
             if args.backend != "nccl":
                 raise SystemExit("--exchange native needs one GPU per rank (RCCL); the gloo aid shares one device")
             with quiet_stdout():
@@ -635,8 +654,9 @@ def main():
                                   "handle's own stream (C ABI: hodor_exchange_direct_copy_dev, the direct transport's flags)" if args.exchange == "copy" else
                                   "direct: the producing pass stores each slab into the peer's receive buffer (C ABI: "
                                   "hodor_sixstep_columns_direct_dev / _rows_direct_dev, no all-to-all, no copy)" if direct is not None else
-                                  "C ABI: hodor_sixstep_exchange_dev (grouped ncclSend/ncclRecv on the library's stream)"
-                                  if native is not None else "torch.distributed all_to_all_single (async)"),
+                                  "library schedule (hodor_dist_ntt_begin_dev / _end_dev) over its own RCCL exchange: ncclAllToAll — grouped "
+                                  "ncclSend/ncclRecv where the library lacks it — on the handle's communication stream"
+                                  if native is not None else "hodor_amd/sixstep.py over torch.distributed all_to_all_single (async)"),
                     "all_to_alls_per_transform": 1, "chunks_per_all_to_all": chunks,
                     "bytes_sent_per_rank_per_transform": sent,
                     "all_to_all_ms_unoverlapped": ms, "gb_per_s_per_rank": (sent / (ms * 1e-3) / 1e9) if world > 1 else None,

@@ -326,7 +326,7 @@ def test_native_exchange_over_rccl_at_world_1(gpu_ctxs):
     x.close()
 
 
-@pytest.mark.parametrize("exchange", ["native", "torch"])
+@pytest.mark.parametrize("exchange", ["native", "torch", "auto"])
 def test_bench_four_step_on_real_rccl_at_world_1(exchange):
     """bench.py's multi-GPU code paths on a real RCCL communicator with one rank (torchrun, --force-collectives): the
     chunked, pipelined exchanges through the library's own exchange (C ABI) and through torch.distributed, the host-side
@@ -337,9 +337,12 @@ def test_bench_four_step_on_real_rccl_at_world_1(exchange):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    extras = ["--big-log-n", "24"] if exchange == "torch" else ["--no-extra"]
+    # torch: both distributed extras through hodor_amd/distributed.py; auto (= the library's schedule over its own RCCL
+    # exchange, what a bare `bench.py --gpus N` runs): the LDE + commit extra through hodor_dist_lde_by_cosets_dev /
+    # hodor_dist_commit_dev as well
+    extras = ["--big-log-n", "24"] if exchange == "torch" else ([] if exchange == "auto" else ["--no-extra"])
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                          "--master-addr", "127.0.0.1", "--master-port", "29577" if exchange == "native" else "29578",
+                          "--master-addr", "127.0.0.1", "--master-port", {"native": "29577", "torch": "29578", "auto": "29579"}[exchange],
                           os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "sixstep", "--force-collectives",
                           "--exchange", exchange, "--exchange-chunks", "4", "--steps", "3", "--warmup", "1",
                           "--log-n", "22", "--strict-steps", "2", "--no-cpu-baseline"] + extras,
@@ -349,7 +352,10 @@ def test_bench_four_step_on_real_rccl_at_world_1(exchange):
     assert "fallback" not in line, line.get("fallback")
     assert line["checks"]["roundtrip"] is True and line["checks"]["fft_digest_vs_cpu_oracle"] is True
     assert line["collective_on_data_path"] is True and line["pipelined_across_steps"] is True
-    assert ("C ABI" in line["exchange"]["transport"]) == (exchange == "native")
+    assert ("library schedule" in line["exchange"]["transport"]) == (exchange != "torch")
+    if exchange == "auto":
+        lc = line["extra"]["lde_commit"]
+        assert lc["root"] == FULL["lde"]["22"]["root"] and lc["schedule"].startswith("library"), lc
     if exchange == "torch":
         assert line["extra"]["lde_commit"]["root"] == FULL["lde"]["22"]["root"], line["extra"]["lde_commit"]
         c4 = line["extra"]["config4"]
