@@ -481,6 +481,10 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
     // BASE_BLAKE2S_PARAMS, src/iop/blake2s_trivial_iop.rs:8-16
     HostBlake2s::keyed_midstate(ctx->mid.h, (const uint8_t *)"Squeamish Ossifrage", 19,
                                 (const uint8_t *)"Shaftoe", 7);
+    // COSET2 leaves (this build's opt-in format) hash under a personalisation of their own, so that the 64 bytes of two
+    // child digests can never open as a "coset value pair" (round-4 advisor finding; the depth check stays as well)
+    HostBlake2s::keyed_midstate(ctx->mid.hp, (const uint8_t *)"Squeamish Ossifrage", 19,
+                                (const uint8_t *)"Shaftoe2", 8);
     ctx->device = device;
     if (device >= 0) {
         int count = 0;
@@ -538,6 +542,7 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
             if (L.computed) (void)hipEventDestroy(L.computed);
             if (L.stream) (void)hipStreamDestroy(L.stream);
         }
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -594,13 +599,25 @@ extern "C" int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr)
 extern "C" int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes)
 {
     NEED_DEVICE();
+    if (bytes <= hodor_ctx::PINNED_BYTES) {   // small: through the context's pinned buffer (ctx.hpp), never a pin of the caller's page
+        HostXfer xfer(ctx, nullptr);
+        HIPCHK(xfer.h2d(dev_dst, host_src, bytes));
+        HIPCHK(xfer.finish());
+        return HODOR_OK;
+    }
     HIPCHK(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
     return HODOR_OK;
 }
 extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
 {
     NEED_DEVICE();
-    HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    if (bytes <= hodor_ctx::PINNED_BYTES) {
+        HostXfer xfer(ctx, nullptr);
+        HIPCHK(xfer.d2h(host_dst, dev_src, bytes));
+        HIPCHK(xfer.finish());
+    } else {
+        HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    }
     note_round_trip(ctx);
     return HODOR_OK;
 }
@@ -912,9 +929,10 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
     const Level &top = levels.back();
     hodor_fr top_prod[TOP];
     uint32_t host_flag = 0;
-    HIPCHK(hipMemcpyAsync(top_prod, base + top.prod_off, top.T * 32, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HostXfer xfer(ctx, stream);      // through the context's pinned buffer: no stack page is ever pinned (ctx.hpp)
+    HIPCHK(xfer.d2h(top_prod, base + top.prod_off, top.T * 32));
+    HIPCHK(xfer.d2h(&host_flag, flag, 4));
+    HIPCHK(xfer.finish());
     note_round_trip(ctx);
     if (host_flag) {   // full_grand_product.inverse() is None -> SynthesisError::Error, data untouched (:909)
         set_err(ctx, "batch_inversion: zero element");
@@ -936,14 +954,14 @@ extern "C" int hodor_poly_batch_inversion_dev(hodor_ctx *ctx, void *stream_, hod
             inv = ctx->F.mul(inv, v[i]);
         }
     }
-    HIPCHK(hipMemcpyAsync(base + top.prod_off, top_prod, top.T * 32, hipMemcpyHostToDevice, stream));
+    HIPCHK(xfer.h2d(base + top.prod_off, top_prod, top.T * 32));
     for (size_t l = levels.size(); l-- > 0;) {
         const Level &L = levels[l];
         uint4 *target = l == 0 ? (uint4 *)a : (uint4 *)(base + levels[l - 1].prod_off);
         HIPCHK(batchinv_backward_launch(stream, target, L.n, L.T, (const uint4 *)(base + L.prefix_off),
                                         (const uint4 *)(base + L.prod_off), ctx->P));
     }
-    HIPCHK(hipStreamSynchronize(stream));   // top_prod is a stack buffer the upload reads from
+    HIPCHK(xfer.finish());   // the call is synchronous: a[] holds the inverses on return
     return HODOR_OK;
 }
 
@@ -973,8 +991,9 @@ extern "C" int hodor_poly_evaluate_at_dev(hodor_ctx *ctx, void *stream_, const h
     } else {
         HIPCHK(evaluate_at_launch(stream, (const uint4 *)coeffs, n, to_dev(to_h(g)), partials, ticket, res, ctx->P));
     }
-    HIPCHK(hipMemcpyAsync(out, res, 32, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HostXfer xfer(ctx, stream);
+    HIPCHK(xfer.d2h(out, res, 32));
+    HIPCHK(xfer.finish());
     note_round_trip(ctx);
     return HODOR_OK;
 }
@@ -1038,7 +1057,12 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
     {
         std::unique_lock<std::mutex> up(ctx->up_mu, std::defer_lock);
         if (serial) up.lock();
-        if ((e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, L->stream)) != hipSuccess ||
+        const bool small_in = n_in * 32 <= hodor_ctx::PINNED_BYTES;   // small slices go through the context's pinned buffer
+        if (small_in) {
+            HostXfer xfer(ctx, L->stream);
+            if ((e = xfer.h2d(din, in, n_in * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess) return fail(e, "slice upload");
+        }
+        if ((!small_in && (e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, L->stream)) != hipSuccess) ||
             (e = hipEventRecord(L->uploaded, L->stream)) != hipSuccess ||
             (serial && (e = hipStreamSynchronize(L->stream)) != hipSuccess))   // the link is free for the next upload
             return fail(e, "slice upload");
@@ -1059,9 +1083,13 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             if ((e = hipEventSynchronize(L->computed)) != hipSuccess) return fail(e, "slice compute");   // wait OUTSIDE the lock
             down.lock();
         }
-        if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess ||
-            (e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(L->stream)) != hipSuccess)
+        if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess) return fail(e, "slice download");
+        if (n_out * 32 <= hodor_ctx::PINNED_BYTES) {
+            HostXfer xfer(ctx, L->stream);
+            if ((e = xfer.d2h(out, dptr_out, n_out * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess)
+                return fail(e, "slice download");
+        } else if ((e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
+                   (e = hipStreamSynchronize(L->stream)) != hipSuccess)
             return fail(e, "slice download");
     }
     lane_release(ctx, L);

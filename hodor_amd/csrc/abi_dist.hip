@@ -465,9 +465,10 @@ extern "C" int hodor_dist_commit_dev(hodor_exchange *x, void *stream_, const hod
     hodor_fr *gathered = nullptr;
     if ((rc = dist_all_to_all(x, stream, (const hodor_fr *)mine, P, 6, &gathered, &h))) return rc;
     memset(top, 0, 2 * P * 32);
-    hipError_t e = hipMemcpyAsync(top + 32 * P, gathered, 32 * P, hipMemcpyDeviceToHost, stream);
+    HostXfer xfer(ctx, stream);
+    hipError_t e = xfer.d2h(top + 32 * P, gathered, 32 * P);
     int r2 = dist_a2a_release(x, stream, h);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = xfer.finish();
     {
         std::lock_guard<std::mutex> lk(x->mu);
         (void)work_done(x, 5, stream);

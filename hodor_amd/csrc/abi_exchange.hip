@@ -463,7 +463,11 @@ extern "C" int hodor_exchange_direct_set_peers(hodor_exchange *x, uint32_t slot,
             if (t != x->rank) x->peer_flags[t] = (uint32_t *)flags[t];
         }
     }
-    HIPCHK(hipMemcpy(x->slots[slot].d_tab, tab, x->n_ranks * sizeof(uint64_t), hipMemcpyHostToDevice));
+    {
+        HostXfer xfer(ctx, nullptr);
+        HIPCHK(xfer.h2d(x->slots[slot].d_tab, tab, x->n_ranks * sizeof(uint64_t)));
+        HIPCHK(xfer.finish());
+    }
     for (uint32_t t = 0; t < x->n_ranks; t++) x->slots[slot].h_tab[t] = tab[t];
     x->slots[slot].set = true;
     return HODOR_OK;

@@ -160,8 +160,11 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
 
     // challenges | roots | final coefficients sit back to back in the slab's small block: one copy
     std::vector<uint8_t> small(64 * (num_steps + 1) + 32 * out_deg);
-    FRICHK(hipMemcpyAsync(small.data(), d_small, small.size(), hipMemcpyDeviceToHost, stream));
-    FRICHK(hipStreamSynchronize(stream));
+    {
+        HostXfer xfer(ctx, stream);      // through the context's pinned buffer (ctx.hpp): no heap page is pinned behind our back
+        FRICHK(xfer.d2h(small.data(), d_small, small.size()));
+        FRICHK(xfer.finish());
+    }
     note_round_trip(ctx);
     p->roots.assign(small.begin() + 32 * (num_steps + 1), small.begin() + 64 * (num_steps + 1));
     p->challenges.resize(num_steps);
@@ -283,9 +286,12 @@ extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *s
 
     std::vector<uint8_t> small(small_bytes);
     p->final_coeffs.resize(out_deg);                                                                         // :232-234
-    FRICHK(hipMemcpyAsync(small.data(), d_small, small_bytes, hipMemcpyDeviceToHost, stream));
-    FRICHK(hipMemcpyAsync(p->final_coeffs.data(), coeffs, 32 * out_deg, hipMemcpyDeviceToHost, stream));
-    FRICHK(hipStreamSynchronize(stream));
+    {
+        HostXfer xfer(ctx, stream);
+        FRICHK(xfer.d2h(small.data(), d_small, small_bytes));
+        FRICHK(xfer.d2h(p->final_coeffs.data(), coeffs, 32 * out_deg));
+        FRICHK(xfer.finish());
+    }
     note_round_trip(ctx);
     p->roots.assign(small.begin() + 32 * (num_steps + 1), small.end());
     p->challenges.resize(num_steps);
@@ -306,7 +312,7 @@ extern "C" int hodor_fri_commit_through_coefficients(hodor_ctx *ctx, const hodor
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
     DevBuf dv;
     HIPCHK(hipMalloc(&dv.p, n * 32));
-    HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
+    if (int rc_up = hodor_buf_upload(ctx, dv.p, lde_values, n * 32)) return rc_up;   // small codewords through the pinned buffer
     return hodor_fri_commit_through_coefficients_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor,
                                                      out_deg, combiner, out);
 }
@@ -325,7 +331,7 @@ extern "C" int hodor_fri_commit_combined(hodor_ctx *ctx, const hodor_fr *lde_val
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
     DevBuf dv;
     HIPCHK(hipMalloc(&dv.p, n * 32));
-    HIPCHK(hipMemcpy(dv.p, lde_values, n * 32, hipMemcpyHostToDevice));
+    if (int rc_up = hodor_buf_upload(ctx, dv.p, lde_values, n * 32)) return rc_up;   // small codewords through the pinned buffer
     // the context's own compute stream, like every other slice entry point: in-order with the other
     // callers' transforms that share ctx->scratch (hodor_fri_commit_dev holds ctx->mu until it has
     // synchronised), never the legacy NULL stream, which has no ordering with a non-blocking stream
@@ -348,8 +354,11 @@ extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr
     HIPCHK(iop_query_launch(stream, (const uint4 *)(leafs + (natural_index & ~(size_t)1)), (const uint4 *)nodes, n,
                             natural_index, (uint4 *)stage.p, ctx->mid));
     std::vector<uint8_t> host(entries * 32);
-    HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    {
+        HostXfer xfer(ctx, stream);
+        HIPCHK(xfer.d2h(host.data(), stage.p, entries * 32));
+        HIPCHK(xfer.finish());
+    }
     note_round_trip(ctx);
     memcpy(value, host.data(), 32);
     memcpy(path, host.data() + 32, (entries - 1) * 32);
@@ -376,8 +385,11 @@ extern "C" int hodor_iop_query_combined_dev(hodor_ctx *ctx, void *stream_, const
     HIPCHK(iop_query_coset2_launch(stream, (const uint4 *)leafs, (const uint4 *)nodes, n, natural_index,
                                    (uint4 *)stage.p, ctx->mid));
     std::vector<uint8_t> host(entries * 32);
-    HIPCHK(hipMemcpyAsync(host.data(), stage.p, entries * 32, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    {
+        HostXfer xfer(ctx, stream);
+        HIPCHK(xfer.d2h(host.data(), stage.p, entries * 32));
+        HIPCHK(xfer.finish());
+    }
     note_round_trip(ctx);
     memcpy(values, host.data(), 64);
     memcpy(path, host.data() + 64, (entries - 2) * 32);
@@ -446,9 +458,10 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
         domain_size = next;
     }
     std::vector<uint8_t> host(stage_bytes);
-    if (hipMemcpyAsync(host.data(), stage.p, stage_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess)
-        return 0;
+    {
+        HostXfer xfer(ctx, ctx->stream);
+        if (xfer.d2h(host.data(), stage.p, stage_bytes) != hipSuccess || xfer.finish() != hipSuccess) return 0;
+    }
     note_round_trip(ctx);
     size_t o = 0, h = 0;
     auto put64 = [&](uint64_t v) { memcpy(buf + o, &v, 8); o += 8; };
@@ -809,7 +822,8 @@ extern "C" int hodor_fri_verify_prototype(hodor_fri_proto *p, const hodor_fr *ld
     uint64_t domain_size = size, domain_idx = natural_element_index;
     auto fetch = [&](const hodor_fr *base, uint64_t i, HFr *out) -> bool {
         hodor_fr v;
-        if (hipMemcpy(&v, base + i, 32, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        HostXfer xfer(ctx, nullptr);     // a blocking copy of one element, through the pinned buffer like every small one
+        if (xfer.d2h(&v, base + i, 32) != hipSuccess || xfer.finish() != hipSuccess) return false;
         *out = to_h(&v);
         return true;
     };
@@ -882,8 +896,7 @@ extern "C" int hodor_fri_intermediate_values(hodor_fri_proto *p, size_t step, ho
     if (!p || !values || step >= p->num_steps) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = p->ctx;
     NEED_DEVICE();
-    HIPCHK(hipMemcpy(values, p->inter_values[step], p->inter_sizes[step] * 32, hipMemcpyDeviceToHost));
-    return HODOR_OK;
+    return hodor_buf_download(ctx, values, p->inter_values[step], p->inter_sizes[step] * 32);
 }
 extern "C" int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes)
 {
@@ -891,9 +904,8 @@ extern "C" int hodor_fri_tree_nodes(hodor_fri_proto *p, int step, uint8_t *nodes
     hodor_ctx *ctx = p->ctx;
     NEED_DEVICE();
     const size_t shift = p->combiner == HODOR_COMBINER_COSET2 ? 1 : 0;   // a COSET2 tree has half as many entries
-    if (step < 0) HIPCHK(hipMemcpy(nodes, p->l0_nodes, (p->n >> shift) * 32, hipMemcpyDeviceToHost));
-    else HIPCHK(hipMemcpy(nodes, p->inter_nodes[step], (p->inter_sizes[step] >> shift) * 32, hipMemcpyDeviceToHost));
-    return HODOR_OK;
+    if (step < 0) return hodor_buf_download(ctx, nodes, p->l0_nodes, (p->n >> shift) * 32);
+    return hodor_buf_download(ctx, nodes, p->inter_nodes[step], (p->inter_sizes[step] >> shift) * 32);
 }
 
 extern "C" size_t hodor_fri_serialize(const hodor_fri_proto *p, uint8_t *buf, size_t cap)

@@ -147,7 +147,7 @@ static void host_hash_pair(const hodor_ctx *ctx, const hodor_fr *lo, const hodor
     uint8_t buf[64];
     memcpy(buf, lo->l, 32);          // encode_leaf: the raw Montgomery limbs, little-endian (host is LE)
     memcpy(buf + 32, hi->l, 32);
-    HostBlake2s::finish(ctx->mid.h, buf, 64, out);
+    HostBlake2s::finish(ctx->mid.hp, buf, 64, out);   // the COSET2 leaf midstate (personal "Shaftoe2"): not a node hash
 }
 
 extern "C" int hodor_hash_leaf_combined(const hodor_ctx *ctx, const hodor_fr *values, int combiner, uint8_t out[32])

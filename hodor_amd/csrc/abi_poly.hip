@@ -274,8 +274,9 @@ extern "C" int hodor_poly_from_host_h(hodor_ctx *ctx, int form, const hodor_fr *
             for (size_t i = 0; i < len; i++) v[i] = to_dev(to_h(&host[i]));
             e = store_elems_launch(ctx->stream, p->d(), v, (uint32_t)len);
         } else {
-            e = hipMemcpyAsync(p->d(), host, len * 32, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // `host` is the caller's: done with it on return
+            HostXfer xfer(ctx, ctx->stream);   // small vectors through the pinned buffer, whole ones straight from the caller's
+            e = xfer.h2d(p->d(), host, len * 32);
+            if (e == hipSuccess) e = xfer.finish();   // `host` is the caller's: done with it on return
         }
     }
     if (e != hipSuccess) {
@@ -386,8 +387,9 @@ extern "C" int hodor_poly_as_ref_h(hodor_poly *p, const hodor_fr **host)
     if (!host) return HODOR_ERR_INVALID;
     if (!p->host_valid) {
         p->host.resize(p->n);
-        HIPCHK(hipMemcpyAsync(p->host.data(), p->d(), p->n * 32, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HostXfer xfer(ctx, ctx->stream);
+        HIPCHK(xfer.d2h(p->host.data(), p->d(), p->n * 32));
+        HIPCHK(xfer.finish());
         note_round_trip(ctx);
         p->host_valid = true;
     }
@@ -405,8 +407,9 @@ extern "C" int hodor_poly_read_h(hodor_poly *p, size_t first, size_t count, hodo
         memcpy(out, p->host.data() + first, count * 32);
         return HODOR_OK;
     }
-    HIPCHK(hipMemcpyAsync(out, p->dfr() + first, count * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HostXfer xfer(ctx, ctx->stream);
+    HIPCHK(xfer.d2h(out, p->dfr() + first, count * 32));
+    HIPCHK(xfer.finish());
     note_round_trip(ctx);
     return HODOR_OK;
 }
@@ -422,8 +425,9 @@ extern "C" int hodor_poly_write_h(hodor_poly *p, size_t first, size_t count, con
         for (size_t i = 0; i < count; i++) v[i] = to_dev(to_h(&in[i]));
         HIPCHK(store_elems_launch(ctx->stream, p->d() + 2 * first, v, (uint32_t)count));
     } else {
-        HIPCHK(hipMemcpyAsync(p->dfr() + first, in, count * 32, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HostXfer xfer(ctx, ctx->stream);
+        HIPCHK(xfer.h2d(p->dfr() + first, in, count * 32));
+        HIPCHK(xfer.finish());
     }
     if (p->host_valid) memcpy(p->host.data() + first, in, count * 32);   // the copy follows the write
     return HODOR_OK;
@@ -465,8 +469,11 @@ extern "C" int hodor_poly_equal_h(const hodor_poly *a, const hodor_poly *b, int 
     uint32_t host_flag = 1;
     hipError_t e = hipMemsetAsync(flag, 0, 4, ctx->stream);
     if (e == hipSuccess) e = count_diff_launch(ctx->stream, a->d(), b->d(), a->n, (uint32_t *)flag);
-    if (e == hipSuccess) e = hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    {
+        HostXfer xfer(ctx, ctx->stream);
+        if (e == hipSuccess) e = xfer.d2h(&host_flag, flag, 4);
+        if (e == hipSuccess) e = xfer.finish();
+    }
     pool_release(ctx, flag, got);
     HIPCHK(e);
     note_round_trip(ctx);
@@ -867,17 +874,18 @@ extern "C" int hodor_iop_roots_h(hodor_iop *const *ts, size_t count, uint8_t *ro
     hodor_ctx *ctx = ts[0]->ctx;
     NEED_DEVICE();
     bool pending = false;
-    for (size_t i = 0; i < count; i++) {
-        if (!ts[i] || ts[i]->ctx != ctx) return HODOR_ERR_INVALID;
-        if (!ts[i]->root_valid) {
-            HIPCHK(hipMemcpyAsync(ts[i]->root, ts[i]->d() + 32, 32, hipMemcpyDeviceToHost, ctx->stream));   // nodes[1]
-            pending = true;
+    {
+        HostXfer xfer(ctx, ctx->stream);
+        for (size_t i = 0; i < count; i++) {
+            if (!ts[i] || ts[i]->ctx != ctx) return HODOR_ERR_INVALID;
+            if (!ts[i]->root_valid) {
+                HIPCHK(xfer.d2h(ts[i]->root, ts[i]->d() + 32, 32));   // nodes[1]
+                pending = true;
+            }
         }
+        HIPCHK(xfer.finish());
     }
-    if (pending) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        note_round_trip(ctx);
-    }
+    if (pending) note_round_trip(ctx);
     for (size_t i = 0; i < count; i++) {
         ts[i]->root_valid = true;
         memcpy(roots + 32 * i, ts[i]->root, 32);
@@ -891,8 +899,9 @@ extern "C" int hodor_iop_nodes_h(hodor_iop *t, uint8_t *nodes)
     if (!t || !nodes) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = t->ctx;
     NEED_DEVICE();
-    HIPCHK(hipMemcpyAsync(nodes, t->d(), t->entries * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HostXfer xfer(ctx, ctx->stream);
+    HIPCHK(xfer.d2h(nodes, t->d(), t->entries * 32));
+    HIPCHK(xfer.finish());
     note_round_trip(ctx);
     return HODOR_OK;
 }

@@ -35,11 +35,11 @@ __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n)
 
 // One final-block compression on top of the key-block midstate.  `t` = total bytes incl. the
 // 64-byte key block (96 for a leaf, 128 for a node).
-__device__ __forceinline__ void b2s_final(const B2Mid &mid, const uint32_t m[16], uint32_t t,
+__device__ __forceinline__ void b2s_final(const uint32_t (&h0)[8], const uint32_t m[16], uint32_t t,
                                           uint32_t out[8])
 {
-    uint32_t v0 = mid.h[0], v1 = mid.h[1], v2 = mid.h[2], v3 = mid.h[3];
-    uint32_t v4 = mid.h[4], v5 = mid.h[5], v6 = mid.h[6], v7 = mid.h[7];
+    uint32_t v0 = h0[0], v1 = h0[1], v2 = h0[2], v3 = h0[3];
+    uint32_t v4 = h0[4], v5 = h0[5], v6 = h0[6], v7 = h0[7];
     uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
     uint32_t v12 = 0x510E527Fu ^ t, v13 = 0x9B05688Cu, v14 = ~0x1F83D9ABu, v15 = 0x5BE0CD19u;
     B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
@@ -52,10 +52,10 @@ __device__ __forceinline__ void b2s_final(const B2Mid &mid, const uint32_t m[16]
     B2S_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10);
     B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5);
     B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0);
-    out[0] = mid.h[0] ^ v0 ^ v8;  out[1] = mid.h[1] ^ v1 ^ v9;
-    out[2] = mid.h[2] ^ v2 ^ v10; out[3] = mid.h[3] ^ v3 ^ v11;
-    out[4] = mid.h[4] ^ v4 ^ v12; out[5] = mid.h[5] ^ v5 ^ v13;
-    out[6] = mid.h[6] ^ v6 ^ v14; out[7] = mid.h[7] ^ v7 ^ v15;
+    out[0] = h0[0] ^ v0 ^ v8;  out[1] = h0[1] ^ v1 ^ v9;
+    out[2] = h0[2] ^ v2 ^ v10; out[3] = h0[3] ^ v3 ^ v11;
+    out[4] = h0[4] ^ v4 ^ v12; out[5] = h0[5] ^ v5 ^ v13;
+    out[6] = h0[6] ^ v6 ^ v14; out[7] = h0[7] ^ v7 ^ v15;
 }
 
 // hash of one 32-byte leaf (message words 8..15 are zero and fold away at compile time)
@@ -63,15 +63,16 @@ __device__ __forceinline__ void b2s_leaf(const B2Mid &mid, const uint4 &lo, cons
                                          uint32_t out[8])
 {
     uint32_t m[16] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0, 0, 0, 0, 0, 0, 0, 0};
-    b2s_final(mid, m, 96, out);
+    b2s_final(mid.h, m, 96, out);
 }
 
-// hash of one COSET2 leaf: the 64 bytes of two field elements (one compression, like a node)
+// hash of one COSET2 leaf: the 64 bytes of two field elements — one compression like a node, but on top of the
+// "Shaftoe2" midstate (mid.hp): the two child digests of an interior node never hash to that node as a "leaf"
 __device__ __forceinline__ void b2s_pair(const B2Mid &mid, const uint4 &a0, const uint4 &a1, const uint4 &b0,
                                          const uint4 &b1, uint32_t out[8])
 {
     uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    b2s_final(mid, m, 128, out);
+    b2s_final(mid.hp, m, 128, out);
 }
 
 __device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], const uint32_t r[8],
@@ -80,7 +81,7 @@ __device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], 
     uint32_t m[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) { m[i] = l[i]; m[8 + i] = r[i]; }
-    b2s_final(mid, m, 128, out);
+    b2s_final(mid.h, m, 128, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -95,6 +96,7 @@ __device__ __forceinline__ void b2s_node(const B2Mid &mid, const uint32_t l[8], 
 struct B2Quad {
     uint32_t off[40];                     // byte offset, in use order, of the message words this lane feeds to G
     uint32_t a0, b0, c0, d0_leaf, d0_node;   // this lane's column of the initial state (t = 96 / 128, final block)
+    uint32_t a0p, b0p;                       // rows a, b of the COSET2 leaf midstate (mid.hp)
 };
 
 __device__ __forceinline__ uint32_t b2q_pick(uint32_t j, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
@@ -121,6 +123,8 @@ __device__ __forceinline__ void b2q_init(B2Quad &q, const B2Mid &mid, uint32_t j
     }
     q.a0 = b2q_pick(j, mid.h[0], mid.h[1], mid.h[2], mid.h[3]);
     q.b0 = b2q_pick(j, mid.h[4], mid.h[5], mid.h[6], mid.h[7]);
+    q.a0p = b2q_pick(j, mid.hp[0], mid.hp[1], mid.hp[2], mid.hp[3]);
+    q.b0p = b2q_pick(j, mid.hp[4], mid.hp[5], mid.hp[6], mid.hp[7]);
     q.c0 = b2q_pick(j, 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
     q.d0_leaf = b2q_pick(j, 0x510E527Fu ^ 96u, 0x9B05688Cu, ~0x1F83D9ABu, 0x5BE0CD19u);
     q.d0_node = b2q_pick(j, 0x510E527Fu ^ 128u, 0x9B05688Cu, ~0x1F83D9ABu, 0x5BE0CD19u);
@@ -129,15 +133,19 @@ __device__ __forceinline__ void b2q_init(B2Quad &q, const B2Mid &mid, uint32_t j
 #define B2Q_DPP(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, 0xf, true))
 
 // `msg`: the 64-byte message block in LDS (the same address in the four lanes).  Returns this lane's
-// two digest words: h_lo = word j, h_hi = word 4 + j.
-__device__ __forceinline__ void b2q_compress(const B2Quad &q, const uint32_t *msg, bool node, uint32_t &h_lo,
+// two digest words: h_lo = word j, h_hi = word 4 + j.  kind: B2Q_LEAF (32-byte leaf, t = 96), B2Q_NODE (t = 128),
+// B2Q_PAIR (a COSET2 leaf: t = 128 on the "Shaftoe2" midstate).
+enum { B2Q_LEAF = 0, B2Q_NODE = 1, B2Q_PAIR = 2 };
+__device__ __forceinline__ void b2q_compress(const B2Quad &q, const uint32_t *msg, int kind, uint32_t &h_lo,
                                              uint32_t &h_hi)
 {
+    const bool node = kind != B2Q_LEAF;
+    const uint32_t ia = kind == B2Q_PAIR ? q.a0p : q.a0, ib = kind == B2Q_PAIR ? q.b0p : q.b0;
     uint32_t m[40];
 #pragma unroll
     for (int i = 0; i < 40; i++)
         m[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(msg) + q.off[i]);
-    uint32_t a = q.a0, b = q.b0, c = q.c0, d = node ? q.d0_node : q.d0_leaf;
+    uint32_t a = ia, b = ib, c = q.c0, d = node ? q.d0_node : q.d0_leaf;
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         if (r) {   // back from the diagonal layout: column j's b, c, d sit in lanes j+3, j+2, j+1
@@ -148,8 +156,8 @@ __device__ __forceinline__ void b2q_compress(const B2Quad &q, const uint32_t *ms
         B2S_G(a, b, c, d, m[4 * r + 2], m[4 * r + 3]);
     }
     b = B2Q_DPP(b, 0x93); c = B2Q_DPP(c, 0x4E); d = B2Q_DPP(d, 0x39);
-    h_lo = q.a0 ^ a ^ c;
-    h_hi = q.b0 ^ b ^ d;
+    h_lo = ia ^ a ^ c;
+    h_hi = ib ^ b ^ d;
 }
 
 // interpret_hash (src/iop/blake2s_trivial_iop.rs:48-60): big-endian read of the digest words `d`,

@@ -190,6 +190,17 @@ struct hodor_ctx {
     // device -> host results handed out so far (roots, evaluations, query answers, prototypes, as_ref() copies): every one
     // of them stalls the queue, so a device-resident prover counts them (hodor_ctx_host_round_trips)
     std::atomic<uint64_t> host_round_trips{0};
+    // One pinned host buffer for every SMALL device <-> host transfer of the library (HostXfer below): roots, challenges,
+    // flags, query answers, prototypes' result blocks.  Why (round 5, the root cause of the suite's intermittent SIGABRT,
+    // DESIGN.md §8): an asynchronous copy to or from PAGEABLE host memory makes the runtime pin the pages it touches and
+    // map them into the GPU's address space at the same virtual address; the library used to hand it stack variables and
+    // short-lived std::vectors, i.e. pages of the process heap that the NEXT small buffer of anybody (a torch CPU tensor,
+    // a numpy array) shares.  When the runtime dropped the stale pin of such a page while another copy into the same
+    // page was in flight, the GPU lost the mapping under it: "Memory access fault by GPU ... on address <a heap page>",
+    // abort() on the ROCr event thread.  Memory the library pinned itself, once, shares a page with nobody.
+    void *pinned = nullptr;
+    static constexpr size_t PINNED_BYTES = (size_t)1 << 20;
+    std::mutex pinned_mu;
     std::string err;           // written through set_err() only (entry points run concurrently)
     mutable std::mutex err_mu;
 };
@@ -199,6 +210,70 @@ static inline void set_err(hodor_ctx *ctx, const std::string &msg)
     std::lock_guard<std::mutex> lk(ctx->err_mu);
     ctx->err = msg;
 }
+
+// Small transfers between device and host through the context's own pinned buffer (see hodor_ctx::pinned).  Holds the
+// buffer's mutex for its lifetime; d2h() results are in the caller's memory after finish() (which synchronises `stream`);
+// h2d() copies the caller's bytes into the buffer at once, so stack variables may go out of scope — the buffer itself is
+// not reused before finish().  Transfers that do not fit (> 1 MiB: whole vectors) go straight to / from the caller's
+// memory, which is then an allocation of its own pages and must stay alive until finish().
+class HostXfer {
+  public:
+    HostXfer(hodor_ctx *c, hipStream_t s) : ctx_(c), stream_(s), lk_(c->pinned_mu) {}
+    ~HostXfer() { (void)finish(); }
+    hipError_t d2h(void *host, const void *dev, size_t n)
+    {
+        if (n == 0) return hipSuccess;
+        hipError_t e = room(n);
+        if (e != hipSuccess) return e;
+        if (n > hodor_ctx::PINNED_BYTES) { pending_ = true; return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream_); }
+        items_.push_back(Item{host, used_, n});
+        e = hipMemcpyAsync((uint8_t *)ctx_->pinned + used_, dev, n, hipMemcpyDeviceToHost, stream_);
+        used_ += (n + 63) & ~(size_t)63;
+        pending_ = true;
+        return e;
+    }
+    hipError_t h2d(void *dev, const void *host, size_t n)
+    {
+        if (n == 0) return hipSuccess;
+        hipError_t e = room(n);
+        if (e != hipSuccess) return e;
+        if (n > hodor_ctx::PINNED_BYTES) { pending_ = true; return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream_); }
+        memcpy((uint8_t *)ctx_->pinned + used_, host, n);
+        e = hipMemcpyAsync(dev, (uint8_t *)ctx_->pinned + used_, n, hipMemcpyHostToDevice, stream_);
+        used_ += (n + 63) & ~(size_t)63;
+        pending_ = true;
+        return e;
+    }
+    hipError_t finish()
+    {
+        if (!pending_) return hipSuccess;
+        pending_ = false;
+        hipError_t e = hipStreamSynchronize(stream_);
+        if (e == hipSuccess)
+            for (auto &it : items_) memcpy(it.host, (uint8_t *)ctx_->pinned + it.off, it.n);
+        items_.clear();
+        used_ = 0;
+        return e;
+    }
+
+  private:
+    struct Item { void *host; size_t off, n; };
+    hipError_t room(size_t n)
+    {
+        if (!ctx_->pinned) {
+            hipError_t e = hipHostMalloc(&ctx_->pinned, hodor_ctx::PINNED_BYTES, hipHostMallocDefault);
+            if (e != hipSuccess) { ctx_->pinned = nullptr; return e; }
+        }
+        if (n <= hodor_ctx::PINNED_BYTES && used_ + n > hodor_ctx::PINNED_BYTES) return finish();   // drain, start over at 0
+        return hipSuccess;
+    }
+    hodor_ctx *ctx_;
+    hipStream_t stream_;
+    std::unique_lock<std::mutex> lk_;
+    std::vector<Item> items_;
+    size_t used_ = 0;
+    bool pending_ = false;
+};
 
 struct hodor_fri_proto {
     hodor_ctx *ctx;

@@ -25,7 +25,8 @@ struct Fr {
 
 // BLAKE2s chaining value after the keyed first block (see merkle.hip)
 struct B2Mid {
-    uint32_t h[8];
+    uint32_t h[8];    // chaining value after the key block, personal "Shaftoe": leaves and nodes of the reference's format
+    uint32_t hp[8];   // the same with personal "Shaftoe2": COSET2 LEAVES only (round 5: a 64-byte leaf must not hash like a node)
 };
 
 __device__ __forceinline__ Fr fr_zero()

@@ -133,7 +133,7 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
         if (quad_leafs) {
             if (quad < leaves) {
                 uint32_t lo, hi;
-                b2q_compress(bq, reinterpret_cast<const uint32_t *>(buf_m + 4 * quad), COMB, lo, hi);
+                b2q_compress(bq, reinterpret_cast<const uint32_t *>(buf_m + 4 * quad), COMB ? B2Q_PAIR : B2Q_LEAF, lo, hi);
                 uint32_t *o = reinterpret_cast<uint32_t *>(buf_a + 2 * quad);
                 o[j] = lo; o[4 + j] = hi;
             }
@@ -152,7 +152,7 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
             if (w <= QUADS) {
                 if (quad < w) {
                     uint32_t lo, hi;
-                    b2q_compress(bq, reinterpret_cast<const uint32_t *>(s + 4 * quad), true, lo, hi);
+                    b2q_compress(bq, reinterpret_cast<const uint32_t *>(s + 4 * quad), B2Q_NODE, lo, hi);
                     uint32_t *o = reinterpret_cast<uint32_t *>(d + 2 * quad);
                     o[j] = lo; o[4 + j] = hi;
                     uint32_t *g = reinterpret_cast<uint32_t *>(nodes + 2 * (w + quad));

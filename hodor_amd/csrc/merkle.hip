@@ -168,7 +168,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
             const uint32_t quad = tid >> 2, j = tid & 3;
             if (quad < w) {
                 uint32_t lo, hi;
-                b2q_compress(bq, reinterpret_cast<const uint32_t *>(src + 4 * quad), true, lo, hi);
+                b2q_compress(bq, reinterpret_cast<const uint32_t *>(src + 4 * quad), B2Q_NODE, lo, hi);
                 uint32_t *o = reinterpret_cast<uint32_t *>(dst + 2 * quad);
                 o[j] = lo; o[4 + j] = hi;
                 uint32_t *g = reinterpret_cast<uint32_t *>(lvl_out + 2 * quad);

@@ -57,7 +57,9 @@ typedef struct {
  * points does not bump it).  A caller built against another revision must not call into the library: check once.
  *   4  hodor_fri_verify_proof_strict(_combined) take expected_lde_factor and expected_output_coeffs_at_degree_plus_one
  *      BEFORE natural_element_index (round 4; the round-3 form had five value arguments)
- *   5  hodor_iop_verify_combined (COSET2) refuses paths of any length but log2(n) - 1 and non-canonical values;
+ *   5  COSET2 leaves hash under the personalisation "Shaftoe2" (trees, paths and proofs of rounds 3-4 in that opt-in
+ *      format do not verify any more; the reference's format is untouched); hodor_iop_verify_combined (COSET2) refuses
+ *      paths of any length but log2(n) - 1 and non-canonical values;
  *      receive buffers of the direct transports are the library's (hodor_exchange_direct_alloc_recv) */
 #define HODOR_ABI_VERSION 5
 int  hodor_abi_version(void);
@@ -146,7 +148,9 @@ int hodor_iop_verify(const hodor_ctx *ctx, const uint8_t root[32], const hodor_f
  * together (src/fri/query_producer.rs:27-34), so HODOR_COMBINER_COSET2 — an opt-in format DEFINED BY THIS BUILD —
  * commits them as ONE leaf:
  *     natural index i of n values  <->  tree element t = 2 (i mod n/2) + (i div n/2)   (natural_index_into_tree_index)
- *     leaf k (k < n/2) = the 64 bytes value[k] || value[k + n/2], hashed with ONE keyed BLAKE2s call
+ *     leaf k (k < n/2) = the 64 bytes value[k] || value[k + n/2], hashed with ONE keyed BLAKE2s call under a
+ *                        personalisation of its own ("Shaftoe2"; nodes and the reference's leaves: "Shaftoe") — the
+ *                        children of an interior node can therefore never be opened as a "value pair" (round 5)
  *     nodes = heap array of the tree over those n/2 leaves: (n/2) x 32 bytes, root = nodes[32..64]
  *     path  = log2(n) - 1 digests; a query returns both values of the coset
  * -> n compressions per tree instead of 2n, one path per FRI round instead of two.  n >= 4.  Every entry point

@@ -1055,7 +1055,9 @@ void o_hash_leaf_pair(uint8_t out[32], const ofr *lo, const ofr *hi)
             enc[8 * i + b] = (uint8_t)(lo->l[i] >> (8 * b));        /* encode_leaf :36-42, twice */
             enc[32 + 8 * i + b] = (uint8_t)(hi->l[i] >> (8 * b));
         }
-    o_blake2s(out, IOP_KEY, 19, IOP_PERSONAL, 7, enc, 64);
+    /* a personalisation of its own ("Shaftoe2"): a COSET2 leaf is 64 bytes like the input of a node hash, and the two
+     * must never collide (an interior node's children opened as a "value pair") */
+    o_blake2s(out, IOP_KEY, 19, (const uint8_t *)"Shaftoe2", 8, enc, 64);
 }
 
 typedef struct { const ofr *values; size_t half; uint8_t *lh; } pairh_ctx;

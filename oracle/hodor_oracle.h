@@ -122,7 +122,8 @@ int  o_iop_verify(const uint8_t root[32], const ofr *leaf, const uint8_t *path, 
  * BUILD (the reference has none to be compared with):
  *   natural index i of n values  <->  tree element index t = 2 (i mod n/2) + (i div n/2)   (natural_index_into_tree_index)
  *   leaf k (k < n/2) = the 64 bytes  value[k] || value[k + n/2]  — the coset FRI opens together
- *   (get_coset_for_natural_index :29-35, src/fri/query_producer.rs:27-34), hashed with ONE keyed BLAKE2s call;
+ *   (get_coset_for_natural_index :29-35, src/fri/query_producer.rs:27-34), hashed with ONE keyed BLAKE2s call under
+ *   the personalisation "Shaftoe2" (never equal to a node hash of the same 64 bytes);
  *   nodes: the heap array of a tree over n/2 leaves, (n/2) x 32 bytes, root nodes[1]; path: log2(n) - 1 digests.
  * n >= 4 (at least two leaves). */
 enum { O_COMBINER_TRIVIAL = 0, O_COMBINER_COSET2 = 1 };

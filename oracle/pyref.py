@@ -221,8 +221,12 @@ def coset2_tree_to_natural(t, n):
     return (t >> 1) + (t & 1) * (n // 2)
 
 
+COSET2_LEAF_PERSONAL = b"Shaftoe2"     # COSET2 leaves hash under their own personalisation: never equal to a node hash
+
+
 def hash_leaf_pair(lo_mont, hi_mont):
-    return b2s(mont_to_bytes(lo_mont) + mont_to_bytes(hi_mont))
+    return hashlib.blake2s(mont_to_bytes(lo_mont) + mont_to_bytes(hi_mont), digest_size=32, key=IOP_KEY,
+                           person=COSET2_LEAF_PERSONAL).digest()
 
 
 def iop_create_coset2(values_mont):

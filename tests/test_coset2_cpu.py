@@ -154,10 +154,11 @@ def test_coset2_verifiers_refuse_tampered_and_truncated_proofs():
 
 
 def test_coset2_opening_binds_the_depth_and_canonical_values():
-    """A COSET2 leaf compresses like an interior node (64 bytes, t = 128), so only its depth tells the two apart: the
-    two child digests of an interior node, presented as a "coset value pair" with the path shortened by one level,
-    hash their way to the root — hodor_iop_verify_combined must refuse every path whose length is not log2(n) - 1
-    (round-4 advisor finding), and values that are not canonical residues."""
+    """A COSET2 leaf is 64 bytes like the input of a node hash.  Round-4 advisor finding: with ONE hash for both, the two
+    child digests of an interior node, presented as a "coset value pair" with a shortened path, hash their way to the
+    root.  Two independent protections since round 5: COSET2 leaves hash under a personalisation of their own
+    ("Shaftoe2": the forged "leaf" no longer equals the node), and hodor_iop_verify_combined refuses every path whose
+    length is not log2(n) - 1 and values that are not canonical residues."""
     F = P.BN256
     ctx = hodor_amd.Context(F.p, F.g, device=-1)
     n = 64
@@ -176,14 +177,16 @@ def test_coset2_opening_binds_the_depth_and_canonical_values():
         short_path.append(nodes[idx ^ 1])
         idx >>= 1
     assert len(short_path) == len(honest) - 2
-    # the walk itself reaches the root (the point of the finding) ...
-    h = P.hash_node(left, right)
-    k = j
-    for sib in short_path:
-        h = P.hash_node(h, sib) if k % 2 == 0 else P.hash_node(sib, h)
-        k >>= 1
-    assert h == root
-    # ... and the library refuses it: wrong depth (and, for most digests, non-canonical "values")
+    def walk(h):
+        k = j
+        for sib in short_path:
+            h = P.hash_node(h, sib) if k % 2 == 0 else P.hash_node(sib, h)
+            k >>= 1
+        return h
+    assert walk(P.hash_node(left, right)) == root                      # with the NODE hash the walk reaches the root ...
+    assert P.hash_leaf_pair(*as_values) != P.hash_node(left, right)    # ... which a COSET2 leaf hash never is
+    assert walk(P.hash_leaf_pair(*as_values)) != root
+    # and the library refuses the opening on its shape alone: wrong depth (and, for most digests, non-canonical "values")
     assert ctx.iop_verify_combined(root, as_values, short_path, j, n, C2) is False
     assert ctx.iop_verify_combined(root, [vals[5], vals[5 + n // 2]], honest[:-1], 5, n, C2) is False
     assert ctx.iop_verify_combined(root, [vals[5], vals[5 + n // 2]], honest + [bytes(32)], 5, n, C2) is False
