@@ -2,7 +2,7 @@
 // concurrent caller threads on ONE context, as the reference calls best_fft from one scoped thread per register
 // (/root/reference/src/arp/per_register/mod.rs:43-49).  Compiled code, no interpreter in the loop.
 //   g++ -O2 -std=c++17 -pthread bench/slice_threads.cpp -Lhodor_amd -lhodor_gpu -Wl,-rpath,$PWD/hodor_amd -o /tmp/slice_threads
-//   /tmp/slice_threads [reps=8] [pinned=0]
+//   /tmp/slice_threads [reps=8] [pinned=0] [only_log_n=0] [only_threads=0]      (HODOR_SLICE_TRACE=1: the library prints each call's phases)
 // Prints, per size and thread count: wall time per transform (all threads together), the aggregate rate, and the ratio to
 // N x the single-caller rate.  A transform moves n*32 bytes up and n*32 bytes down; the link gives ~57 GB/s per direction.
 #include <chrono>
@@ -21,13 +21,17 @@ int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 8;
     const bool pinned = argc > 2 && atoi(argv[2]) != 0;
+    const unsigned only_log = argc > 3 ? atoi(argv[3]) : 0;
+    const int only_threads = argc > 4 ? atoi(argv[4]) : 0;
     hodor_ctx *ctx = nullptr;
     if (hodor_ctx_create(MODULUS, 7, 0, &ctx)) { fprintf(stderr, "no context\n"); return 1; }
     printf("slice API, %s host memory, %d transforms per thread; knobs: [%s]\n", pinned ? "registered (pinned)" : "pageable", reps, hodor_knobs_set());
     for (unsigned log_n : {20u, 22u, 24u}) {
+        if (only_log && log_n != only_log) continue;
         const size_t n = (size_t)1 << log_n;
         double single = 0;
         for (int threads : {1, 2, 3, 4, 6}) {
+            if (only_threads && threads != 1 && threads != only_threads) continue;
             std::vector<std::vector<hodor_fr>> bufs(threads);
             std::mt19937_64 rng(log_n * 100 + threads);
             for (auto &b : bufs) {

@@ -2,6 +2,8 @@
 // C entry points that stand where the reference's L2/L3 Rust functions stand.  No CPU fallback: a
 // context without a device refuses every compute call with HODOR_ERR_DEVICE.
 #include "ctx.hpp"
+#include <chrono>
+#include <cstdio>
 
 namespace hodor {
 
@@ -1032,10 +1034,26 @@ extern "C" int hodor_iop_create_dev(hodor_ctx *ctx, void *stream, const hodor_fr
 // compute stream is serialised (twiddle caches and pass scratch are shared).  Events chain
 // upload -> compute -> download, so with several threads inside the library the PCIe link is busy in
 // both directions while the kernels of a third caller run.  `separate_out`: `op` may not work in place.
+// HODOR_SLICE_TRACE=1 (debugging aid of bench/slice_threads.cpp, never set in production): one line per call on stderr with
+// the call's phase boundaries in microseconds since the first traced call.
+static bool slice_trace_on()
+{
+    static const bool on = [] { const char *e = getenv("HODOR_SLICE_TRACE"); return e && *e && *e != '0'; }();
+    return on;
+}
+static double slice_trace_us()
+{
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
 template <class Op>
 static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *out, size_t n_out, Op op,
                             bool separate_out = false)
 {
+    const bool trace = slice_trace_on();
+    double tr[8] = {0};
+    if (trace) tr[0] = slice_trace_us();
     hodor_ctx::IoLane *L = lane_acquire(ctx);
     auto fail = [&](hipError_t e, const char *what) {
         (void)hipStreamSynchronize(L->stream);
@@ -1057,6 +1075,7 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
     {
         std::unique_lock<std::mutex> up(ctx->up_mu, std::defer_lock);
         if (serial) up.lock();
+        if (trace) tr[1] = slice_trace_us();
         const bool small_in = n_in * 32 <= hodor_ctx::PINNED_BYTES;   // small slices go through the context's pinned buffer
         if (small_in) {
             HostXfer xfer(ctx, L->stream);
@@ -1066,10 +1085,12 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             (e = hipEventRecord(L->uploaded, L->stream)) != hipSuccess ||
             (serial && (e = hipStreamSynchronize(L->stream)) != hipSuccess))   // the link is free for the next upload
             return fail(e, "slice upload");
+        if (trace) tr[2] = slice_trace_us();
     }
     int rc;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
+        if (trace) tr[3] = slice_trace_us();
         e = hipStreamWaitEvent(ctx->stream, L->uploaded, 0);
         rc = e == hipSuccess ? op((const uint4 *)din, (uint4 *)dptr_out) : HODOR_ERR_DEVICE;
         if (e == hipSuccess) e = hipEventRecord(L->computed, ctx->stream);
@@ -1081,8 +1102,10 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         std::unique_lock<std::mutex> down(ctx->down_mu, std::defer_lock);
         if (serial) {
             if ((e = hipEventSynchronize(L->computed)) != hipSuccess) return fail(e, "slice compute");   // wait OUTSIDE the lock
+            if (trace) tr[4] = slice_trace_us();
             down.lock();
         }
+        if (trace) tr[5] = slice_trace_us();
         if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess) return fail(e, "slice download");
         if (n_out * 32 <= hodor_ctx::PINNED_BYTES) {
             HostXfer xfer(ctx, L->stream);
@@ -1091,7 +1114,11 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         } else if ((e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
                    (e = hipStreamSynchronize(L->stream)) != hipSuccess)
             return fail(e, "slice download");
+        if (trace) tr[6] = slice_trace_us();
     }
+    if (trace)
+        fprintf(stderr, "slice lane %d n=%zu: enter %.0f  up [%.0f %.0f]  op enq %.0f  computed %.0f  down [%.0f %.0f] us\n",
+                (int)(L - &ctx->lanes[0]), n_in, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6]);
     lane_release(ctx, L);
     return HODOR_OK;
 }
