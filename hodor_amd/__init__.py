@@ -4,9 +4,9 @@ The product is `libhodor_gpu.so` (hand-written HIP kernels for gfx950 behind the
 include/hodor_gpu.h).  This package is only the thin ctypes binding the tests and bench.py use; it
 has no CPU fallback and fails loudly when the library is missing.
 """
-from ._lib import (BN256_FR_GENERATOR, BN256_FR_MODULUS, COSET2, EXPERIMENTS_FR_GENERATOR, TRIVIAL,
+from ._lib import (BN256_FR_GENERATOR, BN256_FR_MODULUS, COSET2, ERR_DEVICE, ERR_INVALID, ERR_SIZE, EXPERIMENTS_FR_GENERATOR, OK, TRIVIAL,
                    EXPERIMENTS_FR_MODULUS, Context, DirectExchange, Exchange, FriPrototype, HodorError, build, lib, lib_path)
 
 __all__ = ["Context", "DirectExchange", "Exchange", "FriPrototype", "HodorError", "build", "lib", "lib_path",
            "BN256_FR_MODULUS", "BN256_FR_GENERATOR", "EXPERIMENTS_FR_MODULUS",
-           "EXPERIMENTS_FR_GENERATOR", "TRIVIAL", "COSET2"]
+           "EXPERIMENTS_FR_GENERATOR", "TRIVIAL", "COSET2", "OK", "ERR_SIZE", "ERR_INVALID", "ERR_DEVICE"]
