@@ -227,6 +227,37 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
     return hipSuccess;
 }
 
+// The two direction streams of the slice API (ctx.hpp).  Bound to their copy engines here, once: a train of small uploads is
+// put in flight on the upload stream and the download stream's first copy is submitted while they run, so that the
+// runtime finds the upload's engine busy and gives the download another one.
+static hipError_t dir_streams_prepare(hodor_ctx *ctx)
+{
+    std::call_once(ctx->dir_once, [ctx] {
+        hipError_t &e = ctx->dir_err;
+        void *scratch = nullptr;
+        const size_t half = hodor_ctx::PINNED_BYTES / 2;
+        if ((e = hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking)) != hipSuccess) return;
+        if ((e = hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking)) != hipSuccess) return;
+        if ((e = hipMalloc(&scratch, hodor_ctx::PINNED_BYTES)) != hipSuccess) return;
+        {
+            std::lock_guard<std::mutex> lk(ctx->pinned_mu);
+            if (!ctx->pinned && (e = hipHostMalloc(&ctx->pinned, hodor_ctx::PINNED_BYTES, hipHostMallocDefault)) != hipSuccess) {
+                ctx->pinned = nullptr;
+                (void)hipFree(scratch);
+                return;
+            }
+            for (int i = 0; i < 256 && e == hipSuccess; i++)
+                e = hipMemcpyAsync(scratch, ctx->pinned, half, hipMemcpyHostToDevice, ctx->up_stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync((char *)ctx->pinned + half, (char *)scratch + half, half, hipMemcpyDeviceToHost, ctx->down_stream);
+            hipError_t e1 = hipStreamSynchronize(ctx->up_stream), e2 = hipStreamSynchronize(ctx->down_stream);
+            if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+        }
+        (void)hipFree(scratch);
+    });
+    return ctx->dir_err;
+}
+
 // Caller holds ctx->mu.  `user`: the stream whose work is about to use the pool.  Every call that uses the pool
 // ends by recording ctx->scratch_ev on its own stream (ScratchUse below) — while that stream is certainly alive —
 // and the next user, if it runs on a different stream, waits for that event: calls on different streams are
@@ -544,6 +575,8 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
             if (L.computed) (void)hipEventDestroy(L.computed);
             if (L.stream) (void)hipStreamDestroy(L.stream);
         }
+        if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
+        if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
@@ -1055,8 +1088,11 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
     double tr[8] = {0};
     if (trace) tr[0] = slice_trace_us();
     hodor_ctx::IoLane *L = lane_acquire(ctx);
+    const bool serial = knobs().slice_serial != 0;
+    hipStream_t us = nullptr, ds = nullptr;      // the streams this call uploads and downloads on
     auto fail = [&](hipError_t e, const char *what) {
-        (void)hipStreamSynchronize(L->stream);
+        if (us) (void)hipStreamSynchronize(us);
+        if (ds && ds != us) (void)hipStreamSynchronize(ds);
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
             set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
@@ -1071,19 +1107,21 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         if ((e = lane_prepare(L, 1, (n_out ? n_out : 1) * 32)) != hipSuccess) return fail(e, "slice staging (out)");
         dptr_out = L->buf[1];
     }
-    const bool serial = knobs().slice_serial != 0;
+    if (serial && (e = dir_streams_prepare(ctx)) != hipSuccess) return fail(e, "slice streams");
+    us = serial ? ctx->up_stream : L->stream;
+    ds = serial ? ctx->down_stream : L->stream;
     {
         std::unique_lock<std::mutex> up(ctx->up_mu, std::defer_lock);
         if (serial) up.lock();
         if (trace) tr[1] = slice_trace_us();
         const bool small_in = n_in * 32 <= hodor_ctx::PINNED_BYTES;   // small slices go through the context's pinned buffer
         if (small_in) {
-            HostXfer xfer(ctx, L->stream);
+            HostXfer xfer(ctx, us);
             if ((e = xfer.h2d(din, in, n_in * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess) return fail(e, "slice upload");
         }
-        if ((!small_in && (e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, L->stream)) != hipSuccess) ||
-            (e = hipEventRecord(L->uploaded, L->stream)) != hipSuccess ||
-            (serial && (e = hipStreamSynchronize(L->stream)) != hipSuccess))   // the link is free for the next upload
+        if ((!small_in && (e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, us)) != hipSuccess) ||
+            (e = hipEventRecord(L->uploaded, us)) != hipSuccess ||
+            (serial && (e = hipStreamSynchronize(us)) != hipSuccess))   // the link is free for the next upload
             return fail(e, "slice upload");
         if (trace) tr[2] = slice_trace_us();
     }
@@ -1096,7 +1134,7 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         if (e == hipSuccess) e = hipEventRecord(L->computed, ctx->stream);
         if (rc || e != hipSuccess) (void)hipStreamSynchronize(ctx->stream);
     }
-    if (rc) { (void)hipStreamSynchronize(L->stream); lane_release(ctx, L); return rc; }
+    if (rc) { (void)hipStreamSynchronize(us); lane_release(ctx, L); return rc; }
     if (e != hipSuccess) return fail(e, "slice compute");
     {
         std::unique_lock<std::mutex> down(ctx->down_mu, std::defer_lock);
@@ -1106,13 +1144,13 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             down.lock();
         }
         if (trace) tr[5] = slice_trace_us();
-        if ((e = hipStreamWaitEvent(L->stream, L->computed, 0)) != hipSuccess) return fail(e, "slice download");
+        if ((e = hipStreamWaitEvent(ds, L->computed, 0)) != hipSuccess) return fail(e, "slice download");
         if (n_out * 32 <= hodor_ctx::PINNED_BYTES) {
-            HostXfer xfer(ctx, L->stream);
+            HostXfer xfer(ctx, ds);
             if ((e = xfer.d2h(out, dptr_out, n_out * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess)
                 return fail(e, "slice download");
-        } else if ((e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, L->stream)) != hipSuccess ||
-                   (e = hipStreamSynchronize(L->stream)) != hipSuccess)
+        } else if ((e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ds)) != hipSuccess ||
+                   (e = hipStreamSynchronize(ds)) != hipSuccess)
             return fail(e, "slice download");
         if (trace) tr[6] = slice_trace_us();
     }

@@ -173,6 +173,15 @@ struct hodor_ctx {
     // OPPOSITE directions overlap.  With these two mutexes N concurrent callers form a clean three-stage pipeline
     // (upload | kernels | download) whose throughput is the slower direction's.
     std::mutex up_mu, down_mu;
+    // ...and each direction has its OWN stream (abi.hip: dir_streams_prepare).  The HIP runtime binds a copy engine to a
+    // (stream, direction) pair the first time the pair is used — the lowest-numbered engine idle at that moment — and keeps
+    // the binding.  Lanes that copy both ways on their own stream therefore tend to end up all on engine 0 (the first
+    // upload and the first download of a lane both find it idle), and then an upload and a download "in parallel" share one
+    // engine: measured, 17-19 ms each instead of 9.6 (profiles/r05/slice_trace.txt).  One stream that only ever uploads and
+    // one that only ever downloads, bound while the other is busy, get two engines.
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::once_flag dir_once;
+    hipError_t dir_err = hipSuccess;
     std::atomic<int> live_exchanges{0};   // hodor_exchange handles that point at this context (abi_exchange.hip)
     std::atomic<int> live_handles{0};     // hodor_poly / hodor_iop / hodor_fri_proto objects whose memory is this context's pool
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X

@@ -44,15 +44,23 @@ def test_from_coeffs_pads_and_caches_the_domain(gpu_ctxs, oracles, field_name, l
 
 
 def test_beyond_the_two_adicity_is_an_error(gpu_ctxs):
-    """Domain::new_for_size's Err (src/domains/mod.rs:30-32): the experiments field has S = 10"""
-    ctx = gpu_ctxs["experiments"]
-    assert ctx.S == 10
-    ok = Polynomial.new_for_size(ctx, COEFFICIENTS, 1 << 10)
-    assert ok.size() == 1 << 10
-    ok.free()
+    """Domain::new_for_size's Err (src/domains/mod.rs:30-32): bn254's scalar field has S = 28; refused before anything is
+    allocated"""
+    ctx = gpu_ctxs["bn254"]
+    assert ctx.S == 28
+    _, live0 = ctx.pool_stats()
     with pytest.raises(hodor_amd.HodorError) as e:
-        Polynomial.new_for_size(ctx, COEFFICIENTS, (1 << 10) + 1)
+        Polynomial.new_for_size(ctx, COEFFICIENTS, (1 << 28) + 1)
     assert e.value.code == hodor_amd.ERR_SIZE
+    p = Polynomial.new_for_size(ctx, COEFFICIENTS, 1 << 10)
+    for call in (lambda: p.lde(1 << 19), lambda: p.coset_lde(1 << 19), lambda: Polynomial.lde_all([p, p], 1 << 19),
+                 lambda: p.pad_by_factor(1 << 19), lambda: p.pad_to_size(1 << 29)):
+        with pytest.raises(hodor_amd.HodorError) as e:
+            call()
+        assert e.value.code == hodor_amd.ERR_SIZE
+    assert p.size() == 1 << 10
+    p.free()
+    assert ctx.pool_stats()[1] == live0
 
 
 def test_read_write_elem_op_clone_equal(gpu_ctxs, oracles, field_name):
@@ -143,15 +151,18 @@ def test_lde_matches_oracle(gpu_ctxs, oracles, log_n, factor):
         p.free()
 
 
-def test_lde_on_the_small_field(gpu_ctxs, oracles):
-    ctx, O = gpu_ctxs["experiments"], oracles["experiments"]
-    a = O.random_elements(64, 3)
+def test_lde_on_the_other_fields(gpu_ctxs, oracles, field_name):
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    a = O.random_elements(100, 3)                               # padded to 128 coefficients
     p = Polynomial.from_coeffs(ctx, a)
-    out = p.lde(16)
-    assert np.array_equal(out.as_ref(), O.poly_lde(a, 16))
-    with pytest.raises(hodor_amd.HodorError):                  # 2^6 * 32 = 2^11 > 2^S
-        p.lde(32)
-    out.free()
+    padded = np.zeros((128, 4), dtype=np.uint64)
+    padded[:100] = a
+    for coset in (False, True):
+        out = p.lde(16, coset=coset)
+        assert np.array_equal(out.as_ref(), O.poly_lde(padded, 16, coset=coset))
+        out.free()
+    with pytest.raises(hodor_amd.HodorError):                   # assert!(factor.is_power_of_two()) :434
+        p.lde(12)
     p.free()
 
 
@@ -387,14 +398,17 @@ def test_fri_commit_on_a_handle_matches_oracle(gpu_ctxs, oracles, log_deg, lde_f
         t.free()
         vals.free()
     n = lde.size()
-    for idx in (0, 3, n // 2 + 1, n - 1):
+    for idx in (1, 3, n // 2 + 1, n - 1):
         assert got.verify_prototype(idx)
+    with pytest.raises(hodor_amd.HodorError) as e:                  # x^(n/2) == 1: "not in the LDE domain" (src/fri/verifier.rs:28-36)
+        got.verify_prototype(2)
+    assert e.value.code == hodor_amd.ERR_INVALID
     got.free()
     lde.free()
     p.free()
 
 
-@pytest.mark.parametrize("log_deg,lde_factor,index", [(3, 4, 7), (5, 4, 70), (5, 8, 255)])
+@pytest.mark.parametrize("log_deg,lde_factor,index", [(3, 4, 7), (5, 4, 71), (5, 8, 255)])
 def test_fri_proof_from_a_handle_matches_restated_query_producer(gpu_ctxs, log_deg, lde_factor, index):
     """produce_proof (src/fri/query_producer.rs:10-53) from device-resident values and trees: the bytes of the Python
     restatement, which the restated verifier accepts (src/fri/verifier.rs:131-289)"""
