@@ -214,6 +214,11 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
     for (auto &r : x->own_recv)
         if (r) (void)hipFree(r);
     if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+    for (uint32_t t = 0; t < HODOR_EXCHANGE_MAX_RANKS; t++) {
+        if (x->peer_done[t]) (void)hipEventDestroy(x->peer_done[t]);
+        if (x->peer_stream[t]) (void)hipStreamDestroy(x->peer_stream[t]);
+    }
+    if (x->gate) (void)hipEventDestroy(x->gate);
     if (x->owns_comm && x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
     if (x->ready) (void)hipEventDestroy(x->ready);
     for (uint64_t i = 0; i < hodor_exchange::RING; i++)
@@ -583,7 +588,8 @@ extern "C" int hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream
 
 // Copy-engine transport: the chunked schedule's send pieces (hodor_sixstep_columns_dev / _rows_dev into a LOCAL send
 // buffer, exactly as for hodor_sixstep_exchange_dev) moved into the peers' mapped receive buffers by P device-to-device
-// copies per chunk on the handle's own stream — between devices the runtime runs those on the SDMA engines, so the
+// copies per chunk, each on the stream of its destination (one copy engine / link per peer, all P at once; the handle's
+// own stream gates them and collects them) — between devices the runtime runs those on the SDMA engines, so the
 // exchange takes no CU from the VALU-bound transforms and, unlike the direct stores, is spread over whatever the caller
 // enqueues next.  Slab t of the piece lands in rank t's buffer where an all-to-all would put it (piece `chunk`, slab
 // `rank`).  Chunk 0 first waits until every peer has released the slot; the last chunk is followed by the `arrived`
@@ -617,11 +623,21 @@ extern "C" int hodor_exchange_direct_copy_dev(hodor_exchange *x, void *stream, u
         return HODOR_ERR_INVALID;
     }
     const uint8_t *src = (const uint8_t *)(send + (size_t)chunk * piece);
+    if (!x->gate) HIPCHK(hipEventCreateWithFlags(&x->gate, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(x->gate, x->comm_stream));                // the chunk exists and the receivers have let go of the slot
     for (uint32_t i = 0; i < x->n_ranks; i++) {
         const uint32_t t = (x->rank + 1 + i) % x->n_ranks;          // start with the neighbour: the ranks' copies fan out over the links
+        if (!x->peer_stream[t]) {
+            HIPCHK(hipStreamCreateWithFlags(&x->peer_stream[t], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&x->peer_done[t], hipEventDisableTiming));
+        }
         uint8_t *dst = (uint8_t *)(uintptr_t)x->slots[slot].h_tab[t] + ((size_t)chunk * piece + (size_t)x->rank * slab) * 32;
-        HIPCHK(hipMemcpyAsync(dst, src + (size_t)t * slab * 32, slab * 32, hipMemcpyDeviceToDevice, x->comm_stream));
+        HIPCHK(hipStreamWaitEvent(x->peer_stream[t], x->gate, 0));
+        HIPCHK(hipMemcpyAsync(dst, src + (size_t)t * slab * 32, slab * 32, hipMemcpyDeviceToDevice, x->peer_stream[t]));
+        HIPCHK(hipEventRecord(x->peer_done[t], x->peer_stream[t]));
     }
+    for (uint32_t t = 0; t < x->n_ranks; t++)                       // comm_stream: after every copy of this chunk
+        HIPCHK(hipStreamWaitEvent(x->comm_stream, x->peer_done[t], 0));
     if (chunk + 1 == (1u << log_chunks)) return direct_write(x, x->comm_stream, slot, 0, x->slots[slot].produced);
     return HODOR_OK;
 }

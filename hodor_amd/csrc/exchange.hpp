@@ -30,6 +30,12 @@ struct hodor_exchange {
     uint32_t *my_flags = nullptr;           // this rank's flag block: per slot { arrived[n_ranks], released[n_ranks] }
     uint32_t *peer_flags[HODOR_EXCHANGE_MAX_RANKS] = {};   // every rank's flag block as mapped HERE (own one included)
     uint32_t *d_err = nullptr;              // pinned host word (device-visible): set by a flag wait that timed out
+    // copy-engine transport: one stream per destination, so that the copies to the seven peers run on seven engines /
+    // links at once instead of one after the other on comm_stream (created at the first copy; `gate` is recorded on
+    // comm_stream once the generation may be written, peer_done[t] after the copy to rank t)
+    hipStream_t peer_stream[HODOR_EXCHANGE_MAX_RANKS] = {};
+    hipEvent_t peer_done[HODOR_EXCHANGE_MAX_RANKS] = {};
+    hipEvent_t gate = nullptr;
     uint32_t next_slot = 0;                 // abi_dist.hip: slots are claimed round robin
     void *own_recv[16] = {};                // receive buffers the library allocated itself (hodor_exchange_direct_alloc_recv)
     size_t own_recv_bytes = 0;

@@ -457,6 +457,48 @@ def test_a_commit_chain_crosses_pcie_once(gpu_ctxs, oracles):
     p.free()
 
 
+def test_handles_of_one_context_from_several_threads(gpu_ctxs, oracles):
+    """The reference works on its registers from one scoped thread each (src/arp/per_register/mod.rs:43-49,
+    src/polynomials/mod.rs:446-460): different handles of ONE context used from different threads at once — their work
+    is serialised on the context's stream, the pool hands blocks from thread to thread — every result the oracle's."""
+    import threading
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n, factor, threads, rounds = 1 << 12, 8, 4, 6
+    regs = [O.random_elements(n, 500 + t) for t in range(threads)]
+    z = _int(O.random_elements(1, 499)[0])
+    want = []
+    for r in regs:
+        lde = O.poly_lde(r, factor)
+        sq = lde.copy()
+        O.poly_unary(sq, "square")
+        want.append((bytes(O.iop_create(lde)[1]), bytes(O.iop_create(sq)[1]), O.evaluate_at(r, z)))
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(rounds):
+                p = Polynomial.from_coeffs(ctx, regs[t])
+                lde = p.lde(factor)
+                tree = IopTree.create(lde)
+                sq = lde.clone()
+                sq.square()
+                tree2 = IopTree.create(sq)
+                got = (tree.get_root(), tree2.get_root(), p.evaluate_at(z))
+                if got != want[t]:
+                    errors.append("thread %d: wrong result" % t)
+                for x in (tree, tree2, sq, lde, p):
+                    x.free()
+        except Exception as exc:                                  # noqa: BLE001 — reported below
+            errors.append("thread %d: %r" % (t, exc))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_context_refuses_to_die_under_live_handles(oracles):
     """hodor_ctx_try_destroy: HODOR_ERR_INVALID while a handle of the context is alive"""
     import ctypes as C
