@@ -84,3 +84,11 @@ if fetch_kb and write_kb:
     print("pmc_traffic.json:", json.dumps(doc))
 PY
 cat $OUT/summary.txt
+# the raw per-dispatch tables are tens of MiB (gpurun merges at most 64 MiB back): keep the per-kernel statistics, the
+# summary and pmc_traffic.json unless KEEP_RAW=1
+if [ "${KEEP_RAW:-0}" != "1" ]; then
+  find $OUT -name '*kernel_trace.csv' -delete
+  find $OUT -name '*counter_collection.csv' -delete
+  find $OUT -name '*agent_info.csv' -delete
+fi
+du -sh $OUT

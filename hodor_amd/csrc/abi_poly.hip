@@ -19,7 +19,7 @@ static size_t pool_round(size_t bytes)
 
 void pool_drain(hodor_ctx *ctx)
 {
-    std::multimap<size_t, void *> blocks;
+    std::multimap<size_t, hodor_ctx::PoolBlock> blocks;
     {
         std::lock_guard<std::mutex> lk(ctx->pool_mu);
         blocks.swap(ctx->pool_free);
@@ -27,7 +27,7 @@ void pool_drain(hodor_ctx *ctx)
     }
     if (blocks.empty()) return;
     (void)hipDeviceSynchronize();
-    for (auto &b : blocks) (void)hipFree(b.second);
+    for (auto &b : blocks) (void)hipFree(b.second.p);
 }
 
 int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got)
@@ -37,7 +37,7 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got)
         std::lock_guard<std::mutex> lk(ctx->pool_mu);
         auto it = ctx->pool_free.lower_bound(want);
         if (it != ctx->pool_free.end() && it->first <= 2 * want) {
-            *out = it->second;
+            *out = it->second.p;
             *got = it->first;
             ctx->pool_cached -= it->first;
             ctx->pool_live += it->first;
@@ -69,15 +69,22 @@ void pool_release(hodor_ctx *ctx, void *p, size_t bytes)
     {
         std::lock_guard<std::mutex> lk(ctx->pool_mu);
         ctx->pool_live -= bytes;
-        ctx->pool_free.emplace(bytes, p);
+        ctx->pool_free.emplace(bytes, hodor_ctx::PoolBlock{p, ++ctx->pool_seq});
         ctx->pool_cached += bytes;
-        // over the cap: the largest idle blocks go back to HIP (a process that has walked through many sizes — a test
-        // suite — must not sit on all of them; a prover repeating one shape never gets here)
-        while (ctx->pool_cached > ctx->pool_cache_cap && !ctx->pool_free.empty()) {
-            auto it = std::prev(ctx->pool_free.end());
-            ctx->pool_cached -= it->first;
-            spill.push_back(it->second);
-            ctx->pool_free.erase(it);
+        // over the cap: the blocks that have been idle for the longest time go back to HIP (a process that has walked
+        // through many sizes — a test suite, a size sweep — must not sit on all of them; a prover repeating one shape
+        // never gets here).  The block that was just released always stays, whatever its size: it is the one the next
+        // call of the same shape asks for (a 2^30 FRI prototype is one block of ~100 GiB — evicting it meant a hipMalloc
+        // and a hipFree of that size per commit, 3 s instead of 135 ms).
+        const size_t cap = std::max(ctx->pool_cache_cap, bytes);
+        while (ctx->pool_cached > cap) {
+            auto victim = ctx->pool_free.end();
+            for (auto it = ctx->pool_free.begin(); it != ctx->pool_free.end(); ++it)
+                if (it->second.p != p && (victim == ctx->pool_free.end() || it->second.seq < victim->second.seq)) victim = it;
+            if (victim == ctx->pool_free.end()) break;
+            ctx->pool_cached -= victim->first;
+            spill.push_back(victim->second.p);
+            ctx->pool_free.erase(victim);
         }
     }
     if (!spill.empty()) {

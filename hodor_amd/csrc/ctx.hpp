@@ -192,7 +192,9 @@ struct hodor_ctx {
     // device memory pool of the handle API (abi_poly.hip).  Everything a handle does is enqueued on ctx->stream, so a
     // block one handle gives back may be handed to the next at once (stream order makes the reuse safe) and a chain of
     // Polynomial operations with temporaries never meets hipMalloc / hipFree (which synchronise the device).
-    std::multimap<size_t, void *> pool_free;
+    struct PoolBlock { void *p; uint64_t seq; };   // seq: when the block became idle (eviction is oldest-first)
+    std::multimap<size_t, PoolBlock> pool_free;
+    uint64_t pool_seq = 0;
     size_t pool_cached = 0, pool_live = 0;
     size_t pool_cache_cap = (size_t)64 << 30;   // idle bytes kept before blocks go back to HIP (HODOR_POOL_CACHE_GIB)
     std::mutex pool_mu;

@@ -508,3 +508,33 @@ def test_context_refuses_to_die_under_live_handles(oracles):
     assert ctx.L.hodor_ctx_try_destroy(C.c_void_p(ctx.h.value)) == hodor_amd.ERR_INVALID
     p.free()
     ctx.close()
+
+
+def test_pool_keeps_the_block_just_released_whatever_the_cap():
+    """The pool evicts the blocks idle for the longest time first and never the one just released (a prover repeating
+    one shape must not pay hipMalloc + hipFree per call even when that shape alone is larger than the cache cap:
+    HODOR_POOL_CACHE_GIB=0 here, in a process of its own because the knobs are read once)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, hodor_amd
+from hodor_amd.handles import Polynomial, VALUES
+ctx = hodor_amd.Context(device=0)
+a = Polynomial.new_for_size(ctx, VALUES, 1 << 16)          # 2 MiB
+a.free()
+cached, live = ctx.pool_stats()
+assert (cached, live) == (2 << 20, 0), (cached, live)      # over the cap of 0 bytes, and kept
+b = Polynomial.new_for_size(ctx, VALUES, 1 << 16)          # ...so that this one is served from the pool
+assert ctx.pool_stats() == (0, 2 << 20)
+c = Polynomial.new_for_size(ctx, VALUES, 1 << 18)          # 8 MiB
+b.free()
+c.free()                                                   # the older idle block goes, the one just released stays
+assert ctx.pool_stats() == (8 << 20, 0), ctx.pool_stats()
+ctx.close()
+print("ok")
+"""
+    env = dict(os.environ, HODOR_POOL_CACHE_GIB="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
