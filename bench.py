@@ -225,7 +225,7 @@ def main():
                          "producing transform's last pass stores each slab straight into the buffer of the rank it is for "
                          "(hodor_sixstep_columns_direct_dev / _rows_direct_dev) — no copy kernel competing for CUs, no chunks; "
                          "'copy' = the same mapped buffers and flags, but the chunked schedule's local send pieces are moved by "
-                         "device-to-device copies on the handle's own stream (hodor_exchange_direct_copy_dev: SDMA between "
+                         "device-to-device copies, one stream per destination (hodor_exchange_direct_copy_dev: SDMA between "
                          "devices, wire time spread over the step)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sixstep with collectives: finish each step's inverse transform before the next step's forward "
@@ -564,6 +564,8 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
     if multi:
         dt = all_reduce_scalar(dt, dist.ReduceOp.MAX)
+    if args.mode == "sixstep" and direct is not None:
+        direct.status()                          # a flag wait that gave up on its peers voids the run: raise, print nothing
 
     def timed(step, drain, steps):
         """`steps` steps between barrier + synchronize on both sides, max over the ranks, in ms per step."""
@@ -650,8 +652,8 @@ def main():
         torch.cuda.synchronize()
         sent = n * 32 * (world - 1) / world
         ms = e0.elapsed_time(e1) / reps
-        exchange = {"transport": ("copy engines: the chunked schedule's send pieces copied into the peers' mapped receive buffers on the "
-                                  "handle's own stream (C ABI: hodor_exchange_direct_copy_dev, the direct transport's flags)" if args.exchange == "copy" else
+        exchange = {"transport": ("copy engines: the chunked schedule's send pieces copied into the peers' mapped receive buffers, one "
+                                  "stream per destination (C ABI: hodor_exchange_direct_copy_dev, the direct transport's flags)" if args.exchange == "copy" else
                                   "direct: the producing pass stores each slab into the peer's receive buffer (C ABI: "
                                   "hodor_sixstep_columns_direct_dev / _rows_direct_dev, no all-to-all, no copy)" if direct is not None else
                                   "library schedule (hodor_dist_ntt_begin_dev / _end_dev) over its own RCCL exchange: ncclAllToAll — grouped "

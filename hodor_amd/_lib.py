@@ -512,6 +512,12 @@ class DirectExchange(_DistCalls):
     def release(self, slot, stream=None):
         self.ctx._chk(self.ctx.L.hodor_exchange_direct_release_dev(self.h, C.c_void_p(stream), C.c_uint32(slot)))
 
+    def status(self):
+        """hodor_exchange_direct_status: call after synchronising the stream a generation ran on and BEFORE using its
+        output — raises HODOR_ERR_DEVICE when a flag wait of this handle gave up on its peers (that generation's results
+        are undefined and the handle is dead)."""
+        self.ctx._chk(self.ctx.L.hodor_exchange_direct_status(self.h))
+
     def copy(self, slot, send, log_chunks=0, chunk=0, stream=None):
         """copy-engine variant: chunk `chunk` of the local send buffer -> the peers' receive buffers of `slot`"""
         self.ctx._chk(self.ctx.L.hodor_exchange_direct_copy_dev(self.h, C.c_void_p(stream), C.c_uint32(slot), _dptr(send),

@@ -418,8 +418,9 @@ int  hodor_exchange_direct_release_dev(hodor_exchange *x, void *stream, uint32_t
 int  hodor_exchange_direct_status(hodor_exchange *x);
 /* Copy-engine variant on the same handle and flags: the CHUNKED schedule's local send piece (written by
  * hodor_sixstep_columns_dev / _rows_dev as for hodor_sixstep_exchange_dev) is copied into the peers' mapped receive buffers
- * by n_ranks device-to-device copies on the handle's own stream (SDMA between devices: no CU taken from the transforms,
- * wire time spread over whatever is enqueued next).  Chunk 0 waits for the slot's release, the last chunk writes the
+ * by n_ranks device-to-device copies, each on the stream of its destination so that they run side by side, gated and
+ * collected by the handle's own stream (SDMA between devices: no CU taken from the transforms, wire time spread over
+ * whatever is enqueued next).  Chunk 0 waits for the slot's release, the last chunk writes the
  * `arrived` flags; the consumer is hodor_exchange_direct_wait_dev + the plain call on the slot's receive buffer +
  * hodor_exchange_direct_release_dev.  `send` must stay valid until that wait has been enqueued. */
 int  hodor_exchange_direct_copy_dev(hodor_exchange *x, void *stream, uint32_t slot, const hodor_fr *send, size_t n_local,
