@@ -101,8 +101,6 @@ def test_read_write_elem_op_clone_equal(gpu_ctxs, oracles, field_name):
 def test_transforms_match_oracle(gpu_ctxs, oracles, field_name, log_n):
     """fft / coset_fft / ifft / icoset_fft (+ _for_generator) — src/polynomials/mod.rs:611-638, :773-815"""
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
-    if log_n > ctx.S:
-        pytest.skip("beyond the field's two-adicity")
     n = 1 << log_n
     a = O.random_elements(n, 40 + log_n)
     gen = _int(O.random_elements(1, 41)[0])
@@ -203,8 +201,6 @@ def test_values_arithmetic_matches_oracle(gpu_ctxs, oracles, field_name, n):
     """add_assign / sub_assign / mul_assign / add_assign_scaled / pow / square / add_constant / batch_inversion
     on Values (:744-771, :817-954)"""
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
-    if n > (1 << ctx.S):
-        pytest.skip("beyond the field's two-adicity")
     size = O.domain(n)[0]
     a, b = O.random_elements(size, 80 + n), O.random_elements(size, 81 + n)
     s = _int(O.random_elements(1, 82)[0])
