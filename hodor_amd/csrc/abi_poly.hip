@@ -393,7 +393,12 @@ extern "C" int hodor_poly_as_ref_h(hodor_poly *p, const hodor_fr **host)
     POLY_ENTRY(p);
     if (!host) return HODOR_ERR_INVALID;
     if (!p->host_valid) {
-        p->host.resize(p->n);
+        try {
+            p->host.resize(p->n);
+        } catch (...) {   // no exception crosses the ABI: a host copy of a vector that large is simply refused
+            set_err(ctx, "as_ref: no host memory for a copy of the polynomial");
+            return HODOR_ERR_INVALID;
+        }
         HostXfer xfer(ctx, ctx->stream);
         HIPCHK(xfer.d2h(p->host.data(), p->d(), p->n * 32));
         HIPCHK(xfer.finish());
@@ -553,7 +558,7 @@ extern "C" int hodor_poly_pad_to_size_h(hodor_poly *p, size_t new_size)
 extern "C" int hodor_poly_trim_to_degree_h(hodor_poly *p, size_t degree)
 {
     POLY_ENTRY(p);
-    if (p->n <= degree + 1) return HODOR_OK;                               // :129-131
+    if (degree >= p->n - 1) return HODOR_OK;                               // size <= degree + 1 :129-131 (without the overflow)
     p->touch();
     HIPCHK(hipMemsetAsync(p->dfr() + degree + 1, 0, (p->n - degree - 1) * 32, ctx->stream));   // truncate + resize :132-133
     return HODOR_OK;

@@ -141,6 +141,39 @@ def test_dist_split_phase_with_ranks_played_on_streams_of_their_own(gpu_ctxs, ki
         x.close()
 
 
+@pytest.mark.parametrize("kind", ["direct", "copy"])
+def test_dist_refuses_a_transform_larger_than_the_receive_buffers(gpu_ctxs, kind):
+    """The peer-mapped transports store into receive buffers the library sized at creation: a transform whose block
+    does not fit is HODOR_ERR_SIZE before anything is enqueued, and the refusal leaves the handle usable (its two
+    transform slots are not leaked)."""
+    import torch
+    import hodor_amd
+    from hodor_amd import _lib
+    ctx = gpu_ctxs["bn256"]
+    small, big = 10, 12
+    x = hodor_amd.DirectExchange(ctx, 1, 0, 1 << small, n_slots=2)
+    hodor_amd.DirectExchange.connect_local([x])
+    x.set_transport(_lib.COPY if kind == "copy" else _lib.DIRECT, force_collectives=True)
+    a_big = torch.empty((1 << big, 4), dtype=torch.int64, device="cuda")
+    ctx.gen_elements_dev(a_big, 0, 1 << big, 77)
+    for _ in range(3):                           # more refusals than the handle has transform slots
+        with pytest.raises(hodor_amd.HodorError) as e:
+            x.dist_begin(a_big, big, ctx.domain(1 << big)[2], False, 0)
+        assert e.value.code == hodor_amd.ERR_SIZE
+    a = a_big[:1 << small].contiguous()
+    spec = torch.empty_like(a)
+    ctx.poly_fft_dev(a, spec, small)
+    w = ctx.domain(1 << small)[2]
+    b = x.dist_end(x.dist_begin(a, small, w, False, 0), torch.empty_like(a))
+    back = x.dist_end(x.dist_begin(b, small, w, True, 0), torch.empty_like(a))
+    torch.cuda.synchronize()
+    from sixstep_ref import layout_b_torch
+    l1 = small // 2
+    assert torch.equal(b, layout_b_torch(spec, l1, small - l1, 0, 1)) and torch.equal(back, a)
+    x.status()
+    x.close()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -189,6 +189,9 @@ def test_generic_methods_match_oracle(gpu_ctxs, oracles, field_name):
         with pytest.raises(hodor_amd.HodorError) as e:
             bad()
         assert e.value.code == hodor_amd.ERR_SIZE
+    for no_op in (2 * n - 1, 2 * n, 1 << 40, (1 << 64) - 1):           # size <= degree + 1: nothing happens (:129-131)
+        p.trim_to_degree(no_op)
+    assert np.array_equal(p.as_ref(), host)
     p.trim_to_degree(100)                                       # coefficients above x^100 become zero (:127-137)
     host = p.as_ref()
     assert np.array_equal(host[:101], exp[:101]) and not host[101:].any()
