@@ -8,6 +8,26 @@
 // every other: 6 GB allocated while the queue is busy stalled the free-running proof run of round 5 by ~190 ms.)
 // Every entry point that enqueues work on the slab synchronises before it returns, so a slab is idle when it is
 // released and the next commit may use it on any stream.
+namespace {
+// a staging block from the context's device pool (no hipMalloc / hipFree — which drains the device — per query); given
+// back once `stream` has run dry, so that the pool's rule (idle blocks only) holds for callers' streams too
+struct PoolBuf {
+    hodor_ctx *ctx;
+    hipStream_t stream;
+    void *p = nullptr;
+    size_t got = 0;
+    bool drained = false;
+    PoolBuf(hodor_ctx *c, hipStream_t s) : ctx(c), stream(s) {}
+    int alloc(size_t bytes) { return pool_alloc(ctx, bytes, &p, &got); }
+    ~PoolBuf()
+    {
+        if (!p) return;
+        if (!drained) (void)hipStreamSynchronize(stream);
+        pool_release(ctx, p, got);
+    }
+};
+}  // namespace
+
 extern "C" void hodor_fri_free(hodor_fri_proto *p)
 {
     if (!p) return;
@@ -349,8 +369,8 @@ extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr
     if (!is_pow2(n) || n < 2 || natural_index >= n) return HODOR_ERR_SIZE;   // asserts at :325-326
     hipStream_t stream = pick_stream(ctx, stream_);
     size_t entries = log2u(n) + 1;
-    DevBuf stage;
-    HIPCHK(hipMalloc(&stage.p, entries * 32));
+    PoolBuf stage(ctx, stream);
+    if (int rc_stage = stage.alloc(entries * 32)) return rc_stage;
     HIPCHK(iop_query_launch(stream, (const uint4 *)(leafs + (natural_index & ~(size_t)1)), (const uint4 *)nodes, n,
                             natural_index, (uint4 *)stage.p, ctx->mid));
     std::vector<uint8_t> host(entries * 32);
@@ -358,6 +378,7 @@ extern "C" int hodor_iop_query_dev(hodor_ctx *ctx, void *stream_, const hodor_fr
         HostXfer xfer(ctx, stream);
         HIPCHK(xfer.d2h(host.data(), stage.p, entries * 32));
         HIPCHK(xfer.finish());
+        stage.drained = true;
     }
     note_round_trip(ctx);
     memcpy(value, host.data(), 32);
@@ -380,8 +401,8 @@ extern "C" int hodor_iop_query_combined_dev(hodor_ctx *ctx, void *stream_, const
     if (!is_pow2(n) || n < 4 || natural_index >= n) return HODOR_ERR_SIZE;
     hipStream_t stream = pick_stream(ctx, stream_);
     size_t entries = log2u(n) + 1;                 // 2 values + (log2(n) - 1) digests
-    DevBuf stage;
-    HIPCHK(hipMalloc(&stage.p, entries * 32));
+    PoolBuf stage(ctx, stream);
+    if (int rc_stage = stage.alloc(entries * 32)) return rc_stage;
     HIPCHK(iop_query_coset2_launch(stream, (const uint4 *)leafs, (const uint4 *)nodes, n, natural_index,
                                    (uint4 *)stage.p, ctx->mid));
     std::vector<uint8_t> host(entries * 32);
@@ -389,6 +410,7 @@ extern "C" int hodor_iop_query_combined_dev(hodor_ctx *ctx, void *stream_, const
         HostXfer xfer(ctx, stream);
         HIPCHK(xfer.d2h(host.data(), stage.p, entries * 32));
         HIPCHK(xfer.finish());
+        stage.drained = true;
     }
     note_round_trip(ctx);
     memcpy(values, host.data(), 64);
@@ -427,8 +449,8 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     if (!buf || cap < need) return need;
     if (hipSetDevice(ctx->device) != hipSuccess) return 0;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    DevBuf stage;
-    if (hipMalloc(&stage.p, stage_bytes) != hipSuccess) return 0;
+    PoolBuf stage(ctx, ctx->stream);
+    if (stage.alloc(stage_bytes)) return 0;
     std::vector<size_t> q_index, q_entries;
     size_t domain_size = p->n, domain_idx = natural_first_element_index, off = 0;
     for (size_t r = 0; r < rounds; r++) {
@@ -461,6 +483,7 @@ extern "C" size_t hodor_fri_produce_proof(hodor_fri_proto *p, const hodor_fr *ld
     {
         HostXfer xfer(ctx, ctx->stream);
         if (xfer.d2h(host.data(), stage.p, stage_bytes) != hipSuccess || xfer.finish() != hipSuccess) return 0;
+        stage.drained = true;
     }
     note_round_trip(ctx);
     size_t o = 0, h = 0;
