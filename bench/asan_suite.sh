@@ -5,7 +5,7 @@
 # usage: bash bench/asan_suite.sh <out.log> [pytest args...]
 OUT=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-make -C "$ROOT/hodor_amd/csrc" asan > /dev/null || exit 9
+make -B -C "$ROOT/hodor_amd/csrc" asan > /dev/null   # -B: a directory named asan/ exists, make would call the target up to date || exit 9
 ASAN=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so)
 mkdir -p "$(dirname "$OUT")"
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1:protect_shadow_gap=0:log_path="$OUT.asan" \
