@@ -285,3 +285,20 @@ def test_bare_multi_gpu_bench_launch_never_answers_with_silence():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["scaling"] == "failed" and d["n_gpus"] == 2 and d["value"] == 0.0 and "reason" in d
+
+
+def test_handle_objects_refuse_without_a_device():
+    """The Python mirror of Polynomial / IopTree (hodor_amd/handles.py) is a binding, not an implementation: on a context
+    without a device every constructor is HODOR_ERR_DEVICE — there is no CPU path to fall back to."""
+    import numpy as np
+    from hodor_amd.handles import COEFFICIENTS, VALUES
+    ctx = hodor_amd.Context(device=-1)
+    zeros = np.zeros((8, 4), dtype=np.uint64)
+    for make in (lambda: hodor_amd.Polynomial.from_coeffs(ctx, zeros), lambda: hodor_amd.Polynomial.from_values(ctx, zeros),
+                 lambda: hodor_amd.Polynomial.new_for_size(ctx, VALUES, 8),
+                 lambda: hodor_amd.Polynomial.generated(ctx, COEFFICIENTS, 0, 8, 1),
+                 lambda: hodor_amd.Polynomial.degree_one_on_domain(ctx, 8, 1, 2)):
+        with pytest.raises(hodor_amd.HodorError) as e:
+            make()
+        assert e.value.code == hodor_amd.ERR_DEVICE
+    ctx.close()
