@@ -94,6 +94,39 @@ class Polynomial:
                                                          C.c_int(1 if coset else 0), C.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def from_roots(cls, ctx, roots, chunks=4):
+        """Polynomial::from_roots (:168-227): prod (x - r_i).  Per-chunk products in coefficient form on the host (the
+        library's scalar helpers), then from_coeffs / lde / mul_assign / ifft exactly as the reference composes them."""
+        roots = [int(r) for r in roots]
+        if not roots:
+            raise HodorError(ERR_INVALID, 'from_roots: result.expect("is some")')
+        size = 1
+        while size < len(roots) + 1:
+            size <<= 1
+        chunk = (len(roots) + chunks - 1) // chunks
+        result = None
+        for start in range(0, len(roots), chunk):
+            s = []
+            for r in roots[start:start + chunk]:
+                if not s:
+                    s = [ctx.sub(0, r), ctx.one]                                   # :187-190
+                    continue
+                tmp = [0] + s                                                      # x * s
+                for i, c in enumerate(s):
+                    tmp[i] = ctx.sub(tmp[i], ctx.mul(c, r))                        # - r * s  :195-199
+                s = tmp
+            arr = np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in s], dtype=np.uint64)
+            t = cls.from_coeffs(ctx, arr)
+            tv = t.lde(size // t.size())                                           # :214-216
+            t.free()
+            if result is None:
+                result = tv
+            else:
+                result.mul_assign(tv)                                              # :217-221
+                tv.free()
+        return result.ifft()                                                       # :225
+
     def clone(self):
         h = C.c_void_p()
         self.ctx._chk(self.ctx.L.hodor_poly_clone_h(self.h, C.byref(h)))
@@ -209,6 +242,18 @@ class Polynomial:
 
     def coset_lde(self, factor):
         return self.lde(factor, coset=True)
+
+    # The reference's other spellings of the same two functions — filtering_lde / coset_filtering_lde (:355-368,
+    # :484-499: best_lde on the zero-padded vector), lde_using_multiple_cosets(_naive) and the coset twins (:370-609) —
+    # all return the values `lde` / `coset_lde` return (asserted by its own tests, :1030); one device schedule serves them.
+    filtering_lde = lde_using_multiple_cosets = lde_using_multiple_cosets_naive = lambda self, factor: self.lde(factor)
+    coset_filtering_lde = coset_lde_using_multiple_cosets = coset_lde_using_multiple_cosets_naive = coset_lde
+
+    def into_coeffs(self):
+        """into_coeffs(self) :50 — the vector on the host; the handle is consumed"""
+        out = self.as_ref()
+        self.free()
+        return out
 
     @staticmethod
     def lde_all(polys, factor, coset=False):

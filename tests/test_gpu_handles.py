@@ -164,6 +164,46 @@ def test_lde_on_the_other_fields(gpu_ctxs, oracles, field_name):
     p.free()
 
 
+def test_from_roots_and_the_other_spellings_of_lde(gpu_ctxs, oracles, field_name):
+    """Polynomial::from_roots (:168-227) against the product computed with big integers; filtering_lde and the
+    *_using_multiple_cosets(_naive) spellings return what lde / coset_lde return (:1030); into_coeffs consumes"""
+    ctx, O, F = gpu_ctxs[field_name], oracles[field_name], PYF[field_name]
+    for count in (1, 3, 13):
+        roots = array_to_ints(O.random_elements(count, 900 + count))
+        want = [1]                                                        # canonical coefficients of prod (x - r)
+        for r in (F.from_mont(m) for m in roots):
+            nxt = [0] * (len(want) + 1)
+            for i, c in enumerate(want):
+                nxt[i + 1] = (nxt[i + 1] + c) % F.p
+                nxt[i] = (nxt[i] - c * r) % F.p
+            want = nxt
+        p = Polynomial.from_roots(ctx, roots)
+        size = O.domain(count + 1)[0]
+        assert p.form == COEFFICIENTS and p.size() == size
+        got = [F.from_mont(m) for m in array_to_ints(p.as_ref())]
+        assert got == want + [0] * (size - len(want))
+        z = roots[0]
+        assert p.evaluate_at(z) == 0                                      # a root is a root
+        p.free()
+    a = O.random_elements(64, 77)
+    p = Polynomial.from_coeffs(ctx, a)
+    base, cbase = p.lde(4), p.coset_lde(4)
+    for name in ("filtering_lde", "lde_using_multiple_cosets", "lde_using_multiple_cosets_naive"):
+        other = getattr(p, name)(4)
+        assert other == base, name
+        other.free()
+    for name in ("coset_filtering_lde", "coset_lde_using_multiple_cosets", "coset_lde_using_multiple_cosets_naive"):
+        other = getattr(p, name)(4)
+        assert other == cbase, name
+        other.free()
+    assert np.array_equal(base.as_ref(), O.poly_lde(a, 4)) and np.array_equal(cbase.as_ref(), O.poly_lde(a, 4, coset=True))
+    base.free()
+    cbase.free()
+    _, live0 = ctx.pool_stats()
+    assert np.array_equal(p.into_coeffs(), a) and p.h is None
+    assert ctx.pool_stats()[1] < live0
+
+
 # ---------------------------------------------------------------- generic and pointwise methods
 def test_generic_methods_match_oracle(gpu_ctxs, oracles, field_name):
     """distribute_powers / scale / negate / pad_by_factor / pad_to_size / trim_to_degree (:54-137)"""
