@@ -67,12 +67,17 @@ def test_verifier_survives_malformed_proofs_and_the_strict_one_accepts_only_the_
             if strict:
                 assert ok is False, "the strict verifier accepted a damaged proof (%d bytes)" % len(bad)
             elif ok:
-                # The reference's verifier never reads proof.output_coeffs_at_degree_plus_one (src/fri/verifier.rs uses
-                # initial_degree_plus_one and lde_factor only, :24, :146): the restated walk accepts any value in that one
-                # word — and nothing else.  (The strict variant binds it to the caller's expectation.)
+                # The reference's verifier never reads proof.output_coeffs_at_degree_plus_one and uses the other two
+                # trailing words only as Domain::new_for_size(initial_degree_plus_one * lde_factor), which rounds up to a
+                # power of two (src/fri/verifier.rs:24, :146; src/domains/mod.rs:21-44): the restated walk accepts a proof
+                # whose three trailing words were changed without changing that domain — and nothing else.  (The strict
+                # variant binds all three to the caller's expectation.)
                 accepted_lenient += 1
-                assert len(bad) == len(raw)
-                word = len(raw) - 16
-                assert bad[:word] == raw[:word] and bad[word + 8:] == raw[word + 8:]
+                assert len(bad) == len(raw) and bad[:-24] == raw[:-24]
+                initial, _, factor = (int.from_bytes(bad[len(bad) - 24 + 8 * k:len(bad) - 16 + 8 * k], "little") for k in range(3))
+                size = 1
+                while size < initial * factor:
+                    size <<= 1
+                assert size == n
     assert tried > 500 and accepted_lenient > 0
     ctx.close()
