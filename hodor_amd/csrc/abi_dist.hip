@@ -198,7 +198,10 @@ extern "C" int hodor_dist_ntt_begin_dev(hodor_exchange *x, void *stream_, const 
         else { pair = x->pair_busy[0] ? 1 : 0; x->pair_busy[pair] = true; x->ops_in_flight++; }
         if (!rc && op->transport != HODOR_TRANSPORT_RCCL) {
             if (!x->slots) { set_err(ctx, "dist_ntt: the exchange handle carries no transport"); rc = HODOR_ERR_INVALID; }
-            else if (x->own_recv_bytes && n_local * 32 > x->own_recv_bytes) {   // the peers would store past the end of the slot
+            else if (x->ops_in_flight > (int)x->n_slots) {   // a second begin on the only slot would wait for a release
+                set_err(ctx, "dist_ntt: a handle with N slots carries at most N transforms in flight");   // its own end enqueues
+                rc = HODOR_ERR_INVALID;
+            } else if (x->own_recv_bytes && n_local * 32 > x->own_recv_bytes) {   // the peers would store past the end of the slot
                 set_err(ctx, "dist_ntt: the slot's receive buffers are too small for this transform");
                 rc = HODOR_ERR_SIZE;
             } else op->slot = claim_slot(x);

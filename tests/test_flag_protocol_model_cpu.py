@@ -1,0 +1,114 @@
+"""A model of the peer-mapped transports' ordering protocol (hodor_amd/csrc/abi_exchange.hip, "direct transport"; the
+schedule on top of it in abi_dist.hip), explored exhaustively over every interleaving of the ranks' in-order streams:
+
+    producer:  begin   wait released[t] >= g - 1 for all t (in MY flag block)   the slot may be overwritten
+               write   my slab of generation g into every peer's receive buffer of the slot
+               signal  arrived[me] := g in every peer's flag block
+    consumer:  wait    arrived[s] >= g for all s (in MY flag block)
+               read    my receive buffer of the slot
+               release released[me] := g in every peer's flag block
+
+No box of the pool has two GPUs, so the protocol has only ever run between processes that share one device; this model is
+the part of "correct by construction" that can be checked without hardware: no slab is overwritten before its reader has
+read it, no reader sees a slab of the wrong generation, and no schedule the library accepts can deadlock — including the
+split-phase pair (two transforms in flight on one stream), which DOES deadlock on a handle with a single slot: the library
+refuses that case (hodor_dist_ntt_begin_dev: "a handle with N slots carries at most N transforms in flight")."""
+import pytest
+
+
+def _program(n_slots, rounds, in_flight):
+    """One rank's stream: `rounds` groups of `in_flight` transforms, all begins of a group before its ends (the split-phase
+    pair of abi_dist.hip: begin A, begin B, end A, end B), slots claimed round robin in call order."""
+    ops, nxt = [], 0
+    gen = [0] * n_slots
+    for _ in range(rounds):
+        group = []
+        for _ in range(in_flight):
+            s = nxt
+            nxt = (nxt + 1) % n_slots
+            gen[s] += 1
+            group.append((s, gen[s]))
+        for s, g in group:
+            ops += [("begin", s, g), ("write", s, g), ("signal", s, g)]
+        for s, g in group:
+            ops += [("wait", s, g), ("read", s, g), ("release", s, g)]
+    return ops
+
+
+def _explore(n_ranks, n_slots, rounds, in_flight, producer_waits=True):
+    """DFS over all interleavings.  Returns (number of states, deadlocked?).  Raises AssertionError on a data hazard."""
+    prog = _program(n_slots, rounds, in_flight)
+    P, S = n_ranks, n_slots
+    # state: pc per rank; arrived[r][s][from]; released[r][s][from]; recv[r][s][from] = generation of the slab lying there;
+    # unread[r][s][from] = True between the write of a slab and its read
+    zero = tuple(tuple(tuple(0 for _ in range(P)) for _ in range(S)) for _ in range(P))
+    start = (tuple(0 for _ in range(P)), zero, zero, zero, zero)
+    seen, stack, deadlock = {start}, [start], False
+
+    def setcell(t, r, s, f, v):
+        row = list(t[r][s])
+        row[f] = v
+        slot = list(t[r])
+        slot[s] = tuple(row)
+        out = list(t)
+        out[r] = tuple(slot)
+        return tuple(out)
+
+    while stack:
+        pcs, arrived, released, recv, unread = state = stack.pop()
+        moved = False
+        for r in range(P):
+            if pcs[r] == len(prog):
+                continue
+            op, s, g = prog[pcs[r]]
+            a2, rel2, rc2, un2 = arrived, released, recv, unread
+            if op == "begin":
+                if producer_waits and any(released[r][s][t] < g - 1 for t in range(P)):
+                    continue                                    # blocked: a peer still reads what I sent last time
+            elif op == "write":
+                for t in range(P):
+                    assert not unread[t][s][r], "rank %d overwrites a slab rank %d has not read (slot %d, gen %d)" % (r, t, s, g)
+                    rc2 = setcell(rc2, t, s, r, g)
+                    un2 = setcell(un2, t, s, r, 1)
+            elif op == "signal":
+                for t in range(P):
+                    a2 = setcell(a2, t, s, r, g)
+            elif op == "wait":
+                if any(arrived[r][s][t] < g for t in range(P)):
+                    continue                                    # blocked: a slab is still on its way
+            elif op == "read":
+                for t in range(P):
+                    assert recv[r][s][t] == g, "rank %d reads generation %d from rank %d, expected %d" % (r, recv[r][s][t], t, g)
+                    un2 = setcell(un2, r, s, t, 0)
+            elif op == "release":
+                for t in range(P):
+                    rel2 = setcell(rel2, t, s, r, g)
+            moved = True
+            nxt = (pcs[:r] + (pcs[r] + 1,) + pcs[r + 1:], a2, rel2, rc2, un2)
+            if nxt not in seen:
+                seen.add(nxt)
+                stack.append(nxt)
+        if not moved and any(pc < len(prog) for pc in pcs):
+            deadlock = True
+    return len(seen), deadlock
+
+
+@pytest.mark.parametrize("n_ranks,n_slots,rounds,in_flight", [
+    (2, 1, 3, 1), (2, 2, 3, 1), (2, 2, 2, 2), (2, 3, 2, 2), (2, 4, 2, 2), (3, 1, 2, 1), (3, 2, 1, 2), (4, 1, 1, 1)])
+def test_every_interleaving_is_safe_and_live(n_ranks, n_slots, rounds, in_flight):
+    states, deadlock = _explore(n_ranks, n_slots, rounds, in_flight)
+    assert states > 10 and not deadlock
+
+
+def test_two_transforms_in_flight_on_one_slot_deadlock_which_is_why_the_library_refuses_them():
+    """begin A, begin B on the same slot: B's begin waits for the release of A's generation, which A's end — behind it on
+    the same in-order stream — would enqueue.  Every interleaving ends in that deadlock."""
+    _, deadlock = _explore(2, 1, 1, 2)
+    assert deadlock
+
+
+def test_the_begin_wait_is_what_prevents_the_overwrite():
+    """The same exploration with the producer's wait removed finds the hazard the wait exists for: some interleaving
+    stores generation 2 over a slab of generation 1 that its reader has not read."""
+    with pytest.raises(AssertionError, match="overwrites a slab"):
+        _explore(2, 1, 2, 1, producer_waits=False)
