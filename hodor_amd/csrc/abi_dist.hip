@@ -323,6 +323,12 @@ extern "C" int hodor_dist_ntt_natural_dev(hodor_exchange *x, void *stream_, cons
     {
         std::lock_guard<std::mutex> lk(x->mu);
         if (x->ops_in_flight) { set_err(ctx, "dist_ntt_natural: a split-phase transform is in flight on this handle"); return HODOR_ERR_INVALID; }
+        if (effective_transport(x) != HODOR_TRANSPORT_RCCL && x->slots && x->n_slots < 2) {
+            // the slot of the first exchange is released only after the transform that reads it, and that transform's own
+            // exchange needs a slot: on one slot its begin would wait for that release (tests/test_flag_protocol_model_cpu.py)
+            set_err(ctx, "dist_ntt_natural: needs a handle with at least two slots");
+            return HODOR_ERR_INVALID;
+        }
         if ((rc = work_acquire(x, 4, n_local * 32, stream, &t0)) || (rc = work_acquire(x, 5, n_local * 32, stream, &t1))) return rc;
     }
     // natural block -> layout A
