@@ -35,9 +35,31 @@ def _program(n_slots, rounds, in_flight):
     return ops
 
 
-def _explore(n_ranks, n_slots, rounds, in_flight, producer_waits=True):
+def _program_natural(n_slots, calls):
+    """hodor_dist_ntt_natural_dev: an exchange whose slot is released only AFTER the transform that reads it — and that
+    transform runs an exchange of its own — then a third exchange (abi_dist.hip)."""
+    ops, nxt = [], 0
+    gen = [0] * n_slots
+
+    def claim():
+        nonlocal nxt
+        s = nxt
+        nxt = (nxt + 1) % n_slots
+        gen[s] += 1
+        return s, gen[s]
+
+    for _ in range(calls):
+        (a, ga), (t, gt), (b, gb) = claim(), claim(), claim()
+        ops += [("begin", a, ga), ("write", a, ga), ("signal", a, ga), ("wait", a, ga), ("read", a, ga)]
+        ops += [("begin", t, gt), ("write", t, gt), ("signal", t, gt), ("wait", t, gt), ("read", t, gt), ("release", t, gt)]
+        ops += [("release", a, ga)]
+        ops += [("begin", b, gb), ("write", b, gb), ("signal", b, gb), ("wait", b, gb), ("read", b, gb), ("release", b, gb)]
+    return ops
+
+
+def _explore(n_ranks, n_slots, rounds, in_flight, producer_waits=True, prog=None):
     """DFS over all interleavings.  Returns (number of states, deadlocked?).  Raises AssertionError on a data hazard."""
-    prog = _program(n_slots, rounds, in_flight)
+    prog = prog or _program(n_slots, rounds, in_flight)
     P, S = n_ranks, n_slots
     # state: pc per rank; arrived[r][s][from]; released[r][s][from]; recv[r][s][from] = generation of the slab lying there;
     # unread[r][s][from] = True between the write of a slab and its read
@@ -104,6 +126,17 @@ def test_two_transforms_in_flight_on_one_slot_deadlock_which_is_why_the_library_
     """begin A, begin B on the same slot: B's begin waits for the release of A's generation, which A's end — behind it on
     the same in-order stream — would enqueue.  Every interleaving ends in that deadlock."""
     _, deadlock = _explore(2, 1, 1, 2)
+    assert deadlock
+
+
+@pytest.mark.parametrize("n_ranks,n_slots,calls", [(2, 2, 2), (2, 3, 1), (2, 4, 2), (3, 2, 1)])
+def test_the_natural_order_schedule_is_safe_and_live_from_two_slots_on(n_ranks, n_slots, calls):
+    states, deadlock = _explore(n_ranks, n_slots, 0, 0, prog=_program_natural(n_slots, calls))
+    assert states > 10 and not deadlock
+
+
+def test_the_natural_order_schedule_deadlocks_on_one_slot_which_is_why_the_library_refuses_it():
+    _, deadlock = _explore(2, 1, 0, 0, prog=_program_natural(1, 1))
     assert deadlock
 
 
