@@ -459,7 +459,11 @@ int  hodor_exchange_direct_alloc_recv(hodor_exchange *x, size_t n_local, int coa
  *                               COSET2 n_block / 2 x 32), the P subtree roots exchanged (32 bytes per rank), the top
  *                               levels hashed by every rank: top = 2 P x 32 bytes, top[i] = global node i (top[1] = root)
  *   hodor_dist_lde_commit_dev   both: BASELINE config[2] over the node
- * All dist calls of one handle are serialised by the caller (one thread); buffers are the handle's own. */
+ * All dist calls of one handle are serialised by the caller (one thread); buffers are the handle's own.  Like any
+ * collective, every rank issues the SAME sequence of dist calls on its handle (the peer-mapped transports claim their
+ * slots in call order).  Those transports need one slot per transform in flight and two slots for
+ * hodor_dist_ntt_natural_dev (HODOR_ERR_INVALID otherwise — the schedule would wait for itself), and a block that fits
+ * the slot's receive buffers (HODOR_ERR_SIZE). */
 enum { HODOR_TRANSPORT_RCCL = 0, HODOR_TRANSPORT_DIRECT = 1, HODOR_TRANSPORT_COPY = 2 };
 typedef struct hodor_dist_op hodor_dist_op;
 void hodor_dist_split(uint32_t log_n, uint32_t *log_n1, uint32_t *log_n2);
