@@ -909,7 +909,7 @@ void o_blake2s(uint8_t out[32], const uint8_t *key, size_t keylen, const uint8_t
     param[1] = (uint8_t)keylen;  /* key length */
     param[2] = 1;                /* fanout */
     param[3] = 1;                /* depth */
-    memcpy(param + 24, personal, personal_len > 8 ? 8 : personal_len);
+    if (personal_len) memcpy(param + 24, personal, personal_len > 8 ? 8 : personal_len);   /* personal may be NULL with length 0 */
     uint32_t h[8];
     for (int i = 0; i < 8; i++) {
         uint32_t pw = (uint32_t)param[4 * i] | ((uint32_t)param[4 * i + 1] << 8) |
