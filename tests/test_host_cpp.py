@@ -150,3 +150,40 @@ def test_two_c_processes_run_the_library_schedules_and_the_transport_soak(tmp_pa
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "all tests passed" in out.stdout
     assert out.stdout.count("0 mismatches") == 4, out.stdout
+
+
+# ---------------------------------------------------------------- the host-only half of the mirror, EXECUTED on the CPU
+def test_host_only_half_of_the_mirror_runs_without_a_device(tmp_path):
+    """tests/host_cpp/test_host_cpu.cpp: Field on a device-less context, Domain, the combiners, FRIProof parse / re-encode,
+    NaiveFriIop::verify_proof(_strict), IOP::verify, Transcript — against a fixture written here by the Python restatement
+    (oracle/pyref.py) — and the refusal (HODOR_ERR_DEVICE) of the device-side constructors."""
+    import hodor_amd
+    from oracle import pyref as P
+    hodor_amd.build()
+    F = P.BN256
+    log_deg, factor, index = 3, 4, 7
+    coeffs = [pow(11, 20 + i, F.p) for i in range(1 << log_deg)]
+    lde = P.poly_lde(F, coeffs, factor)
+    proto = P.fri_commit(F, lde, factor, 1)
+    raw = P.fri_proof_to_bytes(P.fri_produce_proof(F, proto, lde, index, factor, 1))
+    u64 = lambda v: int(v).to_bytes(8, "little")
+    t = P.Transcript(F)
+    t.commit_bytes(bytes(range(32)))
+    t.commit_field_element(12345)
+    ch_bytes = t.get_challenge_bytes()
+    ch_elem = F.to_mont(t.get_challenge())
+    leafs = [F.to_mont(v) for v in lde]
+    nodes = P.iop_create(leafs)
+    leaf_index = 21
+    path = P.iop_path(nodes, leafs, leaf_index)
+    fx = (u64(len(raw)) + raw + u64(index) + P.mont_to_bytes(F.to_mont(lde[index])) + u64(len(lde)) + u64(factor)
+          + ch_bytes + P.mont_to_bytes(ch_elem) + P.mont_to_bytes(leafs[leaf_index]) + u64(leaf_index) + u64(len(path))
+          + b"".join(bytes(x) for x in path) + bytes(nodes[1]))
+    fixture = tmp_path / "fixture.bin"
+    fixture.write_bytes(fx)
+    exe = str(tmp_path / "test_host_cpu")
+    libdir = os.path.join(ROOT, "hodor_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "host_cpp", "test_host_cpu.cpp"),
+                           "-L" + libdir, "-lhodor_gpu", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe, str(fixture)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "host-only checks passed" in out.stdout, out.stdout + out.stderr
