@@ -518,6 +518,16 @@ class DirectExchange(_DistCalls):
         are undefined and the handle is dead)."""
         self.ctx._chk(self.ctx.L.hodor_exchange_direct_status(self.h))
 
+    def synchronize_and_check(self, stream=None):
+        """Wait for `stream` (None: the whole device) and then status(): the one safe way to read a result of the
+        stream-ordered dist_* / direct calls of this handle (a timed-out flag wait cannot be seen any earlier)."""
+        import torch
+        if stream is None:
+            torch.cuda.synchronize()
+        else:
+            torch.cuda.ExternalStream(stream).synchronize()
+        self.status()
+
     def copy(self, slot, send, log_chunks=0, chunk=0, stream=None):
         """copy-engine variant: chunk `chunk` of the local send buffer -> the peers' receive buffers of `slot`"""
         self.ctx._chk(self.ctx.L.hodor_exchange_direct_copy_dev(self.h, C.c_void_p(stream), C.c_uint32(slot), _dptr(send),

@@ -568,6 +568,7 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
             if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
         if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
         pool_drain(ctx);
+        pool_destroy_events(ctx);
         for (auto &L : ctx->lanes) {
             for (int i = 0; i < 2; i++)
                 if (L.buf[i]) (void)hipFree(L.buf[i]);
@@ -612,6 +613,7 @@ extern "C" int hodor_ctx_synchronize(hodor_ctx *ctx)
 {
     NEED_DEVICE();
     HIPCHK(hipDeviceSynchronize());
+    pool_collect(ctx);   // the device is idle: blocks evicted from the pool's cache go back to HIP now
     return HODOR_OK;
 }
 
@@ -1093,10 +1095,9 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
     auto fail = [&](hipError_t e, const char *what) {
         if (us) (void)hipStreamSynchronize(us);
         if (ds && ds != us) (void)hipStreamSynchronize(ds);
-        {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
-        }
+        // set_err takes err_mu only: this runs while a HostXfer (pinned_mu) may still be in scope, and the commit /
+        // batch_inversion / evaluate_at paths take ctx->mu BEFORE pinned_mu — taking ctx->mu here was an inversion
+        set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
         lane_release(ctx, L);
         return HODOR_ERR_DEVICE;
     };

@@ -62,11 +62,27 @@ int work_done(hodor_exchange *x, int i, hipStream_t stream)
     return HODOR_OK;
 }
 
-uint32_t claim_slot(hodor_exchange *x)
+// Slots of the peer-mapped transports.  Round 5 claimed them round robin, which hands a slot that an OPEN split-phase
+// transform still holds to the next one as soon as the others have cycled (begin A, begin B, end B, begin C: C gets A's
+// slot, and its begin waits for a release only A's end will enqueue later on the same stream).  Now: the lowest slot no
+// open operation holds — every rank issues the same sequence of dist calls, so every rank picks the same one — and -1
+// when all are held (the caller refuses with HODOR_ERR_INVALID).  Caller holds x->mu.
+int claim_slot(hodor_exchange *x)
 {
-    const uint32_t s = x->next_slot;
-    x->next_slot = (x->next_slot + 1) % x->n_slots;
-    return s;
+    for (uint32_t s = 0; s < x->n_slots; s++)
+        if (!x->slot_busy[s]) { x->slot_busy[s] = true; return (int)s; }
+    return -1;
+}
+void unclaim_slot(hodor_exchange *x, uint32_t s) { if (s < 16) x->slot_busy[s] = false; }
+
+// A schedule failed after it had opened a generation on a peer-mapped slot (a flag wait, a producer or a copy is in the
+// queue, the matching signal / release is not): the peers will wait for flags that never come.  The handle is marked
+// dead — every later call on it returns HODOR_ERR_DEVICE at once (direct_ready) instead of meeting a half-open
+// protocol, and the peers' waits time out into the same state on their side.
+int dist_dead(hodor_exchange *x, int rc)
+{
+    if (x->d_err) *(volatile uint32_t *)x->d_err = 1;
+    return rc;
 }
 
 void *own_recv_of(const hodor_exchange *x, uint32_t slot) { return (void *)(uintptr_t)x->slots[slot].h_tab[x->rank]; }
@@ -100,11 +116,22 @@ int dist_all_to_all(hodor_exchange *x, hipStream_t stream, const hodor_fr *send,
         return HODOR_OK;
     }
     // direct transports: the copy engine moves `send` into the peers' receive buffers of a slot
-    if (!x->slots) { set_err(ctx, "dist: the exchange handle carries no transport"); return HODOR_ERR_INVALID; }
-    h->slot = claim_slot(x);
-    if (n_local * 32 > x->own_recv_bytes && x->own_recv_bytes) { set_err(ctx, "dist: the slot's receive buffers are too small"); return HODOR_ERR_SIZE; }
-    if ((rc = hodor_exchange_direct_copy_dev(x, stream, h->slot, send, n_local, 0, 0))) return rc;
-    if ((rc = hodor_exchange_direct_wait_dev(x, stream, h->slot))) return rc;
+    if (!x->slots) { set_err(ctx, "dist: the exchange handle carries no transport"); h->transport = -1; return HODOR_ERR_INVALID; }
+    if (n_local * 32 > x->own_recv_bytes && x->own_recv_bytes) { set_err(ctx, "dist: the slot's receive buffers are too small"); h->transport = -1; return HODOR_ERR_SIZE; }
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(x->mu);
+        slot = claim_slot(x);
+    }
+    if (slot < 0) { set_err(ctx, "dist: every slot of the handle is held by an open operation"); h->transport = -1; return HODOR_ERR_INVALID; }
+    h->slot = (uint32_t)slot;
+    if ((rc = hodor_exchange_direct_copy_dev(x, stream, h->slot, send, n_local, 0, 0)) ||
+        (rc = hodor_exchange_direct_wait_dev(x, stream, h->slot))) {
+        std::lock_guard<std::mutex> lk(x->mu);
+        unclaim_slot(x, h->slot);
+        h->transport = -1;
+        return dist_dead(x, rc);
+    }
     *recv = (hodor_fr *)own_recv_of(x, h->slot);
     return HODOR_OK;
 }
@@ -113,7 +140,20 @@ int dist_a2a_release(hodor_exchange *x, hipStream_t stream, const A2A &h)
 {
     if (h.transport < 0) return HODOR_OK;
     if (h.transport == HODOR_TRANSPORT_RCCL) return work_done(x, h.work_recv, stream);
-    return hodor_exchange_direct_release_dev(x, stream, h.slot);
+    int rc = hodor_exchange_direct_release_dev(x, stream, h.slot);
+    std::lock_guard<std::mutex> lk(x->mu);
+    unclaim_slot(x, h.slot);
+    return rc ? dist_dead(x, rc) : rc;
+}
+
+// after the stream a schedule ran on has been synchronised: did one of its flag waits give up (peer-mapped transports)?
+int dist_check_waits(hodor_exchange *x)
+{
+    if (x->d_err && *(volatile uint32_t *)x->d_err) {
+        set_err(x->ctx, "dist: a wait for a peer timed out; the results of this call are undefined");
+        return HODOR_ERR_DEVICE;
+    }
+    return HODOR_OK;
 }
 
 }  // namespace
@@ -157,6 +197,7 @@ struct hodor_dist_op {
     int work_send, work_recv;   // work buffers held (-1: none)
     uint64_t ticket;
     bool collective;
+    bool holds_slot = false;    // a slot of a peer-mapped transport is claimed (given back by end)
 };
 
 extern "C" int hodor_dist_ntt_begin_dev(hodor_exchange *x, void *stream_, const hodor_fr *src, size_t n_local, uint32_t log_n,
@@ -204,7 +245,11 @@ extern "C" int hodor_dist_ntt_begin_dev(hodor_exchange *x, void *stream_, const 
             } else if (x->own_recv_bytes && n_local * 32 > x->own_recv_bytes) {   // the peers would store past the end of the slot
                 set_err(ctx, "dist_ntt: the slot's receive buffers are too small for this transform");
                 rc = HODOR_ERR_SIZE;
-            } else op->slot = claim_slot(x);
+            } else {
+                const int sl = claim_slot(x);
+                if (sl < 0) { set_err(ctx, "dist_ntt: every slot of the handle is held by an open operation"); rc = HODOR_ERR_INVALID; }
+                else { op->slot = (uint32_t)sl; op->holds_slot = true; }
+            }
             if (rc) { x->ops_in_flight--; x->pair_busy[pair] = false; }
         }
     }
@@ -244,6 +289,12 @@ extern "C" int hodor_dist_ntt_begin_dev(hodor_exchange *x, void *stream_, const 
         std::lock_guard<std::mutex> lk(x->mu);
         x->ops_in_flight--;
         x->pair_busy[pair] = false;
+        if (op->work_send >= 0) (void)work_done(x, op->work_send, stream);
+        if (op->work_recv >= 0) (void)work_done(x, op->work_recv, stream);
+        if (op->holds_slot) {   // a generation may be open on the slot (begin / chunk 0 went in, signal did not): the handle is dead
+            unclaim_slot(x, op->slot);
+            (void)dist_dead(x, rc);
+        }
         delete op;
         return rc;
     }
@@ -257,23 +308,27 @@ extern "C" int hodor_dist_ntt_end_dev(hodor_dist_op *op, hodor_fr *dst)
     hodor_exchange *x = op->x;
     hodor_ctx *ctx = x->ctx;
     int rc = HODOR_OK;
-    if (!dst) rc = HODOR_ERR_INVALID;
     hipStream_t stream = op->stream;
-    // the exchange has arrived ...
-    if (!rc && op->transport == HODOR_TRANSPORT_RCCL) { if (op->collective) rc = hodor_sixstep_exchange_wait_dev(x, stream, op->ticket); }
-    else if (!rc) rc = hodor_exchange_direct_wait_dev(x, stream, op->slot);
+    // the exchange has arrived (waited for even when the call is about to fail on a null dst: a slot is released only
+    // after its wait, or the peers' next generation would overwrite what has not been read) ...
+    if (op->transport == HODOR_TRANSPORT_RCCL) { if (op->collective) rc = hodor_sixstep_exchange_wait_dev(x, stream, op->ticket); }
+    else rc = hodor_exchange_direct_wait_dev(x, stream, op->slot);
+    const bool waited = rc == HODOR_OK;
+    if (!rc && !dst) rc = HODOR_ERR_INVALID;
     // ... the consuming half: forward = the row transforms, inverse = the inverse column transforms
     if (!rc)
         rc = op->inverse ? hodor_sixstep_columns_dev(ctx, stream, op->recv, dst, op->log_n1, op->log_n2, op->log_p, x->rank, &op->omega, 1, op->log_chunks, 0)
                          : hodor_sixstep_rows_dev(ctx, stream, op->recv, dst, op->log_n1, op->log_n2, op->log_p, x->rank, &op->omega, 0, op->log_chunks, 0);
     if (op->transport != HODOR_TRANSPORT_RCCL) {
-        int r2 = hodor_exchange_direct_release_dev(x, stream, op->slot);   // the peers may overwrite the slot again
+        int r2 = waited ? hodor_exchange_direct_release_dev(x, stream, op->slot) : HODOR_ERR_DEVICE;   // the peers may overwrite the slot again
+        if (r2) (void)dist_dead(x, r2);   // no release went out: the peers' next begin on this slot can only time out
         if (!rc) rc = r2;
     }
     {
         std::lock_guard<std::mutex> lk(x->mu);
         if (op->work_send >= 0) (void)work_done(x, op->work_send, stream);
         if (op->work_recv >= 0) (void)work_done(x, op->work_recv, stream);
+        if (op->holds_slot) unclaim_slot(x, op->slot);
         x->ops_in_flight--;
         x->pair_busy[op->pair] = false;
     }
@@ -331,36 +386,40 @@ extern "C" int hodor_dist_ntt_natural_dev(hodor_exchange *x, void *stream_, cons
         }
         if ((rc = work_acquire(x, 4, n_local * 32, stream, &t0)) || (rc = work_acquire(x, 5, n_local * 32, stream, &t1))) return rc;
     }
+    // From here on the call holds work buffers 4 and 5 and (between an exchange and its release) a slot: every exit runs
+    // through `leave`, which marks the buffers' last use — and a failure between an exchange and its release still
+    // enqueues that release (dist_a2a_release), so that the peers are not left waiting for it.
+    auto leave = [&](int r) {
+        std::lock_guard<std::mutex> lk(x->mu);
+        (void)work_done(x, 4, stream);
+        (void)work_done(x, 5, stream);
+        return r;
+    };
     // natural block -> layout A
     const hodor_fr *packed = src;
     if (log_p) {
-        if ((rc = hodor_sixstep_pack_dev(ctx, stream, src, (hodor_fr *)t0, log_n1 - log_p, log_n2, log_p))) return rc;
+        if ((rc = hodor_sixstep_pack_dev(ctx, stream, src, (hodor_fr *)t0, log_n1 - log_p, log_n2, log_p))) return leave(rc);
         packed = (const hodor_fr *)t0;
     }
     A2A h;
     hodor_fr *a = nullptr;
-    if ((rc = dist_all_to_all(x, stream, packed, n_local, 6, &a, &h))) return rc;
+    if ((rc = dist_all_to_all(x, stream, packed, n_local, 6, &a, &h))) return leave(rc);
     // A -> B (into t1)
     rc = hodor_dist_ntt_forward_dev(x, stream, a, (hodor_fr *)t1, n_local, log_n, &w, 0);
     int r2 = dist_a2a_release(x, stream, h);
-    if (rc || (rc = r2)) return rc;
-    if (inverse && (rc = hodor_poly_unary_dev(ctx, stream, (hodor_fr *)t1, n_local, HODOR_UN_SCALE, &scale, 0))) return rc;
+    if (rc || (rc = r2)) return leave(rc);
+    if (inverse && (rc = hodor_poly_unary_dev(ctx, stream, (hodor_fr *)t1, n_local, HODOR_UN_SCALE, &scale, 0))) return leave(rc);
     // layout B -> natural block of the output
     const hodor_fr *pb = (const hodor_fr *)t1;
     if (log_p) {
-        if ((rc = hodor_sixstep_pack_dev(ctx, stream, (const hodor_fr *)t1, (hodor_fr *)t0, log_n1 - log_p, log_n2, log_p))) return rc;
+        if ((rc = hodor_sixstep_pack_dev(ctx, stream, (const hodor_fr *)t1, (hodor_fr *)t0, log_n1 - log_p, log_n2, log_p))) return leave(rc);
         pb = (const hodor_fr *)t0;
     }
     hodor_fr *y = nullptr;
-    if ((rc = dist_all_to_all(x, stream, pb, n_local, 6, &y, &h))) return rc;
+    if ((rc = dist_all_to_all(x, stream, pb, n_local, 6, &y, &h))) return leave(rc);
     rc = hodor_transpose_dev(ctx, stream, y, dst, (size_t)1 << log_n1, (size_t)1 << (log_n2 - log_p));   // [k1][k2_local] -> [k2_local][k1]
     r2 = dist_a2a_release(x, stream, h);
-    {
-        std::lock_guard<std::mutex> lk(x->mu);
-        (void)work_done(x, 4, stream);
-        (void)work_done(x, 5, stream);
-    }
-    return rc ? rc : r2;
+    return leave(rc ? rc : r2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +460,13 @@ extern "C" int hodor_dist_lde_by_cosets_dev(hodor_exchange *x, void *stream_, co
         if ((rc = work_acquire(x, 4, fp * n * 32, stream, &res)) || (rc = work_acquire(x, 5, fp * n * 32, stream, &send))) return rc;
         if (paired && (rc = work_acquire(x, 7, fp * n * 16, stream, &half))) return rc;
     }
+    auto leave = [&](int r) {   // every exit marks the last use of the work buffers the call holds
+        std::lock_guard<std::mutex> lk(x->mu);
+        (void)work_done(x, 4, stream);
+        (void)work_done(x, 5, stream);
+        if (paired) (void)work_done(x, 7, stream);
+        return r;
+    };
     // my cosets: res[t][k] = P((g) W^(i) w^k), i = rank fp + t — the coset scale runs inside the first pass of the transform
     for (size_t t = 0; t < fp; t++) {
         const size_t i = (size_t)x->rank * fp + t;
@@ -411,7 +477,7 @@ extern "C" int hodor_dist_lde_by_cosets_dev(hodor_exchange *x, void *stream_, co
         hodor_fr *out = (hodor_fr *)res + t * n;
         rc = (i != 0 || coset) ? hodor_poly_coset_fft_for_generator_dev(ctx, stream, coeffs, out, log_n, &g)
                                : hodor_poly_fft_dev(ctx, stream, coeffs, out, log_n);
-        if (rc) return rc;
+        if (rc) return leave(rc);
     }
     // part: my cosets on a k range of 2^log_len values, [fp][2^log_len] -> my k block of that range, [klen][f]
     auto interleave = [&](const hodor_fr *part, uint32_t log_len, hodor_fr *out) -> int {
@@ -436,17 +502,11 @@ extern "C" int hodor_dist_lde_by_cosets_dev(hodor_exchange *x, void *stream_, co
         for (int hh = 0; hh < 2 && !rc; hh++) {   // the two halves of every coset's k range, each dealt to the ranks
             hipError_t e = hipMemcpy2DAsync(half, (n / 2) * 32, (const uint8_t *)res + (size_t)hh * (n / 2) * 32, n * 32,
                                             (n / 2) * 32, fp, hipMemcpyDeviceToDevice, stream);
-            if (e != hipSuccess) { (void)hipGetLastError(); set_err(ctx, std::string("dist_lde: ") + hipGetErrorString(e)); return HODOR_ERR_DEVICE; }
+            if (e != hipSuccess) { (void)hipGetLastError(); set_err(ctx, std::string("dist_lde: ") + hipGetErrorString(e)); return leave(HODOR_ERR_DEVICE); }
             rc = interleave((const hodor_fr *)half, log_n - 1, lde_block + (size_t)hh * (n * f / P / 2));
         }
     }
-    {
-        std::lock_guard<std::mutex> lk(x->mu);
-        (void)work_done(x, 4, stream);
-        (void)work_done(x, 5, stream);
-        if (paired) (void)work_done(x, 7, stream);
-    }
-    return rc;
+    return leave(rc);
 }
 
 // Blake2sIopTree::create (src/iop/blake2s_trivial_iop.rs:131-219) over the ranks: each rank builds the complete subtree
@@ -472,11 +532,20 @@ extern "C" int hodor_dist_commit_dev(hodor_exchange *x, void *stream_, const hod
         if (x->ops_in_flight) { set_err(ctx, "dist_commit: a split-phase transform is in flight on this handle"); return HODOR_ERR_INVALID; }
         if ((rc = work_acquire(x, 5, P * 32, stream, &mine))) return rc;
     }
+    auto leave = [&](int r) {
+        std::lock_guard<std::mutex> lk(x->mu);
+        (void)work_done(x, 5, stream);
+        return r;
+    };
     for (size_t t = 0; t < P; t++)   // the same 32 bytes for every rank: an all-gather spelled as the all-to-all the transports have
-        HIPCHK(hipMemcpyAsync((uint8_t *)mine + 32 * t, local_nodes + 32, 32, hipMemcpyDeviceToDevice, stream));
+        if (hipMemcpyAsync((uint8_t *)mine + 32 * t, local_nodes + 32, 32, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            set_err(ctx, "dist_commit: copying the subtree root failed");
+            return leave(HODOR_ERR_DEVICE);
+        }
     A2A h;
     hodor_fr *gathered = nullptr;
-    if ((rc = dist_all_to_all(x, stream, (const hodor_fr *)mine, P, 6, &gathered, &h))) return rc;
+    if ((rc = dist_all_to_all(x, stream, (const hodor_fr *)mine, P, 6, &gathered, &h))) return leave(rc);
     memset(top, 0, 2 * P * 32);
     HostXfer xfer(ctx, stream);
     hipError_t e = xfer.d2h(top + 32 * P, gathered, 32 * P);
@@ -488,6 +557,10 @@ extern "C" int hodor_dist_commit_dev(hodor_exchange *x, void *stream_, const hod
     }
     HIPCHK(e);
     if (r2) return r2;
+    // the stream has been synchronised: a flag wait of the 32-byte exchange that gave up (slow or dead peer) left the
+    // slot holding whatever it held — the root hashed from it would be silently wrong (advisor, round 5)
+    if (h.transport == HODOR_TRANSPORT_DIRECT || h.transport == HODOR_TRANSPORT_COPY)
+        if ((rc = dist_check_waits(x))) return rc;
     note_round_trip(ctx);
     for (size_t w = P / 2; w >= 1; w /= 2)
         for (size_t i = 0; i < w; i++)

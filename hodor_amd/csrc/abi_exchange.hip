@@ -562,7 +562,11 @@ extern "C" int hodor_exchange_direct_wait_dev(hodor_exchange *x, void *stream, u
 
 // A wait that gave up (~10 s without its peers) lets the stream run on: what the consumer transform then reads — or the
 // producer overwrites — is UNDEFINED for that generation.  The flag it leaves behind is host-visible; call this after
-// synchronising the stream the generation ran on (hodor_amd/sixstep.py does in every *_end) before using the result.
+// synchronising the stream the generation ran on, before using the result: MANDATORY for a caller of the stream-ordered
+// hodor_dist_* / hodor_exchange_direct_* calls (nothing in them can look at the flag before the stream has run);
+// hodor_dist_commit_dev, which synchronises itself, checks it before it hashes the gathered roots; the Python binding
+// offers it as DirectExchange.status() / .synchronize_and_check() and this repository's tests and benchmarks call it
+// wherever they read a result of a peer-mapped transport.
 // HODOR_ERR_DEVICE: some wait on this handle has timed out; every later call on the handle fails the same way.
 extern "C" int hodor_exchange_direct_status(hodor_exchange *x)
 {

@@ -6,11 +6,13 @@
 // from ONE slab out of the context's device pool (abi_poly.hip): a prover committing polynomial after polynomial
 // meets hipMalloc once per size.  (Rounds 1-4 parked one freed slab on the context and paid hipMalloc + hipFree for
 // every other: 6 GB allocated while the queue is busy stalled the free-running proof run of round 5 by ~190 ms.)
-// Every entry point that enqueues work on the slab synchronises before it returns, so a slab is idle when it is
-// released and the next commit may use it on any stream.
+// A commit may run on ANY stream (the `_dev` entry points take the caller's): the pool orders the slab's new user behind
+// its old one with an event (pool_alloc's `consumer`), and every entry point that enqueues work on the slab on a
+// caller's stream synchronises before it returns, so that at hodor_fri_free the only work that can still be pending on
+// the slab is the handle API's (ctx->stream) — the stream pool_release records its event on.
 namespace {
-// a staging block from the context's device pool (no hipMalloc / hipFree — which drains the device — per query); given
-// back once `stream` has run dry, so that the pool's rule (idle blocks only) holds for callers' streams too
+// a staging block from the context's device pool (no hipMalloc / hipFree — which drains the device — per query); taken
+// for `stream` (ordered behind the block's previous user) and given back once `stream` has run dry
 struct PoolBuf {
     hodor_ctx *ctx;
     hipStream_t stream;
@@ -18,7 +20,7 @@ struct PoolBuf {
     size_t got = 0;
     bool drained = false;
     PoolBuf(hodor_ctx *c, hipStream_t s) : ctx(c), stream(s) {}
-    int alloc(size_t bytes) { return pool_alloc(ctx, bytes, &p, &got); }
+    int alloc(size_t bytes) { return pool_alloc(ctx, bytes, &p, &got, stream); }
     ~PoolBuf()
     {
         if (!p) return;
@@ -107,7 +109,7 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
         }
         delete q;
     };
-    if ((rc = pool_alloc(ctx, need, &p->slab, &p->slab_bytes))) { delete p; return rc; }
+    if ((rc = pool_alloc(ctx, need, &p->slab, &p->slab_bytes, stream))) { delete p; return rc; }
     uint8_t *cursor = (uint8_t *)p->slab;
     auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
     p->l0_nodes = carve(n * 32);
@@ -264,7 +266,7 @@ extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *s
     const size_t small_bytes = 64 * (num_steps + 1);
     size_t need = up(n * 32) + up(small_bytes) + up(n * 32) + up(initial_degree_plus_one * 16);
     for (size_t i = 0, sz = n / 2; i < num_steps; i++, sz >>= 1) need += 2 * up(sz * 32);
-    if ((rc = pool_alloc(ctx, need, &p->slab, &p->slab_bytes))) { delete p; return rc; }
+    if ((rc = pool_alloc(ctx, need, &p->slab, &p->slab_bytes, stream))) { delete p; return rc; }
     uint8_t *cursor = (uint8_t *)p->slab;
     auto carve = [&](size_t b) { uint8_t *r = cursor; cursor += up(b); return (void *)r; };
     p->l0_nodes = carve(n * 32);

@@ -8,13 +8,44 @@
 // ------------------------------------------------------------------------------------------------
 // the pool
 // ------------------------------------------------------------------------------------------------
-// Blocks are recycled by size: a request takes the smallest cached block that fits and is not more than twice as
-// large.  Safe without events because every user of a pooled block is enqueued on ctx->stream (the header's rule).
+// Blocks are recycled by size.  Polynomial sizes are powers of two and a FRI slab's size is a function of its shape, so
+// from 1 MiB up a request is served by a cached block of EXACTLY its (MiB-rounded) size or by hipMalloc — round 5's
+// "smallest block that fits and is not more than twice as large" handed 2^k-element requests 2^(k+1)-element blocks and
+// cost a third of the pool; small blocks (flags, staging, 2-element polynomials) still take anything up to twice their
+// size.  Ordering (round 6): a block goes back with an event recorded on the stream of its LAST user (ctx->stream for
+// the handles; a `_dev` caller's own stream for the prototypes and staging blocks it made), and a new user on any other
+// stream first waits for that event — the same stream needs nothing, stream order does it.
 static size_t pool_round(size_t bytes)
 {
     if (bytes < 256) return 256;
     if (bytes < ((size_t)1 << 20)) return (bytes + 255) & ~(size_t)255;
     return (bytes + (((size_t)1 << 20) - 1)) & ~(((size_t)1 << 20) - 1);     // MiB granules: fewer distinct sizes
+}
+
+static void pool_event_put(hodor_ctx *ctx, hipEvent_t ev)   // caller holds pool_mu
+{
+    if (!ev) return;
+    if (ctx->pool_events.size() < 256) ctx->pool_events.push_back(ev);
+    else (void)hipEventDestroy(ev);
+}
+
+// blocks evicted from the cache wait here until the library is about to enter the allocator anyway (hipFree waits for
+// the whole device: a handle `free` in the middle of a proof must never do that)
+static void pool_reap(hodor_ctx *ctx)
+{
+    std::vector<hodor_ctx::PoolBlock> dead;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        dead.swap(ctx->pool_zombies);
+        ctx->pool_zombie_bytes = 0;
+    }
+    if (dead.empty()) return;
+    for (auto &b : dead) {
+        if (b.ev) (void)hipEventSynchronize(b.ev);
+        (void)hipFree(b.p);
+    }
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    for (auto &b : dead) pool_event_put(ctx, b.ev);
 }
 
 void pool_drain(hodor_ctx *ctx)
@@ -25,26 +56,47 @@ void pool_drain(hodor_ctx *ctx)
         blocks.swap(ctx->pool_free);
         ctx->pool_cached = 0;
     }
+    pool_reap(ctx);
     if (blocks.empty()) return;
     (void)hipDeviceSynchronize();
     for (auto &b : blocks) (void)hipFree(b.second.p);
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    for (auto &b : blocks) pool_event_put(ctx, b.second.ev);
 }
 
-int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got)
+void pool_destroy_events(hodor_ctx *ctx)   // hodor_ctx_destroy, after pool_drain
+{
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    for (hipEvent_t ev : ctx->pool_events) (void)hipEventDestroy(ev);
+    ctx->pool_events.clear();
+}
+
+int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got, hipStream_t consumer)
 {
     const size_t want = pool_round(bytes);
+    bool reap = false;
     {
         std::lock_guard<std::mutex> lk(ctx->pool_mu);
         auto it = ctx->pool_free.lower_bound(want);
-        if (it != ctx->pool_free.end() && it->first <= 2 * want) {
-            *out = it->second.p;
+        if (it != ctx->pool_free.end() && (it->first == want || (want < ((size_t)1 << 20) && it->first <= 2 * want))) {
+            hodor_ctx::PoolBlock b = it->second;
+            *out = b.p;
             *got = it->first;
             ctx->pool_cached -= it->first;
             ctx->pool_live += it->first;
             ctx->pool_free.erase(it);
+            hipError_t e = hipSuccess;
+            if (b.ev && b.last != consumer) e = hipStreamWaitEvent(consumer, b.ev, 0);
+            pool_event_put(ctx, b.ev);
+            if (e != hipSuccess) {   // cannot order the new user behind the old one: wait for the old one here
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(b.last);
+            }
             return HODOR_OK;
         }
+        reap = !ctx->pool_zombies.empty();
     }
+    if (reap) pool_reap(ctx);   // entering the allocator anyway: the evicted blocks go back to HIP first
     hipError_t e = hipMalloc(out, want);
     if (e != hipSuccess) {   // give the cache back and try once more
         (void)hipGetLastError();
@@ -61,37 +113,41 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got)
     ctx->pool_live += want;
     return HODOR_OK;
 }
+int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got) { return pool_alloc(ctx, bytes, out, got, ctx->stream); }
 
-void pool_release(hodor_ctx *ctx, void *p, size_t bytes)
+void pool_release(hodor_ctx *ctx, void *p, size_t bytes, hipStream_t last_user)
 {
     if (!p) return;
-    std::vector<void *> spill;
-    {
-        std::lock_guard<std::mutex> lk(ctx->pool_mu);
-        ctx->pool_live -= bytes;
-        ctx->pool_free.emplace(bytes, hodor_ctx::PoolBlock{p, ++ctx->pool_seq});
-        ctx->pool_cached += bytes;
-        // over the cap: the blocks that have been idle for the longest time go back to HIP (a process that has walked
-        // through many sizes — a test suite, a size sweep — must not sit on all of them; a prover repeating one shape
-        // never gets here).  The block that was just released always stays, whatever its size: it is the one the next
-        // call of the same shape asks for (a 2^30 FRI prototype is one block of ~100 GiB — evicting it meant a hipMalloc
-        // and a hipFree of that size per commit, 3 s instead of 135 ms).
-        const size_t cap = std::max(ctx->pool_cache_cap, bytes);
-        while (ctx->pool_cached > cap) {
-            auto victim = ctx->pool_free.end();
-            for (auto it = ctx->pool_free.begin(); it != ctx->pool_free.end(); ++it)
-                if (it->second.p != p && (victim == ctx->pool_free.end() || it->second.seq < victim->second.seq)) victim = it;
-            if (victim == ctx->pool_free.end()) break;
-            ctx->pool_cached -= victim->first;
-            spill.push_back(victim->second.p);
-            ctx->pool_free.erase(victim);
-        }
-    }
-    if (!spill.empty()) {
-        (void)hipDeviceSynchronize();   // a spilled block may still be read by work enqueued before its release
-        for (void *q : spill) (void)hipFree(q);
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    hipEvent_t ev = nullptr;
+    if (!ctx->pool_events.empty()) { ev = ctx->pool_events.back(); ctx->pool_events.pop_back(); }
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+    if (ev && hipEventRecord(ev, last_user) != hipSuccess) { (void)hipGetLastError(); pool_event_put(ctx, ev); ev = nullptr; }
+    if (!ev) (void)hipStreamSynchronize(last_user);   // no event: the block is idle by the time anybody can take it
+    ctx->pool_live -= bytes;
+    ctx->pool_free.emplace(bytes, hodor_ctx::PoolBlock{p, ++ctx->pool_seq, ev, last_user});
+    ctx->pool_cached += bytes;
+    // over the cap: the blocks that have been idle for the longest time leave the cache (a process that has walked
+    // through many sizes — a test suite, a size sweep — must not sit on all of them; a prover repeating one shape
+    // never gets here).  The block that was just released always stays, whatever its size: it is the one the next
+    // call of the same shape asks for (a 2^30 FRI prototype is one block of ~100 GiB — evicting it meant a hipMalloc
+    // and a hipFree of that size per commit, 3 s instead of 135 ms).  Evicted blocks are NOT freed here (hipFree drains
+    // the device): they wait in pool_zombies for the next call that enters the allocator (pool_alloc's slow path,
+    // hodor_ctx_trim, hodor_ctx_synchronize, hodor_ctx_destroy).
+    const size_t cap = std::max(ctx->pool_cache_cap, bytes);
+    while (ctx->pool_cached > cap) {
+        auto victim = ctx->pool_free.end();
+        for (auto it = ctx->pool_free.begin(); it != ctx->pool_free.end(); ++it)
+            if (it->second.p != p && (victim == ctx->pool_free.end() || it->second.seq < victim->second.seq)) victim = it;
+        if (victim == ctx->pool_free.end()) break;
+        ctx->pool_cached -= victim->first;
+        ctx->pool_zombie_bytes += victim->first;
+        ctx->pool_zombies.push_back(victim->second);
+        ctx->pool_free.erase(victim);
     }
 }
+void pool_release(hodor_ctx *ctx, void *p, size_t bytes) { pool_release(ctx, p, bytes, ctx->stream); }
+void pool_collect(hodor_ctx *ctx) { pool_reap(ctx); }
 
 // ------------------------------------------------------------------------------------------------
 // the objects
@@ -238,7 +294,7 @@ extern "C" int hodor_ctx_pool_stats(const hodor_ctx *ctx_, size_t *cached, size_
     hodor_ctx *ctx = const_cast<hodor_ctx *>(ctx_);
     if (!ctx) return HODOR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->pool_mu);
-    if (cached) *cached = ctx->pool_cached;
+    if (cached) *cached = ctx->pool_cached + ctx->pool_zombie_bytes;   // evicted blocks are still ours until collected
     if (live) *live = ctx->pool_live;
     return HODOR_OK;
 }

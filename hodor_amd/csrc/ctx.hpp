@@ -192,8 +192,13 @@ struct hodor_ctx {
     // device memory pool of the handle API (abi_poly.hip).  Everything a handle does is enqueued on ctx->stream, so a
     // block one handle gives back may be handed to the next at once (stream order makes the reuse safe) and a chain of
     // Polynomial operations with temporaries never meets hipMalloc / hipFree (which synchronise the device).
-    struct PoolBlock { void *p; uint64_t seq; };   // seq: when the block became idle (eviction is oldest-first)
+    // seq: when the block became idle (eviction is oldest-first); ev: recorded on `last`, the stream of the block's last
+    // user, when it was released (null: the block was idle already) — a new user on another stream waits for it
+    struct PoolBlock { void *p; uint64_t seq; hipEvent_t ev; hipStream_t last; };
     std::multimap<size_t, PoolBlock> pool_free;
+    std::vector<PoolBlock> pool_zombies;        // evicted from the cache, not yet handed back to HIP (pool_collect)
+    size_t pool_zombie_bytes = 0;
+    std::vector<hipEvent_t> pool_events;        // idle events, reused
     uint64_t pool_seq = 0;
     size_t pool_cached = 0, pool_live = 0;
     size_t pool_cache_cap = (size_t)64 << 30;   // idle bytes kept before blocks go back to HIP (HODOR_POOL_CACHE_GIB)
@@ -348,9 +353,15 @@ static inline hipStream_t pick_stream(hodor_ctx *ctx, void *stream)
 }
 
 // abi_poly.hip: the handle API's device pool (pool_drain: hodor_ctx_destroy / hodor_ctx_trim; it synchronises the device)
+// `consumer`: the stream the block's new user enqueues on; `last_user`: the stream its old user enqueued on (default for
+// both: ctx->stream, the handles' stream).  pool_collect: hand evicted blocks back to HIP (waits for the device).
 int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got);
+int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got, hipStream_t consumer);
 void pool_release(hodor_ctx *ctx, void *p, size_t bytes);
+void pool_release(hodor_ctx *ctx, void *p, size_t bytes, hipStream_t last_user);
 void pool_drain(hodor_ctx *ctx);
+void pool_collect(hodor_ctx *ctx);
+void pool_destroy_events(hodor_ctx *ctx);
 static inline void note_round_trip(hodor_ctx *ctx) { ctx->host_round_trips.fetch_add(1, std::memory_order_relaxed); }
 
 // defined in abi.hip (caller holds ctx->mu)

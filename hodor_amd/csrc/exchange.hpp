@@ -36,7 +36,9 @@ struct hodor_exchange {
     hipStream_t peer_stream[HODOR_EXCHANGE_MAX_RANKS] = {};
     hipEvent_t peer_done[HODOR_EXCHANGE_MAX_RANKS] = {};
     hipEvent_t gate = nullptr;
-    uint32_t next_slot = 0;                 // abi_dist.hip: slots are claimed round robin
+    // abi_dist.hip: a schedule claims the LOWEST slot no open operation holds and gives it back when its release has been
+    // enqueued — a function of the sequence of dist calls only, hence the same slot on every rank
+    bool slot_busy[16] = {};
     void *own_recv[16] = {};                // receive buffers the library allocated itself (hodor_exchange_direct_alloc_recv)
     size_t own_recv_bytes = 0;
     // ---- the schedule inside the library (abi_dist.hip): grow-only work buffers (send / receive pieces of the RCCL and

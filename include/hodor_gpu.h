@@ -463,7 +463,15 @@ int  hodor_exchange_direct_alloc_recv(hodor_exchange *x, size_t n_local, int coa
  * collective, every rank issues the SAME sequence of dist calls on its handle (the peer-mapped transports claim their
  * slots in call order).  Those transports need one slot per transform in flight and two slots for
  * hodor_dist_ntt_natural_dev (HODOR_ERR_INVALID otherwise — the schedule would wait for itself), and a block that fits
- * the slot's receive buffers (HODOR_ERR_SIZE). */
+ * the slot's receive buffers (HODOR_ERR_SIZE).  Slots are claimed lowest-free-first and given back by the call that
+ * enqueues their release (hodor_dist_ntt_end_dev for a split-phase transform), so begin / end pairs of different
+ * transforms may be closed in any order.
+ * On the peer-mapped transports every dist call but hodor_dist_commit_dev is stream-ordered and CANNOT see a flag wait
+ * that gave up on a slow or dead peer: after synchronising the stream and BEFORE using a result, the caller MUST call
+ * hodor_exchange_direct_status (HODOR_ERR_DEVICE = the result is undefined, the handle dead); hodor_dist_commit_dev /
+ * hodor_dist_lde_commit_dev synchronise themselves and make that check before they hash the gathered subtree roots.
+ * A dist call that fails after it has opened a generation on a slot marks the handle dead as well (its peers' waits
+ * time out into the same state): destroy the handles and build new ones. */
 enum { HODOR_TRANSPORT_RCCL = 0, HODOR_TRANSPORT_DIRECT = 1, HODOR_TRANSPORT_COPY = 2 };
 typedef struct hodor_dist_op hodor_dist_op;
 void hodor_dist_split(uint32_t log_n, uint32_t *log_n1, uint32_t *log_n2);

@@ -16,44 +16,85 @@ refuses that case (hodor_dist_ntt_begin_dev: "a handle with N slots carries at m
 import pytest
 
 
-def _program(n_slots, rounds, in_flight):
+class _Slots:
+    """abi_dist.hip's claim rule (round 6): the LOWEST slot no open operation holds, given back when the operation's
+    release has been enqueued.  `round_robin` = the rule of rounds 4-5, kept to show the sequence it breaks on."""
+
+    def __init__(self, n_slots, round_robin=False):
+        self.busy, self.gen, self.nxt, self.rr = [False] * n_slots, [0] * n_slots, 0, round_robin
+
+    def claim(self):
+        if self.rr:
+            s = self.nxt
+            self.nxt = (self.nxt + 1) % len(self.busy)
+        else:
+            free = [i for i, b in enumerate(self.busy) if not b]
+            if not free:
+                raise RuntimeError("refused: every slot is held by an open operation")    # HODOR_ERR_INVALID
+            s = free[0]
+        self.busy[s] = True
+        self.gen[s] += 1
+        return s, self.gen[s]
+
+    def give_back(self, s):
+        self.busy[s] = False
+
+
+def _program(n_slots, rounds, in_flight, single_slot_unchecked=False):
     """One rank's stream: `rounds` groups of `in_flight` transforms, all begins of a group before its ends (the split-phase
-    pair of abi_dist.hip: begin A, begin B, end A, end B), slots claimed round robin in call order."""
-    ops, nxt = [], 0
-    gen = [0] * n_slots
+    pair of abi_dist.hip: begin A, begin B, end A, end B)."""
+    ops = []
+    slots = _Slots(n_slots, round_robin=single_slot_unchecked)
     for _ in range(rounds):
-        group = []
-        for _ in range(in_flight):
-            s = nxt
-            nxt = (nxt + 1) % n_slots
-            gen[s] += 1
-            group.append((s, gen[s]))
+        group = [slots.claim() for _ in range(in_flight)]
         for s, g in group:
             ops += [("begin", s, g), ("write", s, g), ("signal", s, g)]
         for s, g in group:
             ops += [("wait", s, g), ("read", s, g), ("release", s, g)]
+            slots.give_back(s)
+    return ops
+
+
+def _program_ends_out_of_order(n_slots, round_robin):
+    """begin A, begin B, end B, begin C, end A, end C — ends are not FIFO (the header never asked for that)."""
+    slots = _Slots(n_slots, round_robin)
+    ops = []
+
+    def begin():
+        s, g = slots.claim()
+        ops.extend([("begin", s, g), ("write", s, g), ("signal", s, g)])
+        return s, g
+
+    def end(sg):
+        s, g = sg
+        ops.extend([("wait", s, g), ("read", s, g), ("release", s, g)])
+        slots.give_back(s)
+
+    a, b = begin(), begin()
+    end(b)
+    c = begin()
+    end(a)
+    end(c)
     return ops
 
 
 def _program_natural(n_slots, calls):
     """hodor_dist_ntt_natural_dev: an exchange whose slot is released only AFTER the transform that reads it — and that
     transform runs an exchange of its own — then a third exchange (abi_dist.hip)."""
-    ops, nxt = [], 0
-    gen = [0] * n_slots
-
-    def claim():
-        nonlocal nxt
-        s = nxt
-        nxt = (nxt + 1) % n_slots
-        gen[s] += 1
-        return s, gen[s]
+    ops = []
+    slots = _Slots(n_slots, round_robin=n_slots == 1)   # one slot: the sequence the library refuses, modelled unchecked
 
     for _ in range(calls):
-        (a, ga), (t, gt), (b, gb) = claim(), claim(), claim()
+        a, ga = slots.claim()
         ops += [("begin", a, ga), ("write", a, ga), ("signal", a, ga), ("wait", a, ga), ("read", a, ga)]
+        t, gt = slots.claim()
         ops += [("begin", t, gt), ("write", t, gt), ("signal", t, gt), ("wait", t, gt), ("read", t, gt), ("release", t, gt)]
+        slots.give_back(t)
         ops += [("release", a, ga)]
+        slots.give_back(a)
+        b, gb = slots.claim()
         ops += [("begin", b, gb), ("write", b, gb), ("signal", b, gb), ("wait", b, gb), ("read", b, gb), ("release", b, gb)]
+        slots.give_back(b)
     return ops
 
 
@@ -125,8 +166,22 @@ def test_every_interleaving_is_safe_and_live(n_ranks, n_slots, rounds, in_flight
 def test_two_transforms_in_flight_on_one_slot_deadlock_which_is_why_the_library_refuses_them():
     """begin A, begin B on the same slot: B's begin waits for the release of A's generation, which A's end — behind it on
     the same in-order stream — would enqueue.  Every interleaving ends in that deadlock."""
-    _, deadlock = _explore(2, 1, 1, 2)
+    _, deadlock = _explore(2, 1, 1, 2, prog=_program(1, 1, 2, single_slot_unchecked=True))
     assert deadlock
+    with pytest.raises(RuntimeError, match="refused"):      # ... and the claim rule itself refuses it
+        _program(1, 1, 2)
+
+
+def test_ends_in_any_order_are_live_with_lowest_free_first_and_were_not_with_round_robin():
+    """Advisor, round 5: begin A (slot 0), begin B (slot 1), end B, begin C.  Round robin hands C slot 0 while A still holds
+    it: C's begin waits for the release of A's generation, which A's end — later on the same stream — would enqueue.
+    Lowest-free-first gives C the slot B gave back."""
+    _, deadlock = _explore(2, 2, 0, 0, prog=_program_ends_out_of_order(2, round_robin=True))
+    assert deadlock
+    states, deadlock = _explore(2, 2, 0, 0, prog=_program_ends_out_of_order(2, round_robin=False))
+    assert states > 10 and not deadlock
+    states, deadlock = _explore(3, 2, 0, 0, prog=_program_ends_out_of_order(2, round_robin=False))
+    assert not deadlock
 
 
 @pytest.mark.parametrize("n_ranks,n_slots,calls", [(2, 2, 2), (2, 3, 1), (2, 4, 2), (3, 2, 1)])
