@@ -7,13 +7,17 @@
 OUT=${1:-/dev/stdout}; LOG=${2:-20}; REGS=${3:-4}; F=${4:-16}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 EXE=/tmp/prove_shape_cpp
-g++ -O2 -std=c++17 "$ROOT/tests/host_cpp/prove_shape.cpp" -L"$ROOT/hodor_amd" -lhodor_gpu -Wl,-rpath,"$ROOT/hodor_amd" -o $EXE || exit 9
+g++ -O2 -std=c++17 -pthread "$ROOT/tests/host_cpp/prove_shape.cpp" -L"$ROOT/hodor_amd" -lhodor_gpu -Wl,-rpath,"$ROOT/hodor_amd" -o $EXE || exit 9
 {
   for comb in 0 1; do
-    echo "== C++ through hodor.hpp, combiner $comb, free-running (no synchronisation between the phases)"
-    $EXE $LOG $REGS $F $comb /tmp/proof_$comb.bin 5 0
+    echo "== C++ through hodor.hpp, combiner $comb, from_arp AS WRITTEN (Polynomial::as_mut), free-running (no synchronisation between the phases)"
+    $EXE $LOG $REGS $F $comb /tmp/proof_$comb.bin 5 0 0
     echo "== the same with the device drained after every phase (per-phase times)"
-    $EXE $LOG $REGS $F $comb /tmp/proof_sync_$comb.bin 5 1
+    $EXE $LOG $REGS $F $comb /tmp/proof_sync_$comb.bin 5 1 0
+    echo "== from_arp's vectors device-resident (dense_divisor_on_coset, coset table cloned in HBM), free-running / drained"
+    $EXE $LOG $REGS $F $comb /tmp/proof_res_$comb.bin 5 0 1
+    $EXE $LOG $REGS $F $comb /tmp/proof_res_sync_$comb.bin 5 1 1
+    cmp /tmp/proof_$comb.bin /tmp/proof_res_$comb.bin && echo "proof bytes identical in both forms of from_arp"
     python3 - <<PY
 import hashlib
 a=open("/tmp/proof_$comb.bin","rb").read(); b=open("/tmp/proof_sync_$comb.bin","rb").read()

@@ -82,6 +82,9 @@ EXPORTS = [
     "hodor_poly_pad_to_size_h", "hodor_poly_pow_h", "hodor_poly_quotient_term_h", "hodor_poly_read_h",
     "hodor_poly_scale_h", "hodor_poly_size_h", "hodor_poly_square_h", "hodor_poly_trim_to_degree_h",
     "hodor_poly_write_h",
+    # round 6: whole-slice as_mut() with write-back, PCIe byte counters
+    "hodor_poly_as_mut_h", "hodor_poly_commit_mut_h", "hodor_ctx_host_traffic",
+    "hodor_poly_dense_divisor_on_coset_dev", "hodor_poly_dense_divisor_on_coset_h",
 ]
 
 

@@ -569,6 +569,7 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
         if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
         pool_drain(ctx);
         pool_destroy_events(ctx);
+        host_images_drain(ctx);
         for (auto &L : ctx->lanes) {
             for (int i = 0; i < 2; i++)
                 if (L.buf[i]) (void)hipFree(L.buf[i]);
@@ -642,6 +643,7 @@ extern "C" int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_
         HIPCHK(xfer.finish());
         return HODOR_OK;
     }
+    ctx->h2d_bytes.fetch_add(bytes, std::memory_order_relaxed);
     HIPCHK(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
     return HODOR_OK;
 }
@@ -653,6 +655,7 @@ extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *de
         HIPCHK(xfer.d2h(host_dst, dev_src, bytes));
         HIPCHK(xfer.finish());
     } else {
+        ctx->d2h_bytes.fetch_add(bytes, std::memory_order_relaxed);
         HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
     }
     note_round_trip(ctx);
@@ -1120,6 +1123,7 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             HostXfer xfer(ctx, us);
             if ((e = xfer.h2d(din, in, n_in * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess) return fail(e, "slice upload");
         }
+        if (!small_in) ctx->h2d_bytes.fetch_add(n_in * 32, std::memory_order_relaxed);
         if ((!small_in && (e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, us)) != hipSuccess) ||
             (e = hipEventRecord(L->uploaded, us)) != hipSuccess ||
             (serial && (e = hipStreamSynchronize(us)) != hipSuccess))   // the link is free for the next upload
@@ -1150,7 +1154,8 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             HostXfer xfer(ctx, ds);
             if ((e = xfer.d2h(out, dptr_out, n_out * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess)
                 return fail(e, "slice download");
-        } else if ((e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ds)) != hipSuccess ||
+        } else if ((ctx->d2h_bytes.fetch_add(n_out * 32, std::memory_order_relaxed), false) ||
+                   (e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ds)) != hipSuccess ||
                    (e = hipStreamSynchronize(ds)) != hipSuccess)
             return fail(e, "slice download");
         if (trace) tr[6] = slice_trace_us();

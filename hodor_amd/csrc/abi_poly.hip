@@ -179,6 +179,79 @@ void slab_unref(Slab *s)
 }
 }  // namespace
 
+// The host image of a polynomial (as_ref() / as_mut()): heap memory below 1 MiB, a PINNED allocation recycled through the
+// context (ctx.hpp: host_free) from there up.  Contents are undefined after reserve().
+struct HostImage {
+    hodor_ctx *ctx = nullptr;
+    hodor_fr *p = nullptr;
+    size_t n = 0;              // elements the image holds
+    size_t bytes = 0;          // allocation size
+    bool pinned = false;
+    hodor_fr *data() const { return p; }
+    int reserve(hodor_ctx *c, size_t elems)
+    {
+        const size_t want = elems * sizeof(hodor_fr);
+        if (p && want <= bytes) { n = elems; return HODOR_OK; }
+        release();
+        ctx = c;
+        if (want < ((size_t)1 << 20)) {
+            p = (hodor_fr *)malloc(want ? want : 32);
+            if (!p) return HODOR_ERR_INVALID;
+            pinned = false;
+        } else {
+            void *q = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(c->host_mu);
+                auto it = c->host_free.find(want);
+                if (it != c->host_free.end()) { q = it->second; c->host_cached -= want; c->host_free.erase(it); }
+            }
+            if (!q && hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return HODOR_ERR_INVALID;   // no host memory for a copy of the polynomial
+            }
+            p = (hodor_fr *)q;
+            pinned = true;
+        }
+        bytes = want;
+        n = elems;
+        return HODOR_OK;
+    }
+    void release()
+    {
+        if (!p) return;
+        if (!pinned) free(p);
+        else {
+            bool keep = false;
+            {
+                std::lock_guard<std::mutex> lk(ctx->host_mu);
+                if (ctx->host_cached + bytes <= hodor_ctx::HOST_CACHE_CAP) {
+                    ctx->host_free.emplace(bytes, (void *)p);
+                    ctx->host_cached += bytes;
+                    keep = true;
+                }
+            }
+            if (!keep) (void)hipHostFree(p);
+        }
+        p = nullptr;
+        n = bytes = 0;
+    }
+    ~HostImage() { release(); }
+    HostImage() = default;
+    HostImage(const HostImage &) = delete;
+    HostImage &operator=(const HostImage &) = delete;
+};
+
+void host_images_drain(hodor_ctx *ctx)   // hodor_ctx_destroy / hodor_ctx_trim
+{
+    std::multimap<size_t, void *> blocks;
+    {
+        std::lock_guard<std::mutex> lk(ctx->host_mu);
+        blocks.swap(ctx->host_free);
+        ctx->host_cached = 0;
+    }
+    for (auto &b : blocks) (void)hipHostFree(b.second);
+}
+
 struct hodor_poly {
     hodor_ctx *ctx = nullptr;
     int form = HODOR_FORM_COEFFICIENTS;
@@ -187,12 +260,16 @@ struct hodor_poly {
     size_t n = 0;              // elements, a power of two
     uint32_t exp = 0;          // :28-33
     HFr omega, omegainv, geninv, minv;
-    std::vector<hodor_fr> host;    // as_ref(): materialised on demand
-    bool host_valid = false;
+    HostImage host;            // as_ref() / as_mut(): materialised on demand
+    bool host_valid = false;   // the image equals the vector
+    // as_mut() (:46) handed the image out as `&mut [F]`: from then on the IMAGE is the vector and the device copy is
+    // stale, until the next operation that needs the device copy — or hodor_poly_commit_mut_h — writes it back
+    bool host_dirty = false;
+    bool all_zero = false;     // new_for_size and nothing since: the image of a large zero polynomial needs no download
     uint4 *d() const { return (uint4 *)((uint8_t *)slab->p + off); }
     hodor_fr *dfr() const { return (hodor_fr *)d(); }
     void *stream() const { return (void *)ctx->stream; }
-    void touch() { host_valid = false; }
+    void touch() { host_valid = false; all_zero = false; }
 };
 
 struct hodor_iop {
@@ -208,10 +285,47 @@ struct hodor_iop {
     uint8_t *d() const { return slab ? (uint8_t *)slab->p + off : raw; }
 };
 
-#define POLY_ENTRY(p)                                                                 \
+// write the host image back after as_mut() (one upload of the whole vector; synchronous: the caller may take the next
+// as_mut() and scribble on the image as soon as this returns)
+static int poly_flush(hodor_poly *p)
+{
+    if (!p->host_dirty) return HODOR_OK;
+    hodor_ctx *ctx = p->ctx;
+    hipError_t e = hipSuccess;
+    if (p->n <= 4) {   // q_poly.as_mut()[1] = F::one() (src/ali/per_register/mod.rs:199-202, deep.rs:61-62): from kernel arguments
+        Fr v[4];
+        for (size_t i = 0; i < p->n; i++) v[i] = to_dev(to_h(&p->host.data()[i]));
+        e = store_elems_launch(ctx->stream, p->d(), v, (uint32_t)p->n);
+    } else {
+        HostXfer xfer(ctx, ctx->stream);
+        e = xfer.h2d(p->d(), p->host.data(), p->n * 32);
+        if (e == hipSuccess) e = xfer.finish();
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_err(ctx, std::string("as_mut write-back: ") + hipGetErrorString(e));
+        return HODOR_ERR_DEVICE;
+    }
+    p->host_dirty = false;
+    p->host_valid = true;      // image and device copy agree again
+    p->all_zero = false;
+    return HODOR_OK;
+}
+// an operand whose device copy is about to be read or written: pending as_mut() writes go in first
+#define POLY_SYNC(q)                                                                  \
+    do {                                                                              \
+        if ((q)->host_dirty) {                                                        \
+            int rc_sync__ = poly_flush(const_cast<hodor_poly *>(q));                  \
+            if (rc_sync__) return rc_sync__;                                          \
+        }                                                                             \
+    } while (0)
+#define POLY_ENTRY_HOST(p)   /* entry points that work on the host image only */       \
     if (!(p)) return HODOR_ERR_INVALID;                                               \
     hodor_ctx *ctx = (p)->ctx;                                                        \
     NEED_DEVICE()
+#define POLY_ENTRY(p)                                                                 \
+    POLY_ENTRY_HOST(p);                                                               \
+    POLY_SYNC(p)
 #define NEED_FORM(p, f)                                                               \
     do {                                                                              \
         if ((p)->form != (f)) {                                                       \
@@ -282,11 +396,18 @@ static int poly_swap_storage(hodor_poly *p, size_t new_n, Slab **old, size_t *ol
 // ------------------------------------------------------------------------------------------------
 extern "C" void *hodor_ctx_stream(hodor_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 extern "C" uint64_t hodor_ctx_host_round_trips(const hodor_ctx *ctx) { return ctx ? ctx->host_round_trips.load() : 0; }
-extern "C" void hodor_ctx_reset_host_round_trips(hodor_ctx *ctx) { if (ctx) ctx->host_round_trips.store(0); }
+extern "C" void hodor_ctx_reset_host_round_trips(hodor_ctx *ctx)
+{
+    if (!ctx) return;
+    ctx->host_round_trips.store(0);
+    ctx->h2d_bytes.store(0);
+    ctx->d2h_bytes.store(0);
+}
 extern "C" int hodor_ctx_trim(hodor_ctx *ctx)
 {
     NEED_DEVICE();
     pool_drain(ctx);
+    host_images_drain(ctx);
     return HODOR_OK;
 }
 extern "C" int hodor_ctx_pool_stats(const hodor_ctx *ctx_, size_t *cached, size_t *live)
@@ -316,8 +437,11 @@ extern "C" int hodor_poly_new_for_size_h(hodor_ctx *ctx, int form, size_t size, 
         hodor_poly_free_h(p);
         return HODOR_ERR_DEVICE;
     }
-    p->host.assign(p->n <= 64 ? p->n : 0, hodor_fr{{0, 0, 0, 0}});   // a small zero polynomial is known on the host too
-    p->host_valid = p->n <= 64;
+    if (p->n <= 64 && p->host.reserve(ctx, p->n) == HODOR_OK) {   // a small zero polynomial is known on the host too
+        memset(p->host.data(), 0, p->n * 32);
+        p->host_valid = true;
+    }
+    p->all_zero = true;
     *out = p;
     return HODOR_OK;
 }
@@ -348,8 +472,8 @@ extern "C" int hodor_poly_from_host_h(hodor_ctx *ctx, int form, const hodor_fr *
         hodor_poly_free_h(p);
         return HODOR_ERR_DEVICE;
     }
-    if (p->n <= 64) {   // small polynomials (the degree-one q(x) of calculate_deep) stay readable without a round trip
-        p->host.assign(p->n, hodor_fr{{0, 0, 0, 0}});
+    if (p->n <= 64 && p->host.reserve(ctx, p->n) == HODOR_OK) {   // small polynomials (the degree-one q(x) of calculate_deep) stay readable without a round trip
+        memset(p->host.data(), 0, p->n * 32);
         if (len) memcpy(p->host.data(), host, len * 32);
         p->host_valid = true;
     }
@@ -412,7 +536,11 @@ extern "C" int hodor_poly_clone_h(const hodor_poly *src, hodor_poly **out)
     int rc = poly_make(ctx, src->form, src->n, &p);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(p->d(), src->d(), src->n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-    if (src->host_valid) { p->host = src->host; p->host_valid = true; }
+    if (src->host_valid && src->n <= 64 && p->host.reserve(ctx, src->n) == HODOR_OK) {   // small ones stay known on the host
+        memcpy(p->host.data(), src->host.data(), src->n * 32);
+        p->host_valid = true;
+    }
+    p->all_zero = src->all_zero;
     *out = p;
     return HODOR_OK;
 }
@@ -430,6 +558,7 @@ extern "C" int hodor_poly_form_h(const hodor_poly *p) { return p ? p->form : -1;
 extern "C" void *hodor_poly_dev_ptr_h(hodor_poly *p)
 {
     if (!p) return nullptr;
+    if (p->host_dirty && poly_flush(p)) return nullptr;   // pending as_mut() writes first
     p->touch();            // the caller may write through it
     return p->d();
 }
@@ -444,34 +573,73 @@ extern "C" int hodor_poly_info_h(const hodor_poly *p, hodor_poly_info *out)
     return HODOR_OK;
 }
 
-extern "C" int hodor_poly_as_ref_h(hodor_poly *p, const hodor_fr **host)
+// the host image brought up to date (as_ref, as_mut): nothing to do while it is valid or dirty (then it IS the vector)
+static int poly_materialise(hodor_poly *p)
 {
-    POLY_ENTRY(p);
-    if (!host) return HODOR_ERR_INVALID;
-    if (!p->host_valid) {
-        try {
-            p->host.resize(p->n);
-        } catch (...) {   // no exception crosses the ABI: a host copy of a vector that large is simply refused
-            set_err(ctx, "as_ref: no host memory for a copy of the polynomial");
-            return HODOR_ERR_INVALID;
-        }
+    hodor_ctx *ctx = p->ctx;
+    if (p->host_valid || p->host_dirty) return HODOR_OK;
+    if (p->host.reserve(ctx, p->n)) {   // no exception crosses the ABI: a host copy of a vector that large is simply refused
+        set_err(ctx, "as_ref / as_mut: no host memory for a copy of the polynomial");
+        return HODOR_ERR_INVALID;
+    }
+    if (p->all_zero) {   // Polynomial::new_for_size(..) followed by as_mut() (src/ali/per_register/mod.rs:112-118): zeros need no PCIe
+        memset(p->host.data(), 0, p->n * 32);
+    } else {
         HostXfer xfer(ctx, ctx->stream);
         HIPCHK(xfer.d2h(p->host.data(), p->d(), p->n * 32));
         HIPCHK(xfer.finish());
         note_round_trip(ctx);
-        p->host_valid = true;
     }
+    p->host_valid = true;
+    return HODOR_OK;
+}
+
+extern "C" int hodor_poly_as_ref_h(hodor_poly *p, const hodor_fr **host)
+{
+    POLY_ENTRY_HOST(p);
+    if (!host) return HODOR_ERR_INVALID;
+    int rc = poly_materialise(p);
+    if (rc) return rc;
     *host = p->host.data();
     return HODOR_OK;
 }
 
+// as_mut() :46 — the whole vector as `&mut [F]` on the host.  The image is materialised like as_ref()'s (one download,
+// none for a polynomial that is still new_for_size's zeros) and is THE vector from now on; it goes back to the device in
+// one upload when hodor_poly_commit_mut_h is called or, failing that, before the next operation on the handle that
+// needs the device copy.  *host stays valid until the handle is freed or resized.
+extern "C" int hodor_poly_as_mut_h(hodor_poly *p, hodor_fr **host)
+{
+    POLY_ENTRY_HOST(p);
+    if (!host) return HODOR_ERR_INVALID;
+    int rc = poly_materialise(p);
+    if (rc) return rc;
+    p->host_dirty = true;
+    p->host_valid = false;
+    *host = p->host.data();
+    return HODOR_OK;
+}
+
+// the end of the `&mut` borrow: the image is uploaded now (HODOR_OK and nothing to do when no as_mut() is outstanding)
+extern "C" int hodor_poly_commit_mut_h(hodor_poly *p)
+{
+    POLY_ENTRY_HOST(p);
+    return poly_flush(p);
+}
+
+extern "C" void hodor_ctx_host_traffic(const hodor_ctx *ctx, uint64_t *h2d_bytes, uint64_t *d2h_bytes)
+{
+    if (h2d_bytes) *h2d_bytes = ctx ? ctx->h2d_bytes.load() : 0;
+    if (d2h_bytes) *d2h_bytes = ctx ? ctx->d2h_bytes.load() : 0;
+}
+
 extern "C" int hodor_poly_read_h(hodor_poly *p, size_t first, size_t count, hodor_fr *out)
 {
-    POLY_ENTRY(p);
+    POLY_ENTRY_HOST(p);
     if (!out && count) return HODOR_ERR_INVALID;
     if (first > p->n || count > p->n - first) return HODOR_ERR_SIZE;   // the slice index panics
     if (count == 0) return HODOR_OK;
-    if (p->host_valid) {
+    if (p->host_valid || p->host_dirty) {
         memcpy(out, p->host.data() + first, count * 32);
         return HODOR_OK;
     }
@@ -484,10 +652,15 @@ extern "C" int hodor_poly_read_h(hodor_poly *p, size_t first, size_t count, hodo
 
 extern "C" int hodor_poly_write_h(hodor_poly *p, size_t first, size_t count, const hodor_fr *in)
 {
-    POLY_ENTRY(p);
+    POLY_ENTRY_HOST(p);
     if (!in && count) return HODOR_ERR_INVALID;
     if (first > p->n || count > p->n - first) return HODOR_ERR_SIZE;
     if (count == 0) return HODOR_OK;
+    if (p->host_dirty) {   // an as_mut() is outstanding: the image is the vector
+        memcpy(p->host.data() + first, in, count * 32);
+        return HODOR_OK;
+    }
+    p->all_zero = false;
     if (count <= 4) {
         Fr v[4];
         for (size_t i = 0; i < count; i++) v[i] = to_dev(to_h(&in[i]));
@@ -507,9 +680,10 @@ extern "C" int hodor_poly_elem_op_h(hodor_poly *p, size_t index, int op, const h
     if (index >= p->n) return HODOR_ERR_SIZE;
     int rc = hodor_poly_unary_dev(ctx, p->stream(), p->dfr() + index, 1, op, c, e);
     if (rc) return rc;
+    p->all_zero = false;
     if (p->host_valid) {   // the same operation on the host copy (src/ali/per_register/deep.rs:62 works on a 2-element q)
         const HostField &F = ctx->F;
-        HFr v = to_h(&p->host[index]), k = c ? to_h(c) : F.one;
+        HFr v = to_h(&p->host.data()[index]), k = c ? to_h(c) : F.one;
         switch (op) {
         case HODOR_UN_NEGATE: v = F.sub(HFr{{0, 0, 0, 0}}, v); break;
         case HODOR_UN_SQUARE: v = F.mul(v, v); break;
@@ -519,7 +693,7 @@ extern "C" int hodor_poly_elem_op_h(hodor_poly *p, size_t index, int op, const h
         case HODOR_UN_SUB_CONSTANT: v = F.sub(v, k); break;
         default: p->touch(); return HODOR_OK;
         }
-        from_h(v, &p->host[index]);
+        from_h(v, &p->host.data()[index]);
     }
     return HODOR_OK;
 }
@@ -528,6 +702,7 @@ extern "C" int hodor_poly_equal_h(const hodor_poly *a, const hodor_poly *b, int 
 {
     POLY_ENTRY(a);
     if (!b || !equal || b->ctx != ctx) return HODOR_ERR_INVALID;
+    POLY_SYNC(b);
     *equal = 0;
     if (a->form != b->form || a->n != b->n) return HODOR_OK;
     void *flag = nullptr;
@@ -719,6 +894,7 @@ extern "C" int hodor_poly_lde_batch_h(const hodor_poly *const *ps, size_t count,
     bool contiguous = true;
     for (size_t i = 0; i < count; i++) {
         if (!ps[i] || ps[i]->ctx != ctx || ps[i]->n != n) return HODOR_ERR_INVALID;
+        POLY_SYNC(ps[i]);
         NEED_FORM(ps[i], HODOR_FORM_COEFFICIENTS);
         if ((uint8_t *)ps[i]->d() != (uint8_t *)ps[0]->d() + i * n * 32) contiguous = false;
     }
@@ -787,6 +963,7 @@ extern "C" int hodor_poly_binary_h(hodor_poly *a, const hodor_poly *b, int op)
 {
     POLY_ENTRY(a);
     if (!b || b->ctx != ctx) return HODOR_ERR_INVALID;
+    POLY_SYNC(b);
     size_t len;
     int rc = binary_len(ctx, a, b, op, &len);
     if (rc) return rc;
@@ -798,6 +975,7 @@ extern "C" int hodor_poly_add_assign_scaled_h(hodor_poly *a, const hodor_poly *b
 {
     POLY_ENTRY(a);
     if (!b || b->ctx != ctx || !scaling) return HODOR_ERR_INVALID;
+    POLY_SYNC(b);
     size_t len;
     int rc = binary_len(ctx, a, b, HODOR_OP_ADD, &len);
     if (rc) return rc;
@@ -822,6 +1000,83 @@ extern "C" int hodor_poly_degree_one_on_domain_h(hodor_ctx *ctx, size_t n, const
     int rc = poly_make(ctx, HODOR_FORM_VALUES, n, &q);
     if (rc) return rc;
     rc = hodor_poly_degree_one_on_domain_dev(ctx, (void *)ctx->stream, q->dfr(), n, alpha, c, coset);
+    if (rc) { hodor_poly_free_h(q); return rc; }
+    *out = q;
+    return HODOR_OK;
+}
+
+// ALIInstance::from_arp's divisor precompute on the device (src/ali/per_register/mod.rs:60-160; kernel: pointwise.hip
+// k_dense_divisor): out[i] = prod_j (x_i - roots[j]) / (x_i^T - 1), x_i = g w^i, on the coset of the domain of
+// `evaluation_size` points; T = column_size.  The n / T distinct values of x^T - 1 on the coset are inverted here on
+// the host (HODOR_ERR_INVALID when one of them is zero — the reference's batch_inversion would return
+// Err(SynthesisError::Error), :136) and travel with the roots in one small upload.
+extern "C" int hodor_poly_dense_divisor_on_coset_dev(hodor_ctx *ctx, void *stream_, hodor_fr *out, size_t evaluation_size,
+                                                     size_t column_size, const hodor_fr *roots, size_t n_roots)
+{
+    NEED_DEVICE();
+    if (!out || (!roots && n_roots)) return HODOR_ERR_INVALID;
+    uint64_t size;
+    uint32_t log_n;
+    HFr w;
+    if (!is_pow2(evaluation_size) || !is_pow2(column_size) || column_size > evaluation_size ||
+        !ctx->F.domain(evaluation_size, &size, &log_n, &w) || size != evaluation_size) {
+        set_err(ctx, "dense_divisor_on_coset: sizes must be powers of two within the field's two-adicity, column_size <= evaluation_size");
+        return HODOR_ERR_SIZE;
+    }
+    const size_t period = evaluation_size / column_size;
+    if (period > ((size_t)1 << 16) || n_roots > ((size_t)1 << 20)) {
+        set_err(ctx, "dense_divisor_on_coset: evaluation_size / column_size <= 2^16 and at most 2^20 roots");
+        return HODOR_ERR_SIZE;
+    }
+    const HostField &F = ctx->F;
+    std::vector<hodor_fr> small;
+    try {
+        small.resize(period + n_roots);
+    } catch (...) {
+        return HODOR_ERR_INVALID;
+    }
+    const HFr gT = F.pow(F.generator, column_size), wT = F.pow(w, column_size);   // x_i^T = g^T (w^T)^(i mod period)
+    HFr v = gT;
+    for (size_t k = 0; k < period; k++) {
+        HFr inv;
+        if (!F.inverse(F.sub(v, F.one), &inv)) {
+            set_err(ctx, "dense_divisor_on_coset: x^T - 1 vanishes on the coset");
+            return HODOR_ERR_INVALID;
+        }
+        from_h(inv, &small[k]);
+        v = F.mul(v, wT);
+    }
+    if (n_roots) memcpy(small.data() + period, roots, n_roots * 32);
+    hipStream_t stream = pick_stream(ctx, stream_);
+    void *stage = nullptr;
+    size_t got = 0;
+    int rc = pool_alloc(ctx, small.size() * 32, &stage, &got, stream);
+    if (rc) return rc;
+    hipError_t e;
+    {
+        HostXfer xfer(ctx, stream);
+        e = xfer.h2d(stage, small.data(), small.size() * 32);
+        if (e == hipSuccess)
+            e = dense_divisor_launch(stream, (uint4 *)out, evaluation_size, to_dev(w), to_dev(F.generator), (const uint4 *)stage,
+                                     (uint32_t)period, (const uint4 *)stage + 2 * period, (uint32_t)n_roots, ctx->P);
+        hipError_t e2 = xfer.finish();   // the staging bytes have left the pinned buffer (and `small`): nothing of the caller's is referenced after return
+        if (e == hipSuccess) e = e2;
+    }
+    pool_release(ctx, stage, got, stream);
+    HIPCHK(e);
+    return HODOR_OK;
+}
+
+extern "C" int hodor_poly_dense_divisor_on_coset_h(hodor_ctx *ctx, size_t evaluation_size, size_t column_size,
+                                                   const hodor_fr *roots, size_t n_roots, hodor_poly **out)
+{
+    NEED_DEVICE();
+    if (!out) return HODOR_ERR_INVALID;
+    if (!is_pow2(evaluation_size)) { set_err(ctx, "dense_divisor_on_coset: evaluation_size must be a power of two"); return HODOR_ERR_SIZE; }
+    hodor_poly *q = nullptr;
+    int rc = poly_make(ctx, HODOR_FORM_VALUES, evaluation_size, &q);
+    if (rc) return rc;
+    rc = hodor_poly_dense_divisor_on_coset_dev(ctx, (void *)ctx->stream, q->dfr(), evaluation_size, column_size, roots, n_roots);
     if (rc) { hodor_poly_free_h(q); return rc; }
     *out = q;
     return HODOR_OK;
@@ -861,6 +1116,8 @@ extern "C" int hodor_poly_quotient_term_h(hodor_poly *acc, const hodor_poly *f, 
 {
     POLY_ENTRY(acc);
     if (!f || !dinv || f->ctx != ctx || dinv->ctx != ctx || !value) return HODOR_ERR_INVALID;
+    POLY_SYNC(f);
+    POLY_SYNC(dinv);
     NEED_FORM(acc, HODOR_FORM_VALUES);
     NEED_FORM(f, HODOR_FORM_VALUES);
     NEED_FORM(dinv, HODOR_FORM_VALUES);
@@ -887,6 +1144,7 @@ extern "C" int hodor_iop_create_batch_h(const hodor_poly *const *vs, size_t coun
     bool contiguous = true;
     for (size_t i = 0; i < count; i++) {
         if (!vs[i] || vs[i]->ctx != ctx || vs[i]->n != n) return HODOR_ERR_INVALID;
+        POLY_SYNC(vs[i]);
         if ((uint8_t *)vs[i]->d() != (uint8_t *)vs[0]->d() + i * n * 32) contiguous = false;
     }
     const size_t entries = iop_entries(n, combiner);
@@ -980,6 +1238,7 @@ extern "C" int hodor_iop_query_h(hodor_iop *t, const hodor_poly *values, size_t 
     if (!t || !values) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = t->ctx;
     if (values->ctx != ctx) return HODOR_ERR_INVALID;
+    POLY_SYNC(values);
     if (values->n != t->n) { set_err(ctx, "query: the values are not the vector this oracle commits to"); return HODOR_ERR_SIZE; }
     return hodor_iop_query_combined_dev(ctx, (void *)ctx->stream, values->dfr(), t->d(), t->n, t->combiner, natural_index,
                                         values_out, path, path_len);
@@ -1004,6 +1263,7 @@ extern "C" size_t hodor_fri_produce_proof_h(hodor_fri_proto *p, const hodor_poly
                                             size_t natural_first_element_index, uint8_t *buf, size_t cap)
 {
     if (!p || !lde_values || lde_values->ctx != p->ctx || lde_values->n != p->n) return 0;
+    if (lde_values->host_dirty && poly_flush(const_cast<hodor_poly *>(lde_values))) return 0;
     return hodor_fri_produce_proof(p, lde_values->dfr(), natural_first_element_index, buf, cap);
 }
 
@@ -1013,6 +1273,7 @@ extern "C" int hodor_fri_verify_prototype_h(hodor_fri_proto *p, const hodor_poly
     if (!p || !lde_values || lde_values->ctx != p->ctx || lde_values->n != p->n) return HODOR_ERR_INVALID;
     hodor_ctx *ctx = p->ctx;
     NEED_DEVICE();
+    POLY_SYNC(lde_values);
     HIPCHK(hipStreamSynchronize(ctx->stream));   // the walk fetches elements with blocking copies
     return hodor_fri_verify_prototype(p, lde_values->dfr(), natural_element_index, valid);
 }

@@ -37,6 +37,8 @@ hipError_t distribute_powers_launch(hipStream_t, uint4 *a, uint64_t n, const Two
 hipError_t distribute_powers_small_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &g, const FrParams &);
 hipError_t gen_elements_launch(hipStream_t, uint4 *out, uint64_t first, uint64_t count, uint64_t seed,
                                uint64_t top_mask, const Fr &r2, const FrParams &);
+hipError_t dense_divisor_launch(hipStream_t, uint4 *out, uint64_t n, const Fr &w, const Fr &g, const uint4 *inv,
+                                uint32_t period, const uint4 *roots, uint32_t n_roots, const FrParams &);
 hipError_t scale_launch(hipStream_t, uint4 *a, uint64_t n, const Fr &f, const FrParams &);
 hipError_t binary_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, int op, const FrParams &);
 hipError_t add_scaled_launch(hipStream_t, uint4 *a, const uint4 *b, uint64_t n, const Fr &f, const FrParams &);
@@ -204,8 +206,17 @@ struct hodor_ctx {
     size_t pool_cache_cap = (size_t)64 << 30;   // idle bytes kept before blocks go back to HIP (HODOR_POOL_CACHE_GIB)
     std::mutex pool_mu;
     // device -> host results handed out so far (roots, evaluations, query answers, prototypes, as_ref() copies): every one
-    // of them stalls the queue, so a device-resident prover counts them (hodor_ctx_host_round_trips)
+    // of them stalls the queue, so a device-resident prover counts them (hodor_ctx_host_round_trips) — and the bytes that
+    // crossed PCIe in either direction on the library's behalf (hodor_ctx_host_traffic)
     std::atomic<uint64_t> host_round_trips{0};
+    std::atomic<uint64_t> h2d_bytes{0}, d2h_bytes{0};
+    // host images of whole polynomials (as_ref / as_mut of the handle API, abi_poly.hip): pinned allocations from 1 MiB
+    // up — a copy of 128 MiB from pageable memory runs at a fraction of the link rate and has the runtime pin and unpin
+    // the caller's pages around it — recycled by exact size (hipHostMalloc of that size costs tens of milliseconds)
+    std::multimap<size_t, void *> host_free;
+    size_t host_cached = 0;
+    static constexpr size_t HOST_CACHE_CAP = (size_t)2 << 30;
+    std::mutex host_mu;
     // One pinned host buffer for every SMALL device <-> host transfer of the library (HostXfer below): roots, challenges,
     // flags, query answers, prototypes' result blocks.  Why (round 5, the root cause of the suite's intermittent SIGABRT,
     // DESIGN.md §8): an asynchronous copy to or from PAGEABLE host memory makes the runtime pin the pages it touches and
@@ -241,6 +252,7 @@ class HostXfer {
         if (n == 0) return hipSuccess;
         hipError_t e = room(n);
         if (e != hipSuccess) return e;
+        ctx_->d2h_bytes.fetch_add(n, std::memory_order_relaxed);
         if (n > hodor_ctx::PINNED_BYTES) { pending_ = true; return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream_); }
         items_.push_back(Item{host, used_, n});
         e = hipMemcpyAsync((uint8_t *)ctx_->pinned + used_, dev, n, hipMemcpyDeviceToHost, stream_);
@@ -253,6 +265,7 @@ class HostXfer {
         if (n == 0) return hipSuccess;
         hipError_t e = room(n);
         if (e != hipSuccess) return e;
+        ctx_->h2d_bytes.fetch_add(n, std::memory_order_relaxed);
         if (n > hodor_ctx::PINNED_BYTES) { pending_ = true; return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream_); }
         memcpy((uint8_t *)ctx_->pinned + used_, host, n);
         e = hipMemcpyAsync(dev, (uint8_t *)ctx_->pinned + used_, n, hipMemcpyHostToDevice, stream_);
@@ -362,6 +375,7 @@ void pool_release(hodor_ctx *ctx, void *p, size_t bytes, hipStream_t last_user);
 void pool_drain(hodor_ctx *ctx);
 void pool_collect(hodor_ctx *ctx);
 void pool_destroy_events(hodor_ctx *ctx);
+void host_images_drain(hodor_ctx *ctx);   // cached pinned host images of the handle API back to HIP
 static inline void note_round_trip(hodor_ctx *ctx) { ctx->host_round_trips.fetch_add(1, std::memory_order_relaxed); }
 
 // defined in abi.hip (caller holds ctx->mu)

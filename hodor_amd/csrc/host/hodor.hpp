@@ -22,6 +22,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -87,14 +88,44 @@ class Field {
     {
         if (rc) throw SynthesisError(rc, std::string(what) + ": " + hodor_last_error(ctx_));
     }
-    // device -> host results handed out so far (the prover's stalls); synchronize = wait for everything enqueued
+    // device -> host results handed out so far (the prover's stalls) and the bytes that crossed PCIe either way;
+    // synchronize = wait for everything enqueued
     uint64_t host_round_trips() const { return hodor_ctx_host_round_trips(ctx_); }
+    std::pair<uint64_t, uint64_t> host_traffic() const   // (host -> device, device -> host) bytes
+    {
+        uint64_t up = 0, down = 0;
+        hodor_ctx_host_traffic(ctx_, &up, &down);
+        return {up, down};
+    }
     void reset_host_round_trips() const { hodor_ctx_reset_host_round_trips(ctx_); }
     void synchronize() const { check(hodor_ctx_synchronize(ctx_), "synchronize"); }
 
   private:
     hodor_ctx *ctx_ = nullptr;
     hodor_field_info info_;
+};
+
+// src/fft/multicore.rs:16-107 — Worker: `scope(elements, |scope, chunk| ...)` hands the closure a scope to spawn threads
+// on and the chunk size elements / cpus (1 when there are fewer elements than cpus); every spawned thread is joined
+// before scope returns.  The host-side loops of the layers above the boundary (ALI's divisor precompute,
+// src/ali/per_register/mod.rs:116-157) run on it exactly as written.
+class Worker {
+  public:
+    size_t cpus;
+    Worker() : cpus(std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 1) {}
+    explicit Worker(size_t c) : cpus(c ? c : 1) {}                                        // new_with_cpus :26
+    uint32_t log_num_cpus() const { uint32_t r = 0; while (((size_t)1 << (r + 1)) <= cpus) r++; return r; }   // :38
+    size_t get_chunk_size(size_t elements) const { return elements < cpus ? 1 : elements / cpus; }           // :76-87
+    struct Scope {
+        std::vector<std::thread> threads;
+        template <class G> void spawn(G g) { threads.emplace_back(std::move(g)); }
+        ~Scope() { for (auto &t : threads) t.join(); }
+    };
+    template <class Fn> void scope(size_t elements, Fn f) const                                              // :61-74
+    {
+        Scope s;
+        f(s, get_chunk_size(elements));
+    }
 };
 
 // src/domains/mod.rs:14-71
@@ -168,6 +199,38 @@ struct Slice {
     bool operator!=(const std::vector<Fr> &o) const { return !(*this == o); }
 };
 
+// what `&mut [F]` is: the polynomial's host image, writable, for as long as this guard lives — the Rust borrow.  While
+// it lives the image IS the vector; its destructor writes the image back to the device in one upload
+// (hodor_poly_commit_mut_h).  chunks_mut(chunk) = slice::chunks_mut.
+struct MutSlice {
+    Fr *p = nullptr;
+    size_t n = 0;
+    hodor_poly *h = nullptr;
+    MutSlice(Fr *ptr, size_t len, hodor_poly *handle) : p(ptr), n(len), h(handle) {}
+    MutSlice(const MutSlice &) = delete;
+    MutSlice &operator=(const MutSlice &) = delete;
+    MutSlice(MutSlice &&o) noexcept : p(o.p), n(o.n), h(o.h) { o.h = nullptr; }
+    ~MutSlice() { if (h) (void)hodor_poly_commit_mut_h(h); }   // a failed upload leaves the image pending: the next device operation retries and reports
+    size_t size() const { return n; }
+    Fr &operator[](size_t i) const { return p[i]; }
+    Fr *begin() const { return p; }
+    Fr *end() const { return p + n; }
+    struct Chunk {
+        Fr *p;
+        size_t n;
+        Fr *begin() const { return p; }
+        Fr *end() const { return p + n; }
+        size_t size() const { return n; }
+        Fr &operator[](size_t i) const { return p[i]; }
+    };
+    std::vector<Chunk> chunks_mut(size_t chunk) const
+    {
+        std::vector<Chunk> out;
+        for (size_t o = 0; o < n; o += chunk) out.push_back(Chunk{p + o, n - o < chunk ? n - o : chunk});
+        return out;
+    }
+};
+
 // src/polynomials/mod.rs:26-34.  Move-only like the Rust value; clone() is #[derive(Clone)].
 template <class Form>
 class Polynomial {
@@ -222,6 +285,14 @@ class Polynomial {
         const Fr *p = nullptr;
         F->check(hodor_poly_as_ref_h(h, &p), "as_ref");
         return Slice{p, size()};
+    }
+    // as_mut() :46 — the whole vector as `&mut [F]`: one download (none for new_for_size's zeros), the write-back
+    // when the guard goes out of scope.  `poly.as_mut()[1] = F.one();` works on the temporary guard like the Rust line.
+    MutSlice as_mut()
+    {
+        Fr *p = nullptr;
+        F->check(hodor_poly_as_mut_h(h, &p), "as_mut");
+        return MutSlice(p, size(), h);
     }
     std::vector<Fr> into_coeffs() && { return as_ref().to_vec(); }                        // :50
     // as_ref()[i] / as_mut()[i] = v / as_mut()[i].sub_assign(&v) ... without moving the rest of the vector
@@ -374,7 +445,12 @@ inline std::vector<Polynomial<Values>> lde_all(const std::vector<Polynomial<Coef
     return out;
 }
 // (coset_)evaluate_at_domain_for_degree_one (:229-290) of a 2-coefficient polynomial q(x) = c0 + c1 x
-inline Polynomial<Values> evaluate_at_domain_for_degree_one(const Polynomial<Coefficients> &q, size_t domain_size, bool coset = false)
+inline Polynomial<Values> evaluate_at_domain_for_degree_one(const Polynomial<Coefficients> &q, size_t domain_size, bool coset = false);
+inline Polynomial<Values> coset_evaluate_at_domain_for_degree_one(const Polynomial<Coefficients> &q, size_t domain_size)   // :260-290
+{
+    return evaluate_at_domain_for_degree_one(q, domain_size, true);
+}
+inline Polynomial<Values> evaluate_at_domain_for_degree_one(const Polynomial<Coefficients> &q, size_t domain_size, bool coset)
 {
     if (q.size() != 2) throw SynthesisError(HODOR_ERR_SIZE, "evaluate_at_domain_for_degree_one: assert_eq!(self.coeffs.len(), 2)");
     const Fr c0 = q.at(0), c1 = q.at(1);   // a small polynomial built on the host is still known there: no round trip
@@ -383,6 +459,17 @@ inline Polynomial<Values> evaluate_at_domain_for_degree_one(const Polynomial<Coe
     while (n < domain_size) n <<= 1;       // Domain::new_for_size(domain_size) :235
     q.F->check(hodor_poly_degree_one_on_domain_h(q.F->ctx(), n, &c1, &c0, coset ? 1 : 0, &v), "evaluate_at_domain_for_degree_one");
     return Polynomial<Values>(*q.F, v);
+}
+// ALIInstance::from_arp's inverse_divisor_for_dense_constraint_in_coset (src/ali/per_register/mod.rs:60-160) without
+// the two host passes: prod_j (x - roots[j]) / (x^T - 1) on the coset of the evaluation domain, generated on the device
+// (include/hodor_gpu.h: hodor_poly_dense_divisor_on_coset_h).  T = column_size.
+inline Polynomial<Values> dense_divisor_on_coset(const Field &F, size_t evaluation_size, size_t column_size,
+                                                 const std::vector<Fr> &roots)
+{
+    hodor_poly *v = nullptr;
+    F.check(hodor_poly_dense_divisor_on_coset_h(F.ctx(), evaluation_size, column_size, roots.data(), roots.size(), &v),
+            "dense_divisor_on_coset");
+    return Polynomial<Values>(F, v);
 }
 // one DEEP quotient term in one pass (include/hodor_gpu.h: hodor_poly_quotient_term_h) — the fused form of
 // clone / add_constant / scale / mul_assign / add_assign (src/ali/per_register/deep.rs:74-84)

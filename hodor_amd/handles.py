@@ -33,6 +33,7 @@ def _declare(L):
     L.hodor_poly_free_h.restype = None
     L.hodor_iop_free_h.restype = None
     L.hodor_ctx_reset_host_round_trips.restype = None
+    L.hodor_ctx_host_traffic.restype = None
     L._hodor_handles_declared = True
 
 
@@ -168,6 +169,31 @@ class Polynomial:
         n = self.size()
         buf = (C.c_uint64 * (4 * n)).from_address(p.value)
         return np.frombuffer(buf, dtype=np.uint64).reshape(n, 4).copy()
+
+    def as_mut(self):
+        """as_mut() :46 — the WHOLE vector as a writable (n, 4) uint64 view of the library's host image (no copy).  The
+        image is the vector from now on; it is uploaded by commit_mut() or before the handle's next device operation.
+        `with p.mutable() as a:` is the Rust borrow: the write-back happens when the block ends."""
+        p = C.c_void_p()
+        self.ctx._chk(self.ctx.L.hodor_poly_as_mut_h(self.h, C.byref(p)))
+        n = self.size()
+        buf = (C.c_uint64 * (4 * n)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
+
+    def commit_mut(self):
+        self.ctx._chk(self.ctx.L.hodor_poly_commit_mut_h(self.h))
+
+    def mutable(self):
+        poly = self
+
+        class _Borrow:
+            def __enter__(self):
+                return poly.as_mut()
+
+            def __exit__(self, *exc):
+                poly.commit_mut()
+                return False
+        return _Borrow()
 
     def read(self, first, count):
         out = np.zeros((count, 4), dtype=np.uint64)
@@ -428,5 +454,14 @@ def host_round_trips(ctx):
 
 
 def reset_host_round_trips(ctx):
+    """... and the PCIe byte counters"""
     _declare(ctx.L)
     ctx.L.hodor_ctx_reset_host_round_trips(ctx.h)
+
+
+def host_traffic(ctx):
+    """(host -> device bytes, device -> host bytes) the library has moved for this context since creation / reset"""
+    _declare(ctx.L)
+    up, down = C.c_uint64(), C.c_uint64()
+    ctx.L.hodor_ctx_host_traffic(ctx.h, C.byref(up), C.byref(down))
+    return int(up.value), int(down.value)

@@ -276,6 +276,16 @@ int hodor_distribute_powers_dev(hodor_ctx *ctx, void *stream, hodor_fr *a, size_
  * (src/ali/per_register/deep.rs:59-66, :128-135) before their batch inversion. */
 int hodor_poly_degree_one_on_domain_dev(hodor_ctx *ctx, void *stream, hodor_fr *out, size_t n,
                                         const hodor_fr *alpha, const hodor_fr *c, int coset);
+/* The divisor precompute of ALIInstance::from_arp — inverse_divisor_for_dense_constraint_in_coset,
+ * src/ali/per_register/mod.rs:60-160 — as ONE launch: out[i] = prod_j (x_i - roots[j]) / (x_i^T - 1) for x_i = g w^i on the
+ * coset of the `evaluation_size`-point domain (g the multiplicative generator, T = column_size; both powers of two,
+ * evaluation_size / column_size <= 2^16).  The reference fills x_i^T - 1 on the host, batch-inverts and multiplies the
+ * root factors in on the host (two as_mut() passes — hodor_poly_as_mut_h replays them as written); this is the
+ * device-resident form of the same vector: x^T - 1 takes only evaluation_size / column_size distinct values on the
+ * coset, which are inverted on the host.  HODOR_ERR_INVALID when one of them is zero (the reference's batch_inversion
+ * returns Err(SynthesisError::Error)).  `roots` is host memory (n_roots elements, may be 0). */
+int hodor_poly_dense_divisor_on_coset_dev(hodor_ctx *ctx, void *stream, hodor_fr *out, size_t evaluation_size,
+                                          size_t column_size, const hodor_fr *roots, size_t n_roots);
 /* PrecomputedOmegas::new_for_domain — src/precomputations/mod.rs:14-66: for the domain of size
  * n = 1<<log_n with generator w: omegas[i] = w^i (n entries), coset[i] = g*w^i (n entries, g the
  * multiplicative generator), omegas_inv[i] = w^-i (n/2 entries).  A NULL output is skipped. */
@@ -593,7 +603,9 @@ typedef struct { uint32_t exp; hodor_fr omega, omegainv, geninv, minv; } hodor_p
 
 void    *hodor_ctx_stream(hodor_ctx *ctx);                    /* hipStream_t of the handle API, for `_dev` calls beside it */
 uint64_t hodor_ctx_host_round_trips(const hodor_ctx *ctx);    /* device -> host results handed out since creation / reset */
-void     hodor_ctx_reset_host_round_trips(hodor_ctx *ctx);
+void     hodor_ctx_reset_host_round_trips(hodor_ctx *ctx);       /* ... and the traffic counters below */
+/* bytes the library has moved over PCIe for this context, host -> device and device -> host, since creation / reset */
+void     hodor_ctx_host_traffic(const hodor_ctx *ctx, uint64_t *h2d_bytes, uint64_t *d2h_bytes);
 int      hodor_ctx_trim(hodor_ctx *ctx);                      /* cached pool blocks back to HIP (synchronises the device) */
 int      hodor_ctx_pool_stats(const hodor_ctx *ctx, size_t *cached_bytes, size_t *live_bytes);
 
@@ -614,8 +626,19 @@ int hodor_poly_info_h(const hodor_poly *p, hodor_poly_info *out);
 void *hodor_poly_dev_ptr_h(hodor_poly *p);   /* the device buffer (size * 32 bytes); order your own work on hodor_ctx_stream */
 /* as_ref() :42 — a host copy materialised on first use and kept until the polynomial is next modified; *host stays
  * valid until then (or until the handle is freed).  read: as_ref()[first .. first + count] without materialising the
- * rest; write: as_mut()[first ..] = in (:46); elem_op: as_mut()[index].op(c) on the device (HODOR_UN_*; e for POW). */
+ * rest; write: as_mut()[first ..] = in (:46) without materialising anything; elem_op: as_mut()[index].op(c) on the
+ * device (HODOR_UN_*; e for POW). */
 int hodor_poly_as_ref_h(hodor_poly *p, const hodor_fr **host);
+/* as_mut() :46 for the WHOLE vector — what src/ali/per_register/mod.rs:118,139 do (`as_mut().chunks_mut(chunk)` inside a
+ * worker.scope, batch_inversion between the two): *host is the polynomial's host image as `&mut [F]` (size * 32 bytes,
+ * pinned from 1 MiB up), materialised like as_ref()'s — one download; none when the polynomial is still new_for_size's
+ * zeros — and from this call on THE vector: the device copy is stale.  The image goes back in ONE upload when
+ * hodor_poly_commit_mut_h is called (the end of the Rust borrow: a guard's Drop) or, failing that,
+ * before the next operation on the handle that needs the device copy; as_ref / read / write work on the image meanwhile.
+ * *host stays valid until the handle is freed or resized; writes through it after the write-back and before the next
+ * hodor_poly_as_mut_h are lost (in Rust the borrow has ended and the compiler refuses them). */
+int hodor_poly_as_mut_h(hodor_poly *p, hodor_fr **host);
+int hodor_poly_commit_mut_h(hodor_poly *p);
 int hodor_poly_read_h(hodor_poly *p, size_t first, size_t count, hodor_fr *out);
 int hodor_poly_write_h(hodor_poly *p, size_t first, size_t count, const hodor_fr *in);
 int hodor_poly_elem_op_h(hodor_poly *p, size_t index, int op, const hodor_fr *c, uint64_t e);
@@ -650,6 +673,9 @@ int hodor_poly_evaluate_at_h(hodor_poly *p, const hodor_fr *g, hodor_fr *out);  
 /* (coset_)evaluate_at_domain_for_degree_one (:229-290) of q(x) = c + alpha x on the size-n domain: a Values handle */
 int hodor_poly_degree_one_on_domain_h(hodor_ctx *ctx, size_t n, const hodor_fr *alpha, const hodor_fr *c, int coset,
                                       hodor_poly **out);
+/* hodor_poly_dense_divisor_on_coset_dev as a new Values handle of evaluation_size elements */
+int hodor_poly_dense_divisor_on_coset_h(hodor_ctx *ctx, size_t evaluation_size, size_t column_size, const hodor_fr *roots,
+                                        size_t n_roots, hodor_poly **out);
 /* Values: pow / square / add_constant / batch_inversion (:744-771, :831-841, :889-954) */
 int hodor_poly_pow_h(hodor_poly *p, uint64_t e);
 int hodor_poly_square_h(hodor_poly *p);

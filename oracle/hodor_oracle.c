@@ -422,6 +422,59 @@ void o_parallel_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_
     free(tmp);
 }
 
+/* parallel_fft_radix_4 — src/fft/radix4_fft/mod.rs:125-184: parallel_fft's split (the naive length-P DFT shuffle, :146-159,
+ * the un-shuffle, :168-183) with serial_fft_radix_4 on the sub-sequences (:162); log_n and log_cpus even (:136-137). */
+static void pfft4_shuffle(void *vctx, size_t j, size_t start, size_t len)
+{
+    (void)start; (void)len;
+    pfft_ctx *c = (pfft_ctx *)vctx;
+    const ofield *f = c->f;
+    size_t num_cpus = (size_t)1 << c->log_cpus, new_n = (size_t)1 << c->log_new_n;
+    ofr *tmp = c->tmp[j];
+    ofr omega_j, omega_step;
+    ofr_pow(f, &omega_j, c->omega, j);
+    ofr_pow(f, &omega_step, c->omega, (uint64_t)j << c->log_new_n);
+    ofr elt = f->r;
+    for (size_t i = 0; i < new_n; i++) {
+        for (size_t s = 0; s < num_cpus; s++) {
+            size_t idx = i + (s << c->log_new_n);                       /* :152 (no wrap: idx < n) */
+            ofr t = c->a[idx];
+            ofr_mul(f, &t, &elt);
+            ofr_add(f, &tmp[i], &t);
+            ofr_mul(f, &elt, &omega_step);
+        }
+        ofr_mul(f, &elt, &omega_j);
+    }
+    o_serial_fft_radix_4(f, tmp, new_n, &c->new_omega, c->log_new_n);   /* :162 */
+}
+
+int o_parallel_fft_radix_4(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, uint32_t log_cpus)
+{
+    if (log_n < log_cpus || (log_n & 1) || (log_cpus & 1)) return -1;   /* asserts :133-137 */
+    size_t num_cpus = (size_t)1 << log_cpus;
+    uint32_t log_new_n = log_n - log_cpus;
+    ofr **tmp = (ofr **)malloc(num_cpus * sizeof(ofr *));
+    for (size_t j = 0; j < num_cpus; j++) tmp[j] = (ofr *)calloc((size_t)1 << log_new_n, sizeof(ofr));
+    pfft_ctx c = {f, a, tmp, omega, {{0}}, log_n, log_cpus, log_new_n};
+    ofr_pow(f, &c.new_omega, omega, num_cpus);                          /* :142 */
+    worker_scope((uint32_t)num_cpus, num_cpus, pfft4_shuffle, &c);
+    punshuf_ctx u = {a, tmp, log_cpus};
+    worker_scope((uint32_t)num_cpus, n, pfft_unshuffle, &u);
+    for (size_t j = 0; j < num_cpus; j++) free(tmp[j]);
+    free(tmp);
+    return 0;
+}
+
+/* best_fft of the radix-4 module — src/fft/radix4_fft/mod.rs:5-20: log_cpus rounded down to even (:8-12) */
+int o_best_fft_radix_4(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, uint32_t cpus)
+{
+    if (log_n & 1) return -1;                                           /* assert :7 */
+    uint32_t log_cpus = log2_floor(cpus < 1 ? 1 : cpus);
+    if (log_cpus & 1) log_cpus -= 1;
+    if (log_n <= log_cpus) { o_serial_fft_radix_4(f, a, n, omega, log_n); return 0; }
+    return o_parallel_fft_radix_4(f, a, n, omega, log_n, log_cpus);
+}
+
 /* best_fft — src/fft/fft.rs:5-19 with use_cpus_hint = None */
 void o_best_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, uint32_t cpus)
 {
@@ -564,6 +617,65 @@ void o_serial_lde(const ofield *f, ofr *a, size_t n_, const ofr *omega, uint32_t
         step++;
         m *= 2;
     }
+}
+
+/* parallel_lde — src/fft/lde.rs:128-193: parallel_fft's split with the zero tail skipped in the shuffle (only
+ * idx < a.len() / lde_factor contributes, :151-157) and, on the sub-sequences, serial_lde with the factor that is left
+ * (lde_factor >> log_cpus, :163-168) or plain serial_fft when none is. */
+typedef struct { pfft_ctx p; size_t non_trivial_len, lde_factor; } plde_ctx;
+
+static void plde_shuffle(void *vctx, size_t j, size_t start, size_t len)
+{
+    (void)start; (void)len;
+    plde_ctx *lc = (plde_ctx *)vctx;
+    pfft_ctx *c = &lc->p;
+    const ofield *f = c->f;
+    size_t num_cpus = (size_t)1 << c->log_cpus, new_n = (size_t)1 << c->log_new_n;
+    ofr *tmp = c->tmp[j];
+    ofr omega_j, omega_step;
+    ofr_pow(f, &omega_j, c->omega, j);
+    ofr_pow(f, &omega_step, c->omega, (uint64_t)j << c->log_new_n);
+    ofr elt = f->r;
+    for (size_t i = 0; i < new_n; i++) {
+        for (size_t s = 0; s < num_cpus; s++) {
+            size_t idx = (i + (s << c->log_new_n)) % ((size_t)1 << c->log_n);   /* :150 */
+            if (idx < lc->non_trivial_len) {                                    /* :151 */
+                ofr t = c->a[idx];
+                ofr_mul(f, &t, &elt);
+                ofr_add(f, &tmp[i], &t);
+            }
+            ofr_mul(f, &elt, &omega_step);
+        }
+        ofr_mul(f, &elt, &omega_j);
+    }
+    size_t new_lde_factor = lc->lde_factor >> c->log_cpus;                      /* :163 */
+    if (new_lde_factor <= 1) o_serial_fft(f, tmp, new_n, &c->new_omega, c->log_new_n);
+    else o_serial_lde(f, tmp, new_n, &c->new_omega, c->log_new_n, new_lde_factor);
+}
+
+int o_parallel_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, uint32_t log_cpus, size_t lde_factor)
+{
+    if (log_n < log_cpus || lde_factor == 0) return -1;                         /* assert :137 */
+    size_t num_cpus = (size_t)1 << log_cpus;
+    uint32_t log_new_n = log_n - log_cpus;
+    ofr **tmp = (ofr **)malloc(num_cpus * sizeof(ofr *));
+    for (size_t j = 0; j < num_cpus; j++) tmp[j] = (ofr *)calloc((size_t)1 << log_new_n, sizeof(ofr));
+    plde_ctx c = {{f, a, tmp, omega, {{0}}, log_n, log_cpus, log_new_n}, n / lde_factor, lde_factor};   /* :144 */
+    ofr_pow(f, &c.p.new_omega, omega, num_cpus);
+    worker_scope((uint32_t)num_cpus, num_cpus, plde_shuffle, &c);
+    punshuf_ctx u = {a, tmp, log_cpus};
+    worker_scope((uint32_t)num_cpus, n, pfft_unshuffle, &u);
+    for (size_t j = 0; j < num_cpus; j++) free(tmp[j]);
+    free(tmp);
+    return 0;
+}
+
+/* best_lde — src/fft/lde.rs:4-13 */
+int o_best_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, size_t lde_factor, uint32_t cpus)
+{
+    uint32_t log_cpus = log2_floor(cpus < 1 ? 1 : cpus);
+    if (log_n <= log_cpus) { o_serial_lde(f, a, n, omega, log_n, lde_factor); return 0; }
+    return o_parallel_lde(f, a, n, omega, log_n, log_cpus, lde_factor);
 }
 
 /* distribute_powers — src/fft/mod.rs:110-123 */

@@ -79,6 +79,15 @@ void o_best_dit_fft(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_
                     uint32_t cpus, size_t non_zero_entries_count);                               /* :114-123 */
 void o_serial_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
                   size_t lde_factor);                                                            /* src/fft/lde.rs:15-126 */
+/* round 6: the remaining parallel forms (-1: the reference's asserts on log_n / log_cpus fail) */
+int  o_parallel_fft_radix_4(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                            uint32_t log_cpus);                                                  /* src/fft/radix4_fft/mod.rs:125-184 */
+int  o_best_fft_radix_4(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n,
+                        uint32_t cpus);                                                          /* src/fft/radix4_fft/mod.rs:5-20 */
+int  o_parallel_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, uint32_t log_cpus,
+                    size_t lde_factor);                                                          /* src/fft/lde.rs:128-193 */
+int  o_best_lde(const ofield *f, ofr *a, size_t n, const ofr *omega, uint32_t log_n, size_t lde_factor,
+                uint32_t cpus);                                                                  /* src/fft/lde.rs:4-13 */
 void o_distribute_powers(const ofield *f, ofr *a, size_t n, const ofr *g, uint32_t cpus);       /* src/fft/mod.rs:110-123 */
 void o_naive_dft(const ofield *f, const ofr *in, ofr *out, size_t n, const ofr *omega);         /* definition, O(n^2) */
 

@@ -7,12 +7,16 @@
 // answers, and the library counts those round trips.
 //
 // The synthetic trace and constraint system are those of tests/prove_shape_ref.py (same SplitMix64 streams, same
-// operation order: tests/ali_replay_ref.py = calculate_g, src/ali/per_register/mod.rs:402-526; tests/deep_replay_ref.py
-// = calculate_deep, src/ali/per_register/deep.rs:14-146), so the proof bytes written here must equal the bytes the CPU
-// oracle assembles for the same shape (tests/test_gpu_prove_shape.py, bench/prove_shape.py).
+// operation order: tests/ali_replay_ref.py = from_arp + calculate_g, src/ali/per_register/mod.rs:36-526;
+// tests/deep_replay_ref.py = calculate_deep, src/ali/per_register/deep.rs:14-146), so the proof bytes written here must
+// equal the bytes the CPU oracle assembles for the same shape (tests/test_gpu_prove_shape.py, bench/prove_shape.py).
+// Since round 6 the value-form inputs of calculate_g are the REAL ones: ALIInstance::from_arp's inverse divisors,
+// boundary divisors and adjustment polynomials (tests/host_cpp/ali_instance.hpp), AS WRITTEN in the reference through
+// Polynomial::as_mut() (ali_mode 0) or device-resident (ali_mode 1) — same proof bytes either way.
 //
-//   prove_shape <log_rows> <registers> <lde_factor> <combiner 0|1> <out.bin> [reps=1] [sync_phases=0]
-// prints one JSON line: total / per-phase milliseconds (median run), host round trips, proof size.
+//   prove_shape <log_rows> <registers> <lde_factor> <combiner 0|1> <out.bin> [reps=1] [sync_phases=0] [ali_mode=0]
+// prints one JSON line: total / per-phase milliseconds (median run), host round trips and PCIe bytes of one proof and of
+// the from_arp precompute before it, proof size.
 // Build: g++ -O2 -std=c++17 prove_shape.cpp -L<repo>/hodor_amd -lhodor_gpu
 #include <algorithm>
 #include <chrono>
@@ -20,37 +24,41 @@
 #include <cstdlib>
 #include <map>
 
-#include "../../hodor_amd/csrc/host/hodor.hpp"
+#include "ali_instance.hpp"
 
 using namespace hodor;
 
 static const uint64_t BN256_FR[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
 static const char *PHASES[] = {"Witness polys", "F LDEs", "F oracles", "G poly", "G LDE", "G oracle", "H1 and H2", "FRI", "queries"};
-static const size_t G_FACTOR = 4;            // constraint domain = 4 x trace domain
+static const size_t G_FACTOR = ali::MAX_CONSTRAINT_POWER;   // constraint domain = 4 x trace domain
 static const uint64_t SEED = 0x50524F56;     // tests/prove_shape_ref.py:make_trace
 
 typedef Polynomial<Coefficients> PolyC;
 typedef Polynomial<Values> PolyV;
 
-struct Prep {   // the value-form inputs ALI prepares + fixed scalars (prove_shape_ref.make_trace)
+struct Prep {   // ALIInstance::from_arp's vectors + fixed scalars (prove_shape_ref.make_trace)
     Fr coeff, constant[2], boundary_value, masks[2];
-    PolyV adj, divisors, boundary_divisors;
+    ali::ALIInstance instance;
 };
 
 static void put64(std::vector<uint8_t> &o, uint64_t v) { for (int b = 0; b < 8; b++) o.push_back((uint8_t)(v >> (8 * b))); }
 static void put(std::vector<uint8_t> &o, const void *p, size_t n) { o.insert(o.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
 
-// ALI's calculate_g (src/ali/per_register/mod.rs:402-526) on the synthetic constraint system of tests/ali_replay_ref.py
+// ALI's calculate_g (src/ali/per_register/mod.rs:246-526) on the synthetic constraint system of tests/ali_replay_ref.py
+// (calculate_g_for_instance): two challenges per constraint drawn from the transcript as the reference draws them
 struct Term { int reg; uint64_t power; int kind; };   // kind: 0 one, 1 minus_one, 2 scale
-static PolyC calculate_g(const Field &F, const std::vector<PolyC> &witness, const Prep &P, const Fr &alpha)
+static PolyC calculate_g(const Field &F, Transcript &transcript, const std::vector<PolyC> &witness, const Prep &P)
 {
     const Term c0[] = {{0, 2, 2}, {1, 1, 1}}, c1[] = {{1, 3, 0}, {0, 1, 2}};
     const Term *constraints[2] = {c0, c1};
-    const bool adjust[2] = {true, false};
-    const size_t big = witness[0].size() * G_FACTOR;
-    PolyV g = PolyV::new_for_size(F, big), batch = PolyV::new_for_size(F, big);
+    const uint64_t degree[2] = {2, 4};
+    const ali::ALIInstance &I = P.instance;
+    const size_t big = (size_t)I.constraints_domain.size;
+    PolyV g = PolyV::new_for_size(F, big), batch = PolyV::new_for_size(F, big);              // :249, :427
     for (int ci = 0; ci < 2; ci++) {
-        PolyV cv = PolyV::new_for_size(F, big);
+        const uint64_t adjustment = I.max_constraint_power - degree[ci];                   // :431
+        const Fr alpha = transcript.get_challenge(), beta = transcript.get_challenge();    // :432-433
+        PolyV cv = PolyV::new_for_size(F, big);                                            // :451
         for (int t = 0; t < 2; t++) {
             const Term &term = constraints[ci][t];
             PolyV base = coset_lde(witness[term.reg], G_FACTOR);      // :402-417
@@ -60,17 +68,23 @@ static PolyC calculate_g(const Field &F, const std::vector<PolyC> &witness, cons
             cv.add_assign(base);                                      // :455-463
         }
         cv.add_constant(P.constant[ci]);                              // :465
-        if (adjust[ci]) cv.mul_assign(P.adj); else cv.scale(alpha);   // :466-471
+        if (adjustment) cv.mul_assign(I.calculate_adjustment_polynomial_in_coset(F, adjustment, alpha, beta));   // :435-449, :467
+        else cv.scale(alpha);                                         // :470
         batch.add_assign(cv);                                         // :473
     }
-    batch.mul_assign(P.divisors);                                     // :476
+    batch.mul_assign(I.constraint_divisors);                          // :476-478
     g.add_assign(batch);                                              // :480
-    PolyC w = witness[0].clone();                                     // boundary constraint :486-521
-    w.sub_assign_at(0, P.boundary_value);
-    PolyV cv = coset_lde(w, G_FACTOR);
-    cv.scale(alpha);
-    cv.mul_assign(P.boundary_divisors);
-    g.add_assign(cv);
+    for (const ali::BoundaryConstraint &b_c : ali::BOUNDARY) {        // :486-521
+        const Fr alpha = transcript.get_challenge(), beta = transcript.get_challenge();
+        const uint64_t adjustment = I.max_constraint_power - 1;
+        PolyC w = witness[b_c.reg].clone();
+        w.sub_assign_at(0, P.boundary_value);                         // witness_poly.as_mut()[0].sub_assign(&value) :511 (one element: on the device)
+        PolyV cv = coset_lde(w, G_FACTOR);
+        if (adjustment) cv.mul_assign(I.calculate_adjustment_polynomial_in_coset(F, adjustment, alpha, beta));
+        else cv.scale(alpha);
+        cv.mul_assign(I.boundary_constraint_divisors.at(b_c.at_row));
+        g.add_assign(cv);
+    }
     return icoset_fft(std::move(g));                                  // :523
 }
 
@@ -159,11 +173,10 @@ static std::vector<uint8_t> prove(const Field &F, const std::vector<PolyV> &trac
     for (auto &r : f_iop_roots) T.commit_bytes(r);
     clk.lap("F oracles");
     // G poly (:87), G LDE (:89), G oracle (:91-93)
-    const Fr alpha = T.get_challenge();
     std::vector<PolyC> two;
     two.push_back(w_polys[0].clone());
     two.push_back(w_polys[1].clone());
-    PolyC g_poly = calculate_g(F, two, P, alpha);
+    PolyC g_poly = calculate_g(F, T, two, P);
     clk.lap("G poly");
     PolyV g_lde = lde(g_poly, lde_factor);
     clk.lap("G LDE");
@@ -210,15 +223,16 @@ static std::vector<uint8_t> prove(const Field &F, const std::vector<PolyV> &trac
 
 int main(int argc, char **argv)
 {
-    if (argc < 6) { fprintf(stderr, "usage: %s log_rows registers lde_factor combiner out.bin [reps] [sync_phases]\n", argv[0]); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: %s log_rows registers lde_factor combiner out.bin [reps] [sync_phases] [ali_mode]\n", argv[0]); return 2; }
     const unsigned log_rows = (unsigned)atoi(argv[1]);
     const size_t registers = (size_t)atoi(argv[2]), lde_factor = (size_t)atoi(argv[3]);
     const int combiner = atoi(argv[4]);
     const int reps = argc > 6 ? atoi(argv[6]) : 1;
     const bool sync_phases = argc > 7 && atoi(argv[7]) != 0;
+    const int ali_mode = argc > 8 ? atoi(argv[8]) : 0;   // 0: from_arp as written (as_mut), 1: device-resident precompute
     try {
         Field F(BN256_FR, 7, 0);
-        const size_t n = (size_t)1 << log_rows, big = n * G_FACTOR;
+        const size_t n = (size_t)1 << log_rows;
         std::vector<PolyV> trace;
         for (size_t r = 0; r < registers; r++) trace.push_back(PolyV::generated(F, 0, n, SEED + r));
         Prep P;
@@ -226,13 +240,26 @@ int main(int argc, char **argv)
             auto sc = PolyV::generated(F, 0, 6, SEED + 100).as_ref().to_vec();   // 8 entries, the last two are padding
             P.coeff = sc[0]; P.constant[0] = sc[1]; P.constant[1] = sc[2]; P.boundary_value = sc[3]; P.masks[0] = sc[4]; P.masks[1] = sc[5];
         }
-        P.adj = PolyV::generated(F, 0, big, SEED + 101);
-        P.divisors = PolyV::generated(F, 0, big, SEED + 102);
-        P.boundary_divisors = PolyV::generated(F, 0, big, SEED + 103);
+        // ALIInstance::from_arp (instance setup, before the proof): timed and metered on its own
+        Worker worker;
+        double from_arp_ms[2] = {0, 0};
+        uint64_t from_arp_trips = 0;
+        std::pair<uint64_t, uint64_t> from_arp_bytes;
+        for (int rep = 0; rep < 2; rep++) {   // run 0 warms the pool, the pinned host images and the tables
+            F.synchronize();
+            F.reset_host_round_trips();
+            auto t0 = std::chrono::steady_clock::now();
+            P.instance = ali::ALIInstance::from_arp(F, n, worker, ali_mode != 0);
+            F.synchronize();
+            from_arp_ms[rep] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            from_arp_trips = F.host_round_trips();
+            from_arp_bytes = F.host_traffic();
+        }
 
         std::vector<uint8_t> proof;
         std::vector<std::pair<double, std::map<std::string, double>>> runs;
         uint64_t trips = 0;
+        std::pair<uint64_t, uint64_t> bytes;
         for (int rep = 0; rep < reps + 1; rep++) {   // run 0 warms the twiddle tables, the pool and the FRI slab
             Clock clk{F, sync_phases, {}, {}};
             F.synchronize();
@@ -243,6 +270,7 @@ int main(int argc, char **argv)
             F.synchronize();
             double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             trips = F.host_round_trips();
+            bytes = F.host_traffic();
             if (rep == 0) proof = got;
             else if (got != proof) { fprintf(stderr, "the run is not deterministic\n"); return 1; }
             if (rep > 0 || reps == 0) runs.emplace_back(total, clk.ms);
@@ -255,10 +283,15 @@ int main(int argc, char **argv)
         auto &med = runs[runs.size() / 2];
         size_t cached = 0, live = 0;
         hodor_ctx_pool_stats(F.ctx(), &cached, &live);
-        printf("{\"log_rows\": %u, \"registers\": %zu, \"lde_factor\": %zu, \"combiner\": %d, \"proof_bytes\": %zu, \"reps\": %d, "
-               "\"sync_phases\": %s, \"total_ms\": %.3f, \"best_ms\": %.3f, \"host_round_trips\": %llu, \"pool_gib\": %.2f, \"phases_ms\": {",
-               log_rows, registers, lde_factor, combiner, proof.size(), reps, sync_phases ? "true" : "false", med.first,
-               runs[0].first, (unsigned long long)trips, (double)(cached + live) / (1ull << 30));
+        printf("{\"log_rows\": %u, \"registers\": %zu, \"lde_factor\": %zu, \"combiner\": %d, \"ali_mode\": \"%s\", \"proof_bytes\": %zu, \"reps\": %d, "
+               "\"sync_phases\": %s, \"total_ms\": %.3f, \"best_ms\": %.3f, \"host_round_trips\": %llu, \"h2d_bytes\": %llu, \"d2h_bytes\": %llu, "
+               "\"from_arp\": {\"ms_cold\": %.3f, \"ms\": %.3f, \"host_threads\": %zu, \"host_round_trips\": %llu, \"h2d_bytes\": %llu, \"d2h_bytes\": %llu}, "
+               "\"pool_gib\": %.2f, \"phases_ms\": {",
+               log_rows, registers, lde_factor, combiner, ali_mode ? "device-resident" : "as written (as_mut)", proof.size(), reps,
+               sync_phases ? "true" : "false", med.first, runs[0].first, (unsigned long long)trips, (unsigned long long)bytes.first,
+               (unsigned long long)bytes.second, from_arp_ms[0], from_arp_ms[1], worker.cpus, (unsigned long long)from_arp_trips,
+               (unsigned long long)from_arp_bytes.first, (unsigned long long)from_arp_bytes.second,
+               (double)(cached + live) / (1ull << 30));
         for (size_t i = 0; i < 9; i++) printf("%s\"%s\": %.3f", i ? ", " : "", PHASES[i], med.second[PHASES[i]]);
         printf("}, \"runs_ms\": [");
         for (size_t i = 0; i < runs.size(); i++) printf("%s%.3f", i ? ", " : "", runs[i].first);

@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "../../hodor_amd/csrc/host/hodor.hpp"
+#include "ali_instance.hpp"
 
 using namespace hodor;
 
@@ -461,6 +461,69 @@ static void test_sixstep_two_ranks(const Field &F)
         for (int b = 0; b < 4; b++) hodor_buf_free(F.ctx(), dev[q][b]);
 }
 
+// Polynomial::as_mut() (src/polynomials/mod.rs:46) for the whole slice and ALIInstance::from_arp's divisor precompute
+// (src/ali/per_register/mod.rs:36-244) AS WRITTEN on top of it — worker.scope + as_mut().chunks_mut(), batch_inversion,
+// as_mut().chunks_mut() again — against (a) the closed form evaluated on the host element by element and (b) the
+// device-resident form of the same vectors (hodor::dense_divisor_on_coset); an instance whose trace fills only part of
+// its column domain (num_rows < column size: several roots) and constraints that start late (start_at > 0) included.
+static void test_as_mut_and_ali_divisors(const Field &F)
+{
+    Worker worker(7);   // an odd worker count: chunks that do not divide the vector evenly (get_chunk_size, multicore.rs:76-87)
+    CHECK(worker.get_chunk_size(3) == 1 && worker.get_chunk_size(64) == 9 && worker.log_num_cpus() == 2);
+    {   // the guard: the image is the vector, the write-back happens when it goes out of scope
+        auto p = Polynomial<Values>::new_for_size(F, 64);
+        F.reset_host_round_trips();
+        {
+            MutSlice s = p.as_mut();
+            CHECK(s.size() == 64);
+            for (size_t i = 0; i < 64; i++) s[i] = F.from_u64(i + 1);
+            CHECK(p.at(5) == F.from_u64(6));              // as_ref()[5] during the borrow reads the image
+        }
+        CHECK(F.host_round_trips() == 0);                 // new_for_size's zeros are not downloaded
+        p.square();
+        for (size_t i = 0; i < 64; i += 9) CHECK(p.at(i) == F.from_u64((i + 1) * (i + 1)));
+        p.as_mut()[3] = F.one();                          // the temporary guard: `p.as_mut()[3] = F::one();`
+        auto q = p.clone();
+        CHECK(q.at(3) == F.one() && q.at(4) == F.from_u64(25) && p == q);
+    }
+    struct Case { uint64_t num_rows; ali::DenseConstraint dc; };
+    const Case cases[] = {{64, {0, 1}}, {64, {2, 3}}, {50, {1, 2}}, {1024, {0, 1}}};
+    for (const Case &c : cases) {
+        Domain column = Domain::new_for_size(F, c.num_rows);
+        Domain evaluation = Domain::new_for_size(F, column.size * ali::MAX_CONSTRAINT_POWER);
+        auto written = ali::inverse_divisor_for_dense_constraint_in_coset(F, column, evaluation, c.dc, c.num_rows, worker);
+        CHECK(written.second == column.size - c.dc.start_at - (column.size - c.num_rows) - c.dc.span);
+        const std::vector<Fr> roots = ali::dense_constraint_roots(F, column, c.dc, c.num_rows);
+        CHECK(roots.size() == c.dc.start_at + (column.size - (c.num_rows - c.dc.span)));
+        auto resident = dense_divisor_on_coset(F, (size_t)evaluation.size, (size_t)column.size, roots);
+        CHECK(written.first == resident);
+        Slice got = written.first.as_ref();
+        Fr x = F.multiplicative_generator();
+        for (size_t i = 0; i < got.size(); i++) {         // prod (x - root) / (x^T - 1), one element at a time
+            Fr d = F.inverse(F.sub(F.pow(x, column.size), F.one()));
+            for (const Fr &r : roots) d = F.mul(d, F.sub(x, r));
+            CHECK(got[i] == d);
+            x = F.mul(x, evaluation.generator);
+        }
+    }
+    for (bool resident : {false, true}) {                 // from_arp, both forms: the same instance
+        auto I = ali::ALIInstance::from_arp(F, 256, worker, resident);
+        auto J = ali::ALIInstance::from_arp(F, 256, Worker(3), !resident);
+        CHECK(I.constraint_divisors == J.constraint_divisors);
+        CHECK(I.boundary_constraint_divisors.at(0) == J.boundary_constraint_divisors.at(0));
+        const Fr alpha = F.from_u64(77), beta = F.from_u64(5);
+        CHECK(I.calculate_adjustment_polynomial_in_coset(F, 3, alpha, beta) == J.calculate_adjustment_polynomial_in_coset(F, 3, alpha, beta));
+        Fr x = F.multiplicative_generator();              // boundary divisor of row 0: 1 / (x - 1)
+        Slice b = I.boundary_constraint_divisors.at(0).as_ref();
+        for (size_t i = 0; i < b.size(); i += 37) {
+            CHECK(F.mul(b[i], F.sub(F.mul(F.pow(I.constraints_domain.generator, i), x), F.one())) == F.one());
+        }
+    }
+    // no vanishing value on the coset is ever met with the field's generator; a zero in the vector is the reference's Err
+    auto z = Polynomial<Values>::new_for_size(F, 8);
+    CHECK(!z.batch_inversion());
+}
+
 int main()
 {
     Field F(BN256_FR, 7, 0);
@@ -478,6 +541,7 @@ int main()
     test_padding_helpers(F);
     test_value_form_methods(F);
     test_batched_ldes_and_oracles(F);
+    test_as_mut_and_ali_divisors(F);
     printf("host_cpp: all tests passed\n");
     return 0;
 }

@@ -27,7 +27,7 @@ import ali_replay_ref as ali
 import deep_replay_ref as deep
 
 PHASES = ["Witness polys", "F LDEs", "F oracles", "G poly", "G LDE", "G oracle", "H1 and H2", "FRI", "queries"]
-G_FACTOR = 4          # constraint domain = 4 x trace domain (cubic constraints, padded to a power of two)
+G_FACTOR = ali.MAX_CONSTRAINT_POWER   # constraint domain = 4 x trace domain (cubic constraints, padded to a power of two)
 
 
 def u64(v):
@@ -39,16 +39,16 @@ def fr_bytes(mont):
 
 
 def make_trace(O, log_rows, registers, seed=0x50524F56):
-    """`registers` columns of 2^log_rows trace values + the value-form inputs ALI prepares (adj, divisors,
-    boundary divisors on the constraint coset) + fixed scalars, all from the SplitMix64 stream."""
+    """`registers` columns of 2^log_rows trace values from the SplitMix64 stream, fixed scalars, and — since round 6 —
+    the vectors ALIInstance::from_arp REALLY precomputes for calculate_g (ali_replay_ref.from_arp: the inverse divisors
+    of the dense constraints, the boundary-constraint divisors, the coset table of the adjustment polynomials), where
+    rounds 3-5 fed synthetic stand-ins."""
     from oracle.oracle import array_to_ints
     n = 1 << log_rows
     trace = [O.gen_elements(0, n, seed + r) for r in range(registers)]
-    big = n * G_FACTOR
     sc = array_to_ints(O.gen_elements(0, 6, seed + 100))
     prep = {"coeff": sc[0], "constant": [sc[1], sc[2]], "boundary_value": sc[3], "masks": [sc[4], sc[5]],
-            "adj": O.gen_elements(0, big, seed + 101), "divisors": O.gen_elements(0, big, seed + 102),
-            "boundary_divisors": O.gen_elements(0, big, seed + 103)}
+            "instance": ali.from_arp(O, n)}
     return trace, prep
 
 
@@ -78,9 +78,7 @@ def prove(ops, trace, prep, lde_factor, clock=None):
         T.commit_bytes(r)
     lap("F oracles")
     # ---- G poly (calculate_g draws its combination challenge from the transcript)
-    consts = dict(prep)
-    consts["alpha"] = ops.challenge(T)
-    g_poly = ali.calculate_g(ops.ali, w_polys[:2], G_FACTOR, consts)
+    g_poly = ali.calculate_g_for_instance(ops.ali, w_polys[:2], prep["instance"], prep, lambda: ops.challenge(T))
     lap("G poly")
     g_lde = ops.lde_all([g_poly], lde_factor)[0]
     lap("G LDE")
@@ -341,5 +339,20 @@ def to_device(trace, prep):
     import torch
 
     def dev(x):
-        return torch.from_numpy(x.view(np.int64).copy()).cuda()
-    return [dev(t) for t in trace], {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in prep.items()}
+        if isinstance(x, np.ndarray):
+            return torch.from_numpy(x.view(np.int64).copy()).cuda()
+        if isinstance(x, dict):
+            return {k: dev(v) for k, v in x.items()}
+        return x
+    return [dev(t) for t in trace], dev(prep)
+
+
+def copy_prep(prep):
+    """a deep copy of make_trace's prep (the provers modify nothing in it, but a test must not have to trust that)"""
+    if isinstance(prep, np.ndarray):
+        return prep.copy()
+    if isinstance(prep, dict):
+        return {k: copy_prep(v) for k, v in prep.items()}
+    if isinstance(prep, list):
+        return [copy_prep(v) for v in prep]
+    return prep

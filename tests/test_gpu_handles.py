@@ -8,7 +8,7 @@ import pytest
 
 import hodor_amd
 from hodor_amd.handles import (COEFFICIENTS, VALUES, FriPrototypeHandle, IopTree, Polynomial, host_round_trips,
-                               reset_host_round_trips)
+                               host_traffic, reset_host_round_trips)
 from oracle import pyref as P
 from oracle.oracle import array_to_ints, ints_to_array
 
@@ -93,6 +93,80 @@ def test_read_write_elem_op_clone_equal(gpu_ctxs, oracles, field_name):
     other_form = Polynomial.from_coeffs(ctx, a)
     assert not (other_form == q)                          # derive(PartialEq) compares the type too
     for x in (p, q, other_form):
+        x.free()
+
+
+@pytest.mark.parametrize("n", [2, 4, 64, 1 << 10, 1 << 16])
+def test_as_mut_is_the_vector_until_it_is_written_back(gpu_ctxs, oracles, field_name, n):
+    """Polynomial::as_mut() (src/polynomials/mod.rs:46) for the WHOLE slice, the way ALI's divisor precompute uses it
+    (src/ali/per_register/mod.rs:112-160: new_for_size -> as_mut().chunks_mut() fill -> batch_inversion ->
+    as_mut().chunks_mut() again): the host image is the vector while the borrow is open, one upload writes it back
+    (explicitly, or before the next device operation), and a polynomial that is still new_for_size's zeros is not
+    downloaded at all."""
+    ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    a = O.random_elements(n, 21)
+    a[a.sum(axis=1) == 0] = 1                              # (no zero element: the vector is inverted below)
+    p = Polynomial.new_for_size(ctx, VALUES, n)
+    reset_host_round_trips(ctx)
+    with p.mutable() as m:                                 # zeros: nothing comes down
+        assert m.shape == (n, 4) and not m.any()
+        m[:] = a
+        assert np.array_equal(p.as_ref(), a)               # as_ref() during the borrow reads the image
+        assert np.array_equal(p.read(1, 1), a[1:2])
+    up, down = host_traffic(ctx)
+    assert down == 0 and host_round_trips(ctx) == 0
+    assert up == (n * 32 if n > 4 else 0)                  # <= 4 elements travel as kernel arguments
+    p.batch_inversion()                                    # (its zero check is a round trip of its own)
+    exp = a.copy()
+    O.poly_batch_inversion(exp)
+    reset_host_round_trips(ctx)
+    m = p.as_mut()                                         # one download of the inverted vector
+    assert np.array_equal(m, exp)
+    assert host_round_trips(ctx) == 1 and host_traffic(ctx) == (0, n * 32)
+    m[0] = a[0]
+    p.write(1, a[1:2])                                     # as_mut()[1] = v while the borrow is open: into the image
+    exp[0], exp[1] = a[0], a[1]
+    q = p.clone()                                          # NO commit_mut(): the next device operation writes back first
+    assert np.array_equal(q.as_ref(), exp) and np.array_equal(p.as_ref(), exp)
+    assert p == q
+    p.square()                                             # ... and the image is stale after a device operation
+    O.poly_unary(exp, "square")
+    assert np.array_equal(p.as_ref(), exp)
+    with p.mutable() as m:
+        m[n - 1] = a[n - 1]
+    exp[n - 1] = a[n - 1]
+    tree_ok = n < 2 or IopTree.create(p).get_root() == bytes(O.iop_create(exp)[1])
+    assert tree_ok
+    assert np.array_equal(p.as_ref(), exp)
+    p.free()
+    q.free()
+
+
+def test_as_mut_of_a_coefficient_polynomial_feeds_the_transform(gpu_ctxs, oracles):
+    """q_poly.as_mut()[1] = F::one(); q_poly.as_mut()[0].sub_assign(&root) (src/ali/per_register/mod.rs:199-202) and a
+    whole coefficient vector written on the host, then lde / fft straight after — the write-back is implicit."""
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << 12
+    a = O.random_elements(n, 22)
+    p = Polynomial.new_for_size(ctx, COEFFICIENTS, n)
+    p.as_mut()[:] = a
+    lde = p.lde(4)
+    assert np.array_equal(lde.as_ref(), O.poly_lde(a, 4))
+    m = p.as_mut()
+    m[::2] = 0
+    exp = a.copy()
+    exp[::2] = 0
+    p.fft()
+    O.poly_fft(exp)
+    assert p.form == VALUES and np.array_equal(p.as_ref(), exp)
+    q = Polynomial.new_for_size(ctx, COEFFICIENTS, 2)
+    one = O.random_elements(1, 23)
+    q.as_mut()[1] = one[0]
+    q.as_mut()[0] = one[0]
+    assert np.array_equal(q.as_ref(), np.stack([one[0], one[0]]))
+    d = q.evaluate_at(_int(one[0]))
+    assert d == O.add(_int(one[0]), O.mul(_int(one[0]), _int(one[0])))
+    for x in (p, q, lde):
         x.free()
 
 
@@ -568,7 +642,9 @@ b = Polynomial.new_for_size(ctx, VALUES, 1 << 16)          # ...so that this one
 assert ctx.pool_stats() == (0, 2 << 20)
 c = Polynomial.new_for_size(ctx, VALUES, 1 << 18)          # 8 MiB
 b.free()
-c.free()                                                   # the older idle block goes, the one just released stays
+c.free()                                                   # the older idle block goes, the one just released stays ...
+assert ctx.pool_stats() == (10 << 20, 0), ctx.pool_stats() # ... but no free() hands memory back to HIP (hipFree drains the device):
+ctx.synchronize()                                          # the evicted block waits for a call that waits anyway
 assert ctx.pool_stats() == (8 << 20, 0), ctx.pool_stats()
 ctx.close()
 print("ok")

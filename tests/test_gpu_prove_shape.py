@@ -15,8 +15,7 @@ def test_prove_shaped_run_is_byte_identical_to_the_cpu_port(gpu_ctxs, oracles, l
     import prove_shape_ref as ps
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     trace, prep = ps.make_trace(O, log_rows, registers)
-    exp, _, exp_marks = ps.prove(ps.OracleProver(O, P.BN256), [t.copy() for t in trace],
-                                 {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in prep.items()}, lde_factor)
+    exp, _, exp_marks = ps.prove(ps.OracleProver(O, P.BN256), [t.copy() for t in trace], ps.copy_prep(prep), lde_factor)
     d_trace, d_prep = ps.to_device(trace, prep)
     dev = ps.DeviceProver(O, ctx)
     got, times, marks = ps.prove(dev, d_trace, d_prep, lde_factor)
@@ -46,7 +45,7 @@ def test_prove_shaped_run_with_coset2_oracles(gpu_ctxs, oracles, log_rows, regis
     import hodor_amd
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     trace, prep = ps.make_trace(O, log_rows, registers)
-    cp = lambda: ([t.copy() for t in trace], {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in prep.items()})
+    cp = lambda: ([t.copy() for t in trace], ps.copy_prep(prep))
     exp, _, exp_marks = ps.prove(ps.OracleProver(O, P.BN256, combiner=1), *cp(), lde_factor)
     triv, _, _ = ps.prove(ps.OracleProver(O, P.BN256), *cp(), lde_factor)
     d_trace, d_prep = ps.to_device(trace, prep)

@@ -15,7 +15,7 @@ def _build(tmp_path):
     hodor_amd.build()
     exe = str(tmp_path / "test_host")
     libdir = os.path.join(ROOT, "hodor_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", SRC, "-L" + libdir, "-lhodor_gpu",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", SRC, "-L" + libdir, "-lhodor_gpu",
                            "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -42,7 +42,7 @@ def _build_prove_shape(tmp_path):
     hodor_amd.build()
     exe = str(tmp_path / "prove_shape")
     libdir = os.path.join(ROOT, "hodor_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", PS_SRC, "-L" + libdir, "-lhodor_gpu",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", PS_SRC, "-L" + libdir, "-lhodor_gpu",
                            "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -51,18 +51,21 @@ def test_prove_shape_replay_compiles_against_the_host_mirror(tmp_path):
     """CPU: the prover-shaped replay uses nothing but hodor.hpp (no `_dev` entry point, device pointer or stream in its
     source) and links against the C ABI alone."""
     assert os.path.exists(_build_prove_shape(tmp_path))
-    src = open(PS_SRC).read()
-    code = "\n".join(l.split("//")[0] for l in src.splitlines())
-    assert "_dev(" not in code and "hipStream" not in code and "dev_ptr" not in code
+    for path in (PS_SRC, os.path.join(ROOT, "tests", "host_cpp", "ali_instance.hpp")):
+        code = "\n".join(l.split("//")[0] for l in open(path).read().splitlines())
+        assert "_dev(" not in code and "hipStream" not in code and "dev_ptr" not in code
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_rows,registers,lde_factor,combiner", [(6, 2, 4, 0), (10, 4, 16, 0), (12, 3, 8, 0), (10, 4, 16, 1)])
-def test_prove_shape_from_cpp_is_byte_identical_to_the_cpu_port(tmp_path, oracles, log_rows, registers, lde_factor, combiner):
+@pytest.mark.parametrize("log_rows,registers,lde_factor,combiner,ali_mode", [
+    (6, 2, 4, 0, 0), (10, 4, 16, 0, 0), (12, 3, 8, 0, 0), (10, 4, 16, 1, 0), (6, 2, 4, 0, 1), (12, 3, 8, 0, 1), (10, 4, 16, 1, 1)])
+def test_prove_shape_from_cpp_is_byte_identical_to_the_cpu_port(tmp_path, oracles, log_rows, registers, lde_factor, combiner, ali_mode):
     """The phases of Prover::prove (src/prover/mod.rs:66-174; cubic_vdf.rs:288-354) driven from C++ through the
-    device-resident Polynomial / IOP / FRI objects of hodor.hpp: the assembled proof bytes equal the bytes the CPU
-    oracle assembles for the same synthetic instance (tests/prove_shape_ref.py), and the library counted no more
-    host round trips than the schedule has results to hand over."""
+    device-resident Polynomial / IOP / FRI objects of hodor.hpp — ALIInstance::from_arp's divisor precompute included,
+    AS WRITTEN in the reference on Polynomial::as_mut() (ali_mode 0) or device-resident (ali_mode 1): the assembled proof
+    bytes equal the bytes the CPU oracle assembles for the same instance from ITS restatement of from_arp
+    (tests/prove_shape_ref.py, tests/ali_replay_ref.py), and the library counted no more host round trips than the
+    schedule has results to hand over."""
     import json
     import sys
 
@@ -72,7 +75,7 @@ def test_prove_shape_from_cpp_is_byte_identical_to_the_cpu_port(tmp_path, oracle
     from oracle import pyref as P
     exe = _build_prove_shape(tmp_path)
     out_bin = str(tmp_path / "proof.bin")
-    run = subprocess.run([exe, str(log_rows), str(registers), str(lde_factor), str(combiner), out_bin, "1"],
+    run = subprocess.run([exe, str(log_rows), str(registers), str(lde_factor), str(combiner), out_bin, "1", "0", str(ali_mode)],
                          capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     line = json.loads(run.stdout.strip().splitlines()[-1])
@@ -86,6 +89,14 @@ def test_prove_shape_from_cpp_is_byte_identical_to_the_cpu_port(tmp_path, oracle
     # registers + 1 oracle queries
     assert 0 < line["host_round_trips"] <= 2 + 4 + 3 + 2 + 2 + registers + 1
     assert set(line["phases_ms"]) == set(ps.PHASES)
+    # from_arp: as written the divisor vector (4 n elements) goes up, comes down inverted and goes up again, and the coset
+    # table of the adjustment polynomials comes down once; device-resident nothing but the roots and a few inverses move
+    big = 32 * 4 * (1 << log_rows)
+    fa = line["from_arp"]
+    if ali_mode == 0:
+        assert fa["h2d_bytes"] >= 2 * big and fa["d2h_bytes"] >= big and line["h2d_bytes"] >= 2 * big   # 2 adjustment polynomials per proof
+    else:
+        assert fa["h2d_bytes"] < 4096 and fa["d2h_bytes"] < 4096 and line["h2d_bytes"] < (1 << 16)
 
 
 # ---------------------------------------------------------------- plain C (the boundary is a C ABI)
