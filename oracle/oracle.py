@@ -218,6 +218,30 @@ class Oracle:
         self.L.o_serial_lde(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w),
                             C.c_uint32(log_n), C.c_size_t(lde_factor))
 
+    def parallel_fft_radix_4(self, a, omega, log_n, log_cpus):
+        w = self.fr(omega)
+        if self.L.o_parallel_fft_radix_4(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                                         C.c_uint32(log_cpus)) != 0:
+            raise ValueError("assert!(log_n >= log_cpus && log_n % 2 == 0 && log_cpus % 2 == 0)")
+
+    def best_fft_radix_4(self, a, omega, log_n, cpus=None):
+        w = self.fr(omega)
+        if self.L.o_best_fft_radix_4(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                                     C.c_uint32(cpus or self.cpus)) != 0:
+            raise ValueError("assert!(log_n % 2 == 0)")
+
+    def parallel_lde(self, a, omega, log_n, log_cpus, lde_factor):
+        w = self.fr(omega)
+        if self.L.o_parallel_lde(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                                 C.c_uint32(log_cpus), C.c_size_t(lde_factor)) != 0:
+            raise ValueError("assert!(log_n >= log_cpus)")
+
+    def best_lde(self, a, omega, log_n, lde_factor, cpus=None):
+        w = self.fr(omega)
+        if self.L.o_best_lde(C.byref(self.f), _ptr(a), C.c_size_t(len(a)), C.byref(w), C.c_uint32(log_n),
+                             C.c_size_t(lde_factor), C.c_uint32(cpus or self.cpus)) != 0:
+            raise ValueError("assert!(log_n >= log_cpus)")
+
     def naive_dft(self, a, omega):
         out = np.zeros_like(a)
         w = self.fr(omega)

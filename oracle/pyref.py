@@ -99,6 +99,132 @@ def ntt(F, a, omega):
     return a
 
 
+def _digit_reverse(k, digits, bits):
+    r = 0
+    for _ in range(digits):
+        r = (r << bits) | (k & ((1 << bits) - 1))
+        k >>= bits
+    return r
+
+
+def serial_fft_radix_4(F, a, omega):
+    """src/fft/radix4_fft/mod.rs:45-123, loop for loop (canonical ints)"""
+    n, p = len(a), F.p
+    log_n = n.bit_length() - 1
+    assert log_n % 2 == 0
+    a = list(a)
+    for k in range(n):
+        rk = _digit_reverse(k, log_n // 2, 2)
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    v = pow(omega, n // 4, p)
+    m = 1
+    for _ in range(log_n // 2):
+        w_m = pow(omega, n // (4 * m), p)
+        for k in range(0, n, 4 * m):
+            w = 1
+            for j in range(m):
+                u = w
+                x0 = a[k + j]
+                x1 = a[k + j + m] * w % p
+                u = u * w % p
+                x2 = a[k + j + 2 * m] * u % p
+                u = u * w % p
+                x3 = a[k + j + 3 * m] * u % p
+                a[k + j] = (x0 + x2 + x1 + x3) % p
+                a[k + j + 2 * m] = (x0 + x2 - x1 - x3) % p
+                t = (x1 - x3) * v % p
+                a[k + j + m] = (x0 - x2 + t) % p
+                a[k + j + 3 * m] = (x0 - x2 - t) % p
+                w = w * w_m % p
+        m *= 4
+    return a
+
+
+def serial_lde(F, a, omega, lde_factor):
+    """src/fft/lde.rs:15-126: the radix-2 transform whose early rounds skip the operands known to be zero (is_non_zero
+    :28-31, the four-way match :90-116)"""
+    n, p = len(a), F.p
+    log_n = n.bit_length() - 1
+    a = list(a)
+    for k in range(n):
+        rk = _digit_reverse(k, log_n, 1)
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    m, step = 1, 0
+    for _ in range(log_n):
+        w_m = pow(omega, n // (2 * m), p)
+        dense = (lde_factor >> step) <= 1
+        for k in range(0, n, 2 * m):
+            w = 1
+            for j in range(m):
+                odd, even = k + j + m, k + j
+                if dense:
+                    odd_nz = even_nz = True
+                else:
+                    odd_nz = (odd & (lde_factor - 1)) < (1 << step)
+                    even_nz = (even & (lde_factor - 1)) < (1 << step)
+                if odd_nz and even_nz:
+                    t = a[odd] * w % p
+                    a[odd] = (a[even] - t) % p
+                    a[even] = (a[even] + t) % p
+                elif even_nz:
+                    a[odd] = a[even]
+                elif odd_nz:
+                    t = a[odd] * w % p
+                    a[odd] = (-t) % p
+                    a[even] = t
+                w = w * w_m % p
+        step += 1
+        m *= 2
+    return a
+
+
+def _parallel_split(F, a, omega, log_cpus, sub, non_trivial_len=None):
+    """The Cooley-Tukey split shared by parallel_fft (src/fft/fft.rs:68-124), parallel_fft_radix_4
+    (src/fft/radix4_fft/mod.rs:125-184) and parallel_lde (src/fft/lde.rs:128-193): sub-sequence j is the naive length-P DFT
+    shuffle of the inputs (running `elt`), transformed by `sub` with omega^P, and the outputs are un-shuffled
+    a[idx] = tmp[idx & (P - 1)][idx >> log_cpus]."""
+    n, p = len(a), F.p
+    log_n = n.bit_length() - 1
+    assert log_n >= log_cpus
+    num_cpus, log_new_n = 1 << log_cpus, log_n - log_cpus
+    new_omega = pow(omega, num_cpus, p)
+    tmp = []
+    for j in range(num_cpus):
+        t = [0] * (1 << log_new_n)
+        omega_j, omega_step, elt = pow(omega, j, p), pow(omega, j << log_new_n, p), 1
+        for i in range(1 << log_new_n):
+            for s_ in range(num_cpus):
+                idx = (i + (s_ << log_new_n)) % n
+                if non_trivial_len is None or idx < non_trivial_len:
+                    t[i] = (t[i] + a[idx] * elt) % p
+                elt = elt * omega_step % p
+            elt = elt * omega_j % p
+        tmp.append(sub(t, new_omega))
+    return [tmp[idx & (num_cpus - 1)][idx >> log_cpus] for idx in range(n)]
+
+
+def parallel_fft_radix_4(F, a, omega, log_cpus):
+    """src/fft/radix4_fft/mod.rs:125-184"""
+    log_n = len(a).bit_length() - 1
+    assert log_n % 2 == 0 and log_cpus % 2 == 0
+    return _parallel_split(F, a, omega, log_cpus, lambda t, w: serial_fft_radix_4(F, t, w))
+
+
+def parallel_lde(F, a, omega, log_cpus, lde_factor):
+    """src/fft/lde.rs:128-193"""
+    new_factor = lde_factor >> log_cpus
+    sub = (lambda t, w: ntt(F, t, w)) if new_factor <= 1 else (lambda t, w: serial_lde(F, t, w, new_factor))
+    return _parallel_split(F, a, omega, log_cpus, sub, non_trivial_len=len(a) // lde_factor)
+
+
+def best_lde(F, a, omega, lde_factor, cpus):
+    """src/fft/lde.rs:4-13"""
+    log_n, log_cpus = len(a).bit_length() - 1, cpus.bit_length() - 1
+    return serial_lde(F, a, omega, lde_factor) if log_n <= log_cpus else parallel_lde(F, a, omega, log_cpus, lde_factor)
+
+
 def distribute_powers(F, a, g):
     """src/fft/mod.rs:110-123"""
     p, out, u = F.p, [], 1

@@ -83,7 +83,62 @@ def coset2_shapes(O, res, small):
         del a, code, r
 
 
+def reference_test_sizes(small):
+    """The reference's own differential tests at THEIR sizes and over THEIR field (experiments::Fr), restated on the oracle:
+      test_parallel_radix4_fft (src/fft/mod.rs:128-184)        2^22 points: parallel_fft == parallel_fft_radix_4 ==
+                                                               parallel_DIT_fft, element for element
+      test_various_ldes (src/polynomials/mod.rs:1084-1130)     2^22 coefficients x 16: lde_using_multiple_cosets ==
+                                                               filtering_lde (zero-pad + best_lde) == fft of the padded vector
+    The identities are asserted HERE (and again by tests/test_oracle_cpu.py, the LDE one at full size only on request);
+    the digests of the common results are what the GPU is held to (tests/test_gpu_fullsize.py)."""
+    O = Oracle(P.EXPERIMENTS.p, P.EXPERIMENTS.g)
+    log_n, log_lde = (12, 4) if small else (22, 4)
+    n, factor = 1 << log_n, 1 << log_lde
+    res = {"field": "src/experiments/mod.rs Fr", "modulus": hex(P.EXPERIMENTS.p)}
+    t0 = time.time()
+    log_cpus = O.cpus.bit_length() - 1
+    r4 = log_cpus - (log_cpus & 1)
+    a = O.gen_elements(0, n, SEED_NTT)
+    _, k, w = O.domain(n)
+    b, c = a.copy(), a.copy()
+    e = {"seed": SEED_NTT, "log_n": log_n, "input": digest(a)}
+    O.parallel_fft(a, w, k, log_cpus)
+    O.parallel_fft_radix_4(b, w, k, r4)
+    O.parallel_dit_fft(c, w, k, log_cpus, n)
+    assert np.array_equal(a, b) and np.array_equal(a, c), "test_parallel_radix4_fft fails on the oracle"
+    e["fft"] = digest(a)
+    res["parallel_radix4_fft"] = e
+    print("test_parallel_radix4_fft 2^%d done %.0f s" % (log_n, time.time() - t0), flush=True)
+    del a, b, c
+    coeffs = O.gen_elements(0, n, SEED_LDE)
+    e = {"seed": SEED_LDE, "log_n": log_n, "factor": factor, "input": digest(coeffs)}
+    coset = O.poly_lde(coeffs, factor)                       # lde_using_multiple_cosets
+    _, K, W = O.domain(n * factor)
+    filt = np.zeros((n * factor, 4), dtype=np.uint64)
+    filt[:n] = coeffs
+    O.best_lde(filt, W, K, factor)                           # filtering_lde :355-368
+    assert np.array_equal(filt, coset), "test_various_ldes: filtering_lde != lde_using_multiple_cosets on the oracle"
+    del coset
+    naive = np.zeros((n * factor, 4), dtype=np.uint64)
+    naive[:n] = coeffs
+    O.best_fft(naive, W, K)                                  # Polynomial::fft of the padded vector
+    assert np.array_equal(filt, naive), "test_various_ldes: filtering_lde != naive fft on the oracle"
+    e["lde"] = digest(naive)
+    res["various_ldes"] = e
+    print("test_various_ldes 2^%d x %d done %.0f s" % (log_n, factor, time.time() - t0), flush=True)
+    return res
+
+
 def main():
+    if "--ref-sizes" in sys.argv:
+        small = "--small" in sys.argv
+        res = json.load(open(OUT)) if not small else {}
+        res["reference_tests"] = reference_test_sizes(small)
+        out = OUT if not small else "/tmp/fullsize_small_ref.json"
+        with open(out, "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+        print("updated", out)
+        return
     if "--coset2" in sys.argv:
         O = Oracle(P.BN256.p, P.BN256.g)
         small = "--small" in sys.argv

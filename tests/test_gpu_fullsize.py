@@ -99,6 +99,42 @@ def test_config1_ntt_every_element(gpu_ctxs, log_n):
     assert digest(a) == e["fft"]
 
 
+def test_the_reference_tests_at_their_own_sizes(gpu_ctxs):
+    """test_parallel_radix4_fft (src/fft/mod.rs:128-184: 2^22 points) and test_various_ldes
+    (src/polynomials/mod.rs:1084-1130: 2^22 coefficients x 16) over THEIR field, experiments::Fr: the device's transform
+    and both of its LDE spellings — Polynomial::lde and the fft of the zero-padded vector, which is what filtering_lde's
+    best_lde computes — equal, whole buffer, the results on which the oracle's restated parallel_fft /
+    parallel_fft_radix_4 / parallel_DIT_fft resp. lde_using_multiple_cosets / best_lde / best_fft all agreed when
+    tests/golden/gen_fullsize.py --ref-sizes wrote the digests."""
+    import torch
+    ctx, R = gpu_ctxs["experiments"], FULL["reference_tests"]
+    e = R["parallel_radix4_fft"]
+    log_n = e["log_n"]
+    a = dev_elements(ctx, 1 << log_n, e["seed"])
+    ctx.synchronize()
+    assert digest(a) == e["input"]
+    b = torch.empty_like(a)
+    ctx.poly_fft_dev(a, b, log_n)
+    ctx.synchronize()
+    assert digest(b) == e["fft"]
+    del a, b
+    e = R["various_ldes"]
+    log_n, f = e["log_n"], e["factor"]
+    n = 1 << log_n
+    a = dev_elements(ctx, n, e["seed"])
+    ctx.synchronize()
+    assert digest(a) == e["input"]
+    out = torch.empty((n * f, 4), dtype=torch.int64, device="cuda")
+    ctx.poly_lde_dev(a, out, log_n, f)
+    ctx.synchronize()
+    assert digest(out) == e["lde"]
+    out.zero_()
+    out[:n] = a
+    ctx.poly_fft_dev(out, out, log_n + f.bit_length() - 1)      # "naive_lde": Polynomial::fft of the padded vector
+    ctx.synchronize()
+    assert digest(out) == e["lde"]
+
+
 @pytest.mark.parametrize("log_n", sorted(int(k) for k in FULL["lde"]))
 def test_config2_lde_and_commit_every_element(gpu_ctxs, log_n):
     """BASELINE config[2]: lde(8) of 2^22 coefficients and the IOP tree over it, whole buffers."""

@@ -54,6 +54,30 @@ def test_fft_large_matches_parallel_oracle(gpu_ctxs, oracles, log_n):
     assert _digest(got) == _digest(exp)
 
 
+@pytest.mark.parametrize("log_n", [18, 20])
+def test_fft_large_matches_parallel_radix4_and_parallel_lde_oracles(gpu_ctxs, oracles, log_n):
+    """Rows a6 / a8 at config[0]'s size: hodor_fft against the restated parallel_fft_radix_4
+    (src/fft/radix4_fft/mod.rs:125-184, through its best_fft :5-20), hodor_lde against the restated parallel_lde
+    (src/fft/lde.rs:128-193, through best_lde :4-13) — the two parallel forms that had no restatement until round 6."""
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    n = 1 << log_n
+    a = O.random_elements(n, 8)
+    _, _, omega = O.domain(n)
+    exp = a.copy()
+    O.best_fft_radix_4(exp, omega, log_n)
+    got = a.copy()
+    ctx.fft(got, omega, log_n)
+    assert _digest(got) == _digest(exp)
+    for factor in (2, 16):
+        z = a.copy()
+        z[n // factor:] = 0
+        exp = z.copy()
+        O.best_lde(exp, omega, log_n, factor)
+        got = z.copy()
+        ctx.lde(got, omega, log_n, factor)
+        assert _digest(got) == _digest(exp), factor
+
+
 @pytest.mark.parametrize("log_n,log_nz", [(4, 0), (10, 3), (12, 12), (16, 12), (18, 14), (20, 17)])
 def test_pruned_transform_matches_dit_fft(gpu_ctxs, oracles, field_name, log_n, log_nz):
     """Row a7: serial/parallel/best_DIT_fft with non_zero_entries_count (src/fft/dit_fft/mod.rs:4-123,

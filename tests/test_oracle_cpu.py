@@ -174,6 +174,106 @@ def test_dit_fft_three_way_and_pruning(oracles, field_name, log_n):
             assert np.array_equal(sl, full), log_nz
 
 
+@pytest.mark.parametrize("log_n", [2, 4, 6, 8, 12])
+def test_parallel_radix4_and_parallel_lde_restatements(oracles, field_name, log_n):
+    """Round 6: the last two functions of SURVEY §8(a) without a restatement — parallel_fft_radix_4
+    (src/fft/radix4_fft/mod.rs:125-184) with its best_fft (:5-20), parallel_lde / best_lde (src/fft/lde.rs:128-193, :4-13) —
+    against the serial forms, against the big-int twins of oracle/pyref.py (which follow the Rust loops with Python
+    integers) and against the reference's own asserts on log_n / log_cpus."""
+    O, F = oracles[field_name], PYF[field_name]
+    n = 1 << log_n
+    a = O.random_elements(n, 60 + log_n)
+    _, k, w = O.domain(n)
+    ref = a.copy(); O.serial_fft(ref, w, k)
+    for log_cpus in (0, 2, 4):
+        if log_cpus <= log_n:
+            r = a.copy(); O.parallel_fft_radix_4(r, w, k, log_cpus)
+            assert np.array_equal(r, ref), log_cpus
+    for cpus in (1, 2, 4, 7, 16, 64):                        # odd log_cpus are rounded down to even (:8-12)
+        r = a.copy(); O.best_fft_radix_4(r, w, k, cpus)
+        assert np.array_equal(r, ref), cpus
+    with pytest.raises(ValueError):
+        O.parallel_fft_radix_4(a.copy(), w, k, 1)            # assert!(log_cpus % 2 == 0)
+    with pytest.raises(ValueError):
+        O.parallel_fft_radix_4(a.copy(), w, k, log_n + 2)    # assert!(log_n >= log_cpus)
+    if log_n <= 8:
+        canon = canon_list(F, a)
+        wc = F.from_mont(w)
+        assert canon_list(F, ref) == P.serial_fft_radix_4(F, canon, wc) == P.parallel_fft_radix_4(F, canon, wc, 2 if log_n >= 2 else 0)
+    for log_f in range(1, log_n + 1):
+        factor = 1 << log_f
+        z = a.copy(); z[n // factor:] = 0
+        full = z.copy(); O.serial_fft(full, w, k)
+        for log_cpus in (0, 1, 2, 3):
+            if log_cpus <= log_n:
+                r = z.copy(); O.parallel_lde(r, w, k, log_cpus, factor)
+                assert np.array_equal(r, full), (log_f, log_cpus)
+        for cpus in (1, 3, 8, 1 << (log_n + 1)):             # the last one: log_n <= log_cpus -> serial_lde (:8-9)
+            r = z.copy(); O.best_lde(r, w, k, factor, cpus)
+            assert np.array_equal(r, full), (log_f, cpus)
+        if log_n <= 6:
+            canon = canon_list(F, z)
+            wc = F.from_mont(w)
+            exp = canon_list(F, full)
+            assert P.serial_lde(F, canon, wc, factor) == exp
+            assert P.parallel_lde(F, canon, wc, min(2, log_n), factor) == exp
+            assert P.best_lde(F, canon, wc, factor, 4) == exp
+    with pytest.raises(ValueError):
+        O.parallel_lde(a.copy(), w, k, log_n + 1, 2)
+
+
+def test_parallel_radix4_fft_at_the_reference_size(oracles):
+    """test_parallel_radix4_fft (src/fft/mod.rs:128-184) at ITS size and over ITS field: 2^22 points of
+    experiments::Fr, parallel_fft == parallel_fft_radix_4 == parallel_DIT_fft element for element with the host's own
+    worker counts, and the result is the one whose digest tests/golden/fullsize_digests.json commits (the GPU is held to
+    the same digest, tests/test_gpu_fullsize.py)."""
+    import hashlib
+    O = oracles["experiments"]
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_digests.json")))["reference_tests"]["parallel_radix4_fft"]
+    log_n = fx["log_n"]
+    n = 1 << log_n
+    a = O.gen_elements(0, n, fx["seed"])
+    dig = lambda x: hashlib.blake2s(memoryview(np.ascontiguousarray(x)).cast("B"), digest_size=32).hexdigest()
+    assert dig(a) == fx["input"]
+    _, k, w = O.domain(n)
+    log_cpus = O.cpus.bit_length() - 1
+    r4 = log_cpus - (log_cpus & 1)
+    b, c = a.copy(), a.copy()
+    O.parallel_fft(a, w, k, log_cpus)
+    O.parallel_fft_radix_4(b, w, k, r4)
+    assert np.array_equal(a, b)
+    del b
+    O.parallel_dit_fft(c, w, k, log_cpus, n)
+    assert np.array_equal(a, c)
+    assert dig(a) == fx["fft"]
+
+
+def test_various_ldes_identity(oracles):
+    """test_various_ldes (src/polynomials/mod.rs:1084-1130): lde_using_multiple_cosets == filtering_lde (zero-pad +
+    best_lde) == fft of the zero-padded vector.  The reference runs it at 2^22 x 16 (three vectors of 2 GiB, about a
+    minute of CPU on 8 cores): here at 2^16 x 16 by default and at the reference's size — against the committed digest —
+    when HODOR_CPU_FULLSIZE=1 (tests/golden/gen_fullsize.py --ref-sizes asserted the full-size identity when it wrote
+    the digest; tests/test_gpu_fullsize.py holds the GPU to it)."""
+    import hashlib
+    O = oracles["experiments"]
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_digests.json")))["reference_tests"]["various_ldes"]
+    full = os.environ.get("HODOR_CPU_FULLSIZE", "0") not in ("", "0")
+    log_n, factor = (fx["log_n"] if full else 16), fx["factor"]
+    n = 1 << log_n
+    coeffs = O.gen_elements(0, n, fx["seed"])
+    coset = O.poly_lde(coeffs, factor)
+    _, K, W = O.domain(n * factor)
+    filt = np.zeros((n * factor, 4), dtype=np.uint64); filt[:n] = coeffs
+    O.best_lde(filt, W, K, factor)
+    assert np.array_equal(filt, coset)
+    del coset
+    naive = np.zeros((n * factor, 4), dtype=np.uint64); naive[:n] = coeffs
+    O.best_fft(naive, W, K)
+    assert np.array_equal(filt, naive)
+    if full:
+        assert hashlib.blake2s(memoryview(naive).cast("B"), digest_size=32).hexdigest() == fx["lde"]
+
+
 def test_fri_by_values_equals_through_coefficients(oracles, field_name):
     """test_one_fri_step / test_fri_on_values_vs_on_coefficients (src/fri/mod.rs:252-361, :510-692):
     every intermediate vector equals the LDE of the folded coefficients a_2i + beta*a_2i+1."""
