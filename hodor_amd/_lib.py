@@ -591,7 +591,9 @@ class Context:
         mod = (C.c_uint64 * 4)(*_limbs(modulus))
         rc = self.L.hodor_ctx_create(mod, C.c_uint64(generator), C.c_int(device), C.byref(self.h))
         if rc != OK:
-            raise HodorError(rc, "hodor_ctx_create")
+            self.L.hodor_last_error.restype = C.c_char_p
+            why = self.L.hodor_last_error(None)      # NULL: why this thread's last hodor_ctx_create failed (the self-test's verdict)
+            raise HodorError(rc, "hodor_ctx_create" + (": " + why.decode() if why else ""))
         self.modulus, self.device = modulus, device
         _LIVE_CONTEXTS.add(self)
         info = _FieldInfo()

@@ -534,6 +534,12 @@ extern "C" int hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, i
         ctx->min_log_c = (uint32_t)k.min_log_c;
         ctx->pool_cache_cap = (size_t)k.pool_cache_gib << 30;
         if (ctx->max_log_r > ctx->tile_log) ctx->max_log_r = ctx->tile_log;
+        // the kernels this context is about to use against the host implementations of the same arithmetic
+        // (abi_selftest.hip); a context that fails is never handed out
+        if (int rc = ctx_self_test(ctx)) {
+            (void)hodor_ctx_try_destroy(ctx);
+            return rc;
+        }
     }
     *out = ctx;
     return HODOR_OK;
@@ -603,7 +609,7 @@ extern "C" int hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out)
 // reassign ctx->err at any time, so a pointer into it could dangle.  Valid until this thread's next call here.
 extern "C" const char *hodor_last_error(const hodor_ctx *ctx)
 {
-    if (!ctx) return "";
+    if (!ctx) return ctx_create_error();   // why this thread's last hodor_ctx_create failed ("" when it did not)
     static thread_local std::string snapshot;
     std::lock_guard<std::mutex> lk(ctx->err_mu);
     snapshot = ctx->err;

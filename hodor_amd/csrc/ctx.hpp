@@ -378,6 +378,10 @@ void pool_destroy_events(hodor_ctx *ctx);
 void host_images_drain(hodor_ctx *ctx);   // cached pinned host images of the handle API back to HIP
 static inline void note_round_trip(hodor_ctx *ctx) { ctx->host_round_trips.fetch_add(1, std::memory_order_relaxed); }
 
+// abi_selftest.hip: the start-up self-test of hodor_ctx_create and the message of its failure (per thread)
+int ctx_self_test(hodor_ctx *ctx);
+const char *ctx_create_error();
+
 // defined in abi.hip (caller holds ctx->mu)
 int trim_table_cache(hodor_ctx *ctx);
 int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out, uint32_t fmt,

@@ -63,6 +63,13 @@ typedef struct {
  *      receive buffers of the direct transports are the library's (hodor_exchange_direct_alloc_recv) */
 #define HODOR_ABI_VERSION 5
 int  hodor_abi_version(void);
+/* With a device (device >= 0) the new context first runs a START-UP SELF-TEST (csrc/abi_selftest.hip, about a millisecond
+ * and a half): one 2^10-point transform per kernel instantiation it will use, a 2^16-point fft -> ifft round trip and
+ * one small FRI commit (tree, challenge, two folds, final coefficient), every result compared with the library's HOST
+ * implementations of the same arithmetic.  A mismatch — a compiler, code-object or driver change that broke an
+ * assumption of the device code — returns HODOR_ERR_DEVICE and no context; hodor_last_error(NULL) says which check
+ * failed.  HODOR_SELFTEST=0 in the environment skips the test.  device < 0: a host-only context (field helpers,
+ * verifiers, transcript), no test, no HIP call. */
 int  hodor_ctx_create(const uint64_t modulus[4], uint64_t generator, int device, hodor_ctx **out);
 /* Destroy after every prototype and handle obtained from this context has been freed (they hand their device memory
  * back to the context's pool), every hodor_exchange created on it has been destroyed (the call
@@ -73,7 +80,7 @@ void hodor_ctx_destroy(hodor_ctx *ctx);
  * call with the verdict dropped. */
 int  hodor_ctx_try_destroy(hodor_ctx *ctx);
 int  hodor_ctx_field_info(const hodor_ctx *ctx, hodor_field_info *out);
-const char *hodor_last_error(const hodor_ctx *ctx);
+const char *hodor_last_error(const hodor_ctx *ctx);   /* ctx == NULL: why this thread's last hodor_ctx_create failed */
 int  hodor_ctx_synchronize(hodor_ctx *ctx);
 /* Tuning variables found in the environment when the library first read them ("NAME=value ...", empty
  * when none): HODOR_MAX_LOG_R, HODOR_TILE_LOG, HODOR_MIN_LOG_C, HODOR_TW_HI_MAX_LOG, HODOR_NTT_THREADS, HODOR_NTT_TW_SUB, HODOR_NTT_W9, HODOR_NTT_P1,
