@@ -123,6 +123,49 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
+EXTRA_SOURCES = KERNEL_SOURCES + ("merkle.hip", "fri.hip", "blake2s.cuh", "abi_fri.hip")
+HBM_MEASURED_GBS = 5200.0        # streaming copy on this part, read + write (profiles/r02/microbench_gfx950.txt: 4.99-5.2 TB/s)
+COMPRESSION_PS = 25.1            # one BLAKE2s compression per lane at full occupancy, picoseconds per compression across the
+                                 # chip (bench/microbench.hip "blake2s compression", profiles/r03/microbench_gfx950.txt)
+
+
+def extras_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for name in EXTRA_SOURCES:
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(ROOT, "hodor_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+def extra_roofline(workload, alg_bytes, ms, compressions):
+    """The `roofline` object of one extra workload: algorithmic bytes per run over its measured time against the HBM peak,
+    the counter traffic of a run (profiles/rNN/pmc_traffic.json "extras", quoted only when it was taken from THIS build
+    of the kernels), the measured streaming ceiling beside the paper peak, and the floor the hash function sets."""
+    traffic, stale, by_kernel = None, None, None
+    try:
+        pmcs = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r")
+                      and os.path.exists(os.path.join(ROOT, "profiles", p, "pmc_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1], "pmc_traffic.json"))).get("extras")
+        if t:
+            if t.get("sources_sha256") == extras_sources_sha256():
+                traffic = t[workload].get("hbm_bytes_per_run")
+                by_kernel = t[workload].get("kernel_ms_per_run")
+                stale = False
+            else:
+                stale = True
+    except Exception:   # noqa: BLE001
+        pass
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_stale": stale, "alg_bytes_per_run": alg_bytes,
+            "measured_streaming_ceiling_gbs": HBM_MEASURED_GBS, "frac_of_measured_ceiling": achieved / HBM_MEASURED_GBS,
+            "compressions_per_run": compressions, "compression_floor_ms": compressions * COMPRESSION_PS * 1e-9,
+            "rocprofv3_kernel_ms_per_run": by_kernel,
+            "note": "hash-bound: the run's BLAKE2s compressions at the measured compression ceiling (%.1f ps each, "
+                    "bench/microbench.hip) already take compression_floor_ms" % COMPRESSION_PS}
+
+
 def digest_host(arr):
     import hashlib
     return hashlib.blake2s(memoryview(arr).cast("B"), digest_size=32).hexdigest()
@@ -911,6 +954,8 @@ def extra_lde_commit(ctx, torch, stream):
            "lde_commit_gib_per_s": alg_bytes / 2**30 / ((lde_ms + commit_ms) * 1e-3),
            "hbm_frac": alg_bytes / ((lde_ms + commit_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "root": root, "root_equals_cpu_oracle": True}
+    # 2^25 leaf + 2^25 - 1 node compressions; the LDE's own kernel is k_ntt_pass (the headline line's roofline)
+    out["roofline"] = extra_roofline("lde_commit", alg_bytes, lde_ms + commit_ms, 2 * big - 1)
     if "coset2_root" in fx:
         # the same codeword committed in the COSET2 tree format (opt-in; the coset {i, i + n/2} is one 64-byte leaf):
         # gated on the CPU oracle's committed root for that format
@@ -1175,6 +1220,8 @@ def extra_fri_commit(ctx, torch, stream):
            "ms": ms, "rounds": steps, "gib_per_s": 6.0 * n * 32 / 2**30 / (ms * 1e-3),
            "hbm_frac": 6.0 * n * 32 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "final_root": proto.final_root.hex(), "bytes_equal_cpu_oracle": True}
+    # trees over n, n/2, n/4, ... values: 2 (n + n/2 + ...) ~ 4 n compressions
+    out["roofline"] = extra_roofline("fri_commit", 6.0 * n * 32, ms, sum(2 * (n >> k) - 1 for k in range(steps + 1)))
     # the same codeword committed in the COSET2 tree format (opt-in, include/hodor_gpu.h: the coset {i, i + n/2} FRI
     # opens together is ONE 64-byte leaf — the reference's unchecked "coset combining", README.md:46): half the
     # compressions and one path per round; gated on the CPU oracle's committed bytes for that format

@@ -18,6 +18,10 @@ g++ -O2 -std=c++17 -pthread "$ROOT/tests/host_cpp/prove_shape.cpp" -L"$ROOT/hodo
     $EXE $LOG $REGS $F $comb /tmp/proof_res_$comb.bin 5 0 1
     $EXE $LOG $REGS $F $comb /tmp/proof_res_sync_$comb.bin 5 1 1
     cmp /tmp/proof_$comb.bin /tmp/proof_res_$comb.bin && echo "proof bytes identical in both forms of from_arp"
+    echo "== A/B of hodor_fri_commit_batch_h: the same (device-resident, free-running / drained) with h1 and h2 committed one after the other"
+    $EXE $LOG $REGS $F $comb /tmp/proof_seq_$comb.bin 5 0 1 0
+    $EXE $LOG $REGS $F $comb /tmp/proof_seq_sync_$comb.bin 5 1 1 0
+    cmp /tmp/proof_res_$comb.bin /tmp/proof_seq_$comb.bin && echo "proof bytes identical with and without the batched commit"
     python3 - <<PY
 import hashlib
 a=open("/tmp/proof_$comb.bin","rb").read(); b=open("/tmp/proof_sync_$comb.bin","rb").read()

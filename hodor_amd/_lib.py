@@ -85,6 +85,7 @@ EXPORTS = [
     # round 6: whole-slice as_mut() with write-back, PCIe byte counters
     "hodor_poly_as_mut_h", "hodor_poly_commit_mut_h", "hodor_ctx_host_traffic",
     "hodor_poly_dense_divisor_on_coset_dev", "hodor_poly_dense_divisor_on_coset_h",
+    "hodor_fri_commit_batch_h", "hodor_fri_commit_batch_dev", "hodor_ctx_pool_peak",
 ]
 
 

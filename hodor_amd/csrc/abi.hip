@@ -91,8 +91,8 @@ static void make_params9(const HostField &F, Fr9Params *Q)
 static int free_tables(hodor_ctx *ctx)
 {
     HIPCHK(hipDeviceSynchronize());
-    for (auto &t : ctx->pow_tables) { (void)hipFree(t.lo); (void)hipFree(t.hi); }
-    for (auto &t : ctx->radix_tables) { (void)hipFree(t.rtw); if (t.rtw9) (void)hipFree(t.rtw9); }
+    for (auto &t : ctx->pow_tables) { BOUNDS_FORGET(t.lo); BOUNDS_FORGET(t.hi); (void)hipFree(t.lo); (void)hipFree(t.hi); }
+    for (auto &t : ctx->radix_tables) { BOUNDS_FORGET(t.rtw); BOUNDS_FORGET(t.rtw9); (void)hipFree(t.rtw); if (t.rtw9) (void)hipFree(t.rtw9); }
     ctx->pow_tables.clear();
     ctx->radix_tables.clear();
     return HODOR_OK;
@@ -118,6 +118,10 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
     for (auto &t : ctx->pow_tables)
         if (t.log_n == log_n && t.lo_bits == lo_bits && t.fmt == fmt && t.base == base && t.hi_mult == hi_mult) {
             *out = TwoLevel{t.lo, t.hi, t.lo_bits};
+#ifdef HODOR_BOUNDS
+            out->lo_bytes = ((size_t)1 << t.lo_bits) * (fmt == 2 ? 112 : (fmt ? 48 : 32));
+            out->hi_bytes = ((size_t)1 << (log_n - t.lo_bits)) * (fmt == 2 ? 112 : (fmt ? 48 : 32));
+#endif
             return HODOR_OK;
         }
     PowTable t;
@@ -130,6 +134,8 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
     uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
     HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * esz));
     HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * esz));
+    BOUNDS_NOTE(t.lo, lo_cnt * esz);
+    BOUNDS_NOTE(t.hi, hi_cnt * esz);
     Fr b = to_dev(base), one = to_dev(ctx->F.one);
     if (fmt == 2) {
         HIPCHK(pow_table_w3_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, ctx->K3, ctx->P));
@@ -141,6 +147,10 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
     HIPCHK(hipStreamSynchronize(ctx->stream));   // tables are shared across streams afterwards
     ctx->pow_tables.push_back(t);
     *out = TwoLevel{t.lo, t.hi, t.lo_bits};
+#ifdef HODOR_BOUNDS
+    out->lo_bytes = lo_cnt * esz;
+    out->hi_bytes = hi_cnt * esz;
+#endif
     return HODOR_OK;
 }
 
@@ -166,6 +176,8 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     auto fail = [&](hipError_t e, const char *what) {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(ctx->stream);
+        BOUNDS_FORGET(t.rtw);
+        BOUNDS_FORGET(t.rtw9);
         if (t.rtw) (void)hipFree(t.rtw);
         if (t.rtw9) (void)hipFree(t.rtw9);
         set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
@@ -173,14 +185,17 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
     };
     hipError_t e;
     if ((e = hipMalloc((void **)&t.rtw, cnt * 112)) != hipSuccess) return fail(e, "radix table (hipMalloc)");
+    BOUNDS_NOTE(t.rtw, cnt * 112);
     if ((e = pow_table_w3_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt, ctx->K3,
                                  ctx->P)) != hipSuccess)
         return fail(e, "radix table (k_pow_table_w3)");
     if (log_r >= 6) {   // the 16 powers omega_R^(e R/32) = omega^(e << (log_n - 5)) the wave-uniform steps use
         if ((e = hipMalloc((void **)&t.rtw9, 16 * W9_WORDS * sizeof(uint32_t))) != hipSuccess ||
+            (BOUNDS_NOTE(t.rtw9, 16 * W9_WORDS * sizeof(uint32_t)), false) ||
             (e = pow_table_w9_launch(ctx->stream, t.rtw9, to_dev(omega), log_n - 5, 16, ctx->K9, ctx->P)) != hipSuccess) {
             // the W9 table is an optimisation: without it the pass takes the W3 path for every step
             (void)hipGetLastError();
+            BOUNDS_FORGET(t.rtw9);
             if (t.rtw9) (void)hipFree(t.rtw9);
             t.rtw9 = nullptr;
         }
@@ -218,11 +233,13 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
     }
     if (L->bytes[which] >= bytes) return hipSuccess;
     if (L->buf[which]) {   // the lane is idle (its last call synchronised its stream) — safe to free
+        BOUNDS_FORGET(L->buf[which]);
         if ((e = hipFree(L->buf[which])) != hipSuccess) return e;
         L->buf[which] = nullptr;
         L->bytes[which] = 0;
     }
     if ((e = hipMalloc(&L->buf[which], bytes)) != hipSuccess) return e;
+    BOUNDS_NOTE(L->buf[which], bytes);
     L->bytes[which] = bytes;
     return hipSuccess;
 }
@@ -271,11 +288,13 @@ int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes, hipStream_t user)
     if (ctx->scratch_bytes[which] >= bytes) return HODOR_OK;
     if (ctx->scratch[which]) {
         HIPCHK(hipDeviceSynchronize());
+        BOUNDS_FORGET(ctx->scratch[which]);
         HIPCHK(hipFree(ctx->scratch[which]));
         ctx->scratch[which] = nullptr;
         ctx->scratch_bytes[which] = 0;
     }
     HIPCHK(hipMalloc(&ctx->scratch[which], bytes));
+    BOUNDS_NOTE(ctx->scratch[which], bytes);
     ctx->scratch_bytes[which] = bytes;
     return HODOR_OK;
 }
@@ -419,6 +438,27 @@ int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, u
             uint32_t s = log_n - log2u((size_t)nnz);
             A.log_skip = s < log_r ? s : log_r;
         }
+#ifdef HODOR_BOUNDS
+        {   // what this pass may touch (bounds.cuh): the caller's arrays at the sizes the call promises, the ping-pong buffers
+            const uint64_t n_el = 1ull << log_n;
+            if (i == 0) {
+                if (A.col_mode) A.bx_src_bytes = (32ull << log_n) << A.src_log_width;
+                else if (A.src_split.on) A.bx_src_bytes = 32ull * n_el * batch;
+                else A.bx_src_bytes = 32ull * nnz * batch;
+            } else A.bx_src_bytes = bytes;
+            if (i + 1 == passes) A.bx_dst_bytes = A.col_mode ? (32ull << log_n) << A.dst_log_width : 32ull * n_el * batch;
+            else A.bx_dst_bytes = bytes;
+            if (passes == 1 && src == dst && A.bx_src_bytes > A.bx_dst_bytes) A.bx_dst_bytes = A.bx_src_bytes;
+            A.bx_rtw_bytes = (log_r ? (1ull << (log_r - 1)) : 1) * 112;
+            A.bx_rtw9_bytes = A.rtw9 ? 16 * W9_WORDS * sizeof(uint32_t) : 0;
+            A.bx_peers = 0;
+            if (A.peer_tab && lay) {
+                A.bx_peers = lay->bx_peers;
+                A.bx_peer_bytes = lay->bx_peer_bytes;
+                for (uint32_t t = 0; t < lay->bx_peers && t < 8; t++) A.bx_peer_host[t] = lay->bx_peer_host[t];
+            }
+        }
+#endif
         HIPCHK(ntt_launch_pass(stream, A, (scale && !fold_scale && i + 1 == passes) ? &scale_d : nullptr, ctx->Q));
         cur = outs[i];
         log_l += log_r;
@@ -568,17 +608,17 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
-        for (auto &t : ctx->pow_tables) { (void)hipFree(t.lo); (void)hipFree(t.hi); }
-        for (auto &t : ctx->radix_tables) { (void)hipFree(t.rtw); if (t.rtw9) (void)hipFree(t.rtw9); }
+        for (auto &t : ctx->pow_tables) { BOUNDS_FORGET(t.lo); BOUNDS_FORGET(t.hi); (void)hipFree(t.lo); (void)hipFree(t.hi); }
+        for (auto &t : ctx->radix_tables) { BOUNDS_FORGET(t.rtw); BOUNDS_FORGET(t.rtw9); (void)hipFree(t.rtw); if (t.rtw9) (void)hipFree(t.rtw9); }
         for (int i = 0; i < 2; i++)
-            if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+            if (ctx->scratch[i]) { BOUNDS_FORGET(ctx->scratch[i]); (void)hipFree(ctx->scratch[i]); }
         if (ctx->scratch_ev) (void)hipEventDestroy(ctx->scratch_ev);
         pool_drain(ctx);
         pool_destroy_events(ctx);
         host_images_drain(ctx);
         for (auto &L : ctx->lanes) {
             for (int i = 0; i < 2; i++)
-                if (L.buf[i]) (void)hipFree(L.buf[i]);
+                if (L.buf[i]) { BOUNDS_FORGET(L.buf[i]); (void)hipFree(L.buf[i]); }
             if (L.uploaded) (void)hipEventDestroy(L.uploaded);
             if (L.computed) (void)hipEventDestroy(L.computed);
             if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -586,6 +626,8 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
         if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
         if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        for (auto &a : ctx->aux_streams)
+            if (a) (void)hipStreamDestroy(a);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -620,6 +662,9 @@ extern "C" int hodor_ctx_synchronize(hodor_ctx *ctx)
 {
     NEED_DEVICE();
     HIPCHK(hipDeviceSynchronize());
+#ifdef HODOR_BOUNDS
+    if (hodor::bounds_poll(ctx)) return HODOR_ERR_DEVICE;
+#endif
     pool_collect(ctx);   // the device is idle: blocks evicted from the pool's cache go back to HIP now
     return HODOR_OK;
 }
@@ -632,11 +677,13 @@ extern "C" int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr)
     NEED_DEVICE();
     if (!dev_ptr) return HODOR_ERR_INVALID;
     HIPCHK(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    BOUNDS_NOTE(*dev_ptr, bytes);
     return HODOR_OK;
 }
 extern "C" int hodor_buf_free(hodor_ctx *ctx, void *dev_ptr)
 {
     NEED_DEVICE();
+    BOUNDS_FORGET(dev_ptr);
     HIPCHK(hipFree(dev_ptr));
     return HODOR_OK;
 }

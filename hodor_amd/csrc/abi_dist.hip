@@ -39,11 +39,13 @@ int work_acquire(hodor_exchange *x, int i, size_t bytes, hipStream_t stream, voi
     if (x->work_bytes[i] < bytes) {
         if (x->work[i]) {
             HIPCHK(hipDeviceSynchronize());
+            BOUNDS_FORGET(x->work[i]);
             HIPCHK(hipFree(x->work[i]));
             x->work[i] = nullptr;
             x->work_bytes[i] = 0;
         }
         HIPCHK(hipMalloc(&x->work[i], bytes));
+        BOUNDS_NOTE(x->work[i], bytes);
         x->work_bytes[i] = bytes;
     } else if (x->work_used[i] && x->work_free[i]) {
         HIPCHK(hipStreamWaitEvent(stream, x->work_free[i], 0));

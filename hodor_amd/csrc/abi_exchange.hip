@@ -208,11 +208,11 @@ extern "C" void hodor_exchange_destroy(hodor_exchange *x)
     if (x->d_err) (void)hipHostFree(x->d_err);
     (void)hipDeviceSynchronize();           // the work buffers and the library's own receive buffers may still be read
     for (int i = 0; i < hodor_exchange::WORK; i++) {
-        if (x->work[i]) (void)hipFree(x->work[i]);
+        if (x->work[i]) { BOUNDS_FORGET(x->work[i]); (void)hipFree(x->work[i]); }
         if (x->work_free[i]) (void)hipEventDestroy(x->work_free[i]);
     }
     for (auto &r : x->own_recv)
-        if (r) (void)hipFree(r);
+        if (r) { BOUNDS_FORGET(r); (void)hipFree(r); }
     if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
     for (uint32_t t = 0; t < HODOR_EXCHANGE_MAX_RANKS; t++) {
         if (x->peer_done[t]) (void)hipEventDestroy(x->peer_done[t]);
@@ -438,6 +438,7 @@ extern "C" int hodor_exchange_direct_alloc_recv(hodor_exchange *x, size_t n_loca
             set_err(ctx, std::string("exchange (direct): receive buffers: ") + hipGetErrorString(e));
             return HODOR_ERR_DEVICE;
         }
+        BOUNDS_NOTE(x->own_recv[i], n_local * 32);
         recv[i] = x->own_recv[i];
     }
     x->own_recv_bytes = n_local * 32;
@@ -645,6 +646,15 @@ extern "C" int hodor_exchange_direct_copy_dev(hodor_exchange *x, void *stream, u
     if (chunk + 1 == (1u << log_chunks)) return direct_write(x, x->comm_stream, slot, 0, x->slots[slot].produced);
     return HODOR_OK;
 }
+
+#ifdef HODOR_BOUNDS
+extern "C" uint64_t hodor_exchange_direct_host_table(hodor_exchange *x, uint32_t slot, uint64_t out[8])
+{
+    if (!x || !x->slots || slot >= x->n_slots) return 0;
+    for (uint32_t t = 0; t < 8; t++) out[t] = t < x->n_ranks ? x->slots[slot].h_tab[t] : 0;
+    return x->own_recv_bytes;
+}
+#endif
 
 // the device table of a slot and this rank's index, for abi_sixstep.hip
 extern "C" int hodor_exchange_direct_table(hodor_exchange *x, uint32_t slot, const uint64_t **tab, uint32_t *n_ranks,

@@ -45,11 +45,23 @@ extern "C" int hodor_fri_commit_dev(hodor_ctx *ctx, void *stream_, const hodor_f
     return hodor_fri_commit_combined_dev(ctx, stream_, lde_values, n, lde_factor, out_deg, HODOR_COMBINER_TRIVIAL, out);
 }
 
-extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
-                                             size_t lde_factor, size_t out_deg, int combiner, hodor_fri_proto **out)
+// One by-values commit in two halves, so that several commits can be in the queue at once (hodor_fri_commit_batch_h):
+//   fri_commit_enqueue   everything the commit launches, on `stream`, nothing waited for; the prototype it returns has its
+//                        device side complete in stream order and its host fields (roots, challenges, final
+//                        coefficients) still empty
+//   fri_commit_collect   those fields copied out of the slab's small block (the caller has made `xfer`'s stream wait for
+//                        the commit's) — after xfer.finish() the prototype is what hodor_fri_commit_combined_dev returns
+// Caller holds ctx->mu.
+namespace {
+struct FriPending {
+    hodor_fri_proto *p = nullptr;
+    uint8_t *d_small = nullptr;
+    std::vector<uint8_t> small;
+};
+
+int fri_commit_enqueue(hodor_ctx *ctx, hipStream_t stream, const hodor_fr *lde_values, size_t n, size_t lde_factor,
+                       size_t out_deg, int combiner, FriPending *pend)
 {
-    NEED_DEVICE();
-    if (!lde_values || !out) return HODOR_ERR_INVALID;
     if (combiner != HODOR_COMBINER_TRIVIAL && combiner != HODOR_COMBINER_COSET2) return HODOR_ERR_INVALID;
     const bool comb = combiner == HODOR_COMBINER_COSET2;
     if (!is_pow2(n) || !is_pow2(lde_factor) || !is_pow2(out_deg) || n < 2) return HODOR_ERR_SIZE;
@@ -66,11 +78,9 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
     }
     uint32_t log_n = log2u(n);
     HFr omega, omega_inv;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = poly_domain(ctx, log_n, &omega);
     if (rc) return rc;
     ctx->F.inverse(omega, &omega_inv);
-    hipStream_t stream = pick_stream(ctx, stream_);
 
     hodor_fri_proto *p = new (std::nothrow) hodor_fri_proto();
     if (!p) return HODOR_ERR_INVALID;
@@ -157,6 +167,10 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
             T.first_round = (uint32_t)i;
             T.half0 = (uint32_t)next_size;
             T.shave = shave;
+#ifdef HODOR_BOUNDS
+            T.lo_bytes = winv.lo_bytes;
+            T.hi_bytes = winv.hi_bytes;
+#endif
             FRICHK(fri_tail_launch(stream, T, c16, r2, ctx->mid, ctx->Q, ctx->P, comb));
             values = (const uint4 *)p->inter_values[num_steps - 1];
             tail_done = true;
@@ -166,6 +180,10 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
         FRICHK(fri_round_table_launch(stream, prev_nodes, d_chal + 2 * i, d_roots + 2 * i, winv.hi, d_hi_beta, hi_cnt,
                                       c16, r2, shave, ctx->Q, ctx->P));
         FoldArgs fold = {values, (uint4 *)next, next_size, winv.lo, d_hi_beta, winv.lo_bits, (uint32_t)i};
+#ifdef HODOR_BOUNDS
+        fold.lo_bytes = winv.lo_bytes;
+        fold.hi_bytes = 48 * hi_cnt;
+#endif
         const bool fused = merkle_fuses_fold(next_size);   // small rounds: fold inside the tree's leaf launch
         if (!fused) FRICHK(fri_fold_launch(stream, fold, ctx->Q));                                        // :70-104
         FRICHK(merkle_build_launch(stream, (const uint4 *)next, (uint4 *)nodes, next_size, ctx->mid, 1,
@@ -179,24 +197,131 @@ extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, cons
     // final: values -> ifft -> truncate (:130-145)
     rc = poly_transform(ctx, stream, values, d_fin, log2u(fin_n), OP_IFFT);
     if (rc) { fri_release(p); return rc; }
+#undef FRICHK
+    pend->p = p;
+    pend->d_small = d_small;
+    pend->small.resize(64 * (num_steps + 1) + 32 * out_deg);   // challenges | roots | final coefficients: back to back in the small block
+    return HODOR_OK;
+}
 
-    // challenges | roots | final coefficients sit back to back in the slab's small block: one copy
-    std::vector<uint8_t> small(64 * (num_steps + 1) + 32 * out_deg);
+// the copy of the small block into the caller's xfer (whose stream is ordered behind the commit's) ...
+hipError_t fri_commit_fetch(FriPending *pend, HostXfer &xfer) { return xfer.d2h(pend->small.data(), pend->d_small, pend->small.size()); }
+
+// ... and, after xfer.finish(), the host fields
+void fri_commit_finish(hodor_ctx *ctx, FriPending *pend)
+{
+    hodor_fri_proto *p = pend->p;
+    const size_t num_steps = p->num_steps;
+    note_round_trip(ctx);
+    p->roots.assign(pend->small.begin() + 32 * (num_steps + 1), pend->small.begin() + 64 * (num_steps + 1));
+    p->challenges.resize(num_steps);
+    memcpy(p->challenges.data(), pend->small.data(), 32 * num_steps);
+    p->final_coeffs.resize(p->out_deg);
+    memcpy(p->final_coeffs.data(), pend->small.data() + 64 * (num_steps + 1), 32 * p->out_deg);
+    memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
+    ctx->live_handles.fetch_add(1);
+}
+
+void fri_commit_abandon(hodor_ctx *ctx, FriPending *pend, hipStream_t stream)
+{
+    if (!pend->p) return;
+    (void)hipStreamSynchronize(stream);
+    if (pend->p->slab) pool_release(ctx, pend->p->slab, pend->p->slab_bytes);
+    delete pend->p;
+    pend->p = nullptr;
+}
+}  // namespace
+
+extern "C" int hodor_fri_commit_combined_dev(hodor_ctx *ctx, void *stream_, const hodor_fr *lde_values, size_t n,
+                                             size_t lde_factor, size_t out_deg, int combiner, hodor_fri_proto **out)
+{
+    NEED_DEVICE();
+    if (!lde_values || !out) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t stream = pick_stream(ctx, stream_);
+    FriPending pend;
+    int rc = fri_commit_enqueue(ctx, stream, lde_values, n, lde_factor, out_deg, combiner, &pend);
+    if (rc) return rc;
+    hipError_t e;
     {
         HostXfer xfer(ctx, stream);      // through the context's pinned buffer (ctx.hpp): no heap page is pinned behind our back
-        FRICHK(xfer.d2h(small.data(), d_small, small.size()));
-        FRICHK(xfer.finish());
+        e = fri_commit_fetch(&pend, xfer);
+        if (e == hipSuccess) e = xfer.finish();
     }
-    note_round_trip(ctx);
-    p->roots.assign(small.begin() + 32 * (num_steps + 1), small.begin() + 64 * (num_steps + 1));
-    p->challenges.resize(num_steps);
-    memcpy(p->challenges.data(), small.data(), 32 * num_steps);
-    p->final_coeffs.resize(out_deg);
-    memcpy(p->final_coeffs.data(), small.data() + 64 * (num_steps + 1), 32 * out_deg);
-    memcpy(p->final_root, p->roots.data() + 32 * num_steps, 32);   // roots.pop() :124
-#undef FRICHK
-    ctx->live_handles.fetch_add(1);
-    *out = p;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (e != hipErrorAssert) set_err(ctx, std::string("fri_commit: ") + hipGetErrorString(e));
+        fri_commit_abandon(ctx, &pend, stream);
+        return HODOR_ERR_DEVICE;
+    }
+    fri_commit_finish(ctx, &pend);
+    *out = pend.p;
+    return HODOR_OK;
+}
+
+// FriIop::proof_from_lde of SEVERAL polynomials at once — h1 and h2 of Prover::prove (src/prover/mod.rs:112-113: two
+// independent commits back to back).  A commit's last rounds are latency-bound (a dozen launches of a workgroup or
+// two each, the chip idle around them); issued one after the other on one stream the two tails add up.  Here commit 0
+// runs on the context's stream and commit i > 0 on an auxiliary stream of the context (ordered behind everything the
+// handles have enqueued so far), so the tail of one hides behind the hashing of the other; ONE wait and one copy hand
+// all the prototypes' roots / challenges / final coefficients to the host, and the context's stream continues behind
+// all of them.  Same prototypes, byte for byte, as `count` calls of hodor_fri_commit_h.
+extern "C" int hodor_fri_commit_batch_dev(hodor_ctx *ctx, const hodor_fr *const *lde_values, const size_t *ns, size_t count,
+                                          size_t lde_factor, size_t out_deg, int combiner, hodor_fri_proto **outs)
+{
+    NEED_DEVICE();
+    if (!lde_values || !ns || !outs || count == 0 || count > 8) return HODOR_ERR_INVALID;
+    for (size_t i = 0; i < count; i++)
+        if (!lde_values[i]) return HODOR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::vector<FriPending> pend(count);
+    std::vector<hipStream_t> streams(count, ctx->stream);
+    int rc = HODOR_OK;
+    hipError_t e = hipSuccess;
+    hipEvent_t fork = nullptr;
+    if (count > 1) {
+        e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(fork, ctx->stream);
+        for (size_t i = 1; i < count && e == hipSuccess; i++) {
+            if (!ctx->aux_streams[i - 1]) e = hipStreamCreateWithFlags(&ctx->aux_streams[i - 1], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->aux_streams[i - 1], fork, 0);   // the inputs are the handles' (ctx->stream)
+            streams[i] = ctx->aux_streams[i - 1];
+        }
+        if (fork) (void)hipEventDestroy(fork);
+    }
+    size_t enq = 0;
+    // the larger commits first: their hashing is what the others' tails hide behind
+    std::vector<size_t> order(count);
+    for (size_t i = 0; i < count; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ns[a] > ns[b]; });
+    for (; e == hipSuccess && rc == HODOR_OK && enq < count; enq++) {
+        const size_t i = order[enq];
+        rc = fri_commit_enqueue(ctx, streams[i], lde_values[i], ns[i], lde_factor, out_deg, combiner, &pend[i]);
+    }
+    // join: the context's stream behind every auxiliary stream, then one copy of all the small blocks
+    for (size_t i = 1; i < count && e == hipSuccess; i++) {
+        hipEvent_t join = nullptr;
+        e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(join, streams[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, join, 0);
+        if (join) (void)hipEventDestroy(join);
+    }
+    if (e == hipSuccess && rc == HODOR_OK) {
+        HostXfer xfer(ctx, ctx->stream);
+        for (size_t i = 0; i < count && e == hipSuccess; i++) e = fri_commit_fetch(&pend[i], xfer);
+        if (e == hipSuccess) e = xfer.finish();
+    }
+    if (e != hipSuccess || rc != HODOR_OK) {
+        (void)hipGetLastError();
+        if (e != hipSuccess && e != hipErrorAssert) set_err(ctx, std::string("fri_commit (batch): ") + hipGetErrorString(e));
+        for (size_t i = 0; i < count; i++) fri_commit_abandon(ctx, &pend[i], streams[i]);
+        return rc ? rc : HODOR_ERR_DEVICE;
+    }
+    for (size_t i = 0; i < count; i++) {
+        fri_commit_finish(ctx, &pend[i]);
+        outs[i] = pend[i].p;
+    }
+    ctx->host_round_trips.fetch_sub(count - 1);   // one wait handed all of them over
     return HODOR_OK;
 }
 
@@ -334,6 +459,7 @@ extern "C" int hodor_fri_commit_through_coefficients(hodor_ctx *ctx, const hodor
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
     DevBuf dv;
     HIPCHK(hipMalloc(&dv.p, n * 32));
+    BOUNDS_NOTE(dv.p, n * 32);
     if (int rc_up = hodor_buf_upload(ctx, dv.p, lde_values, n * 32)) return rc_up;   // small codewords through the pinned buffer
     return hodor_fri_commit_through_coefficients_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor,
                                                      out_deg, combiner, out);
@@ -353,6 +479,7 @@ extern "C" int hodor_fri_commit_combined(hodor_ctx *ctx, const hodor_fr *lde_val
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
     DevBuf dv;
     HIPCHK(hipMalloc(&dv.p, n * 32));
+    BOUNDS_NOTE(dv.p, n * 32);
     if (int rc_up = hodor_buf_upload(ctx, dv.p, lde_values, n * 32)) return rc_up;   // small codewords through the pinned buffer
     // the context's own compute stream, like every other slice entry point: in-order with the other
     // callers' transforms that share ctx->scratch (hodor_fri_commit_dev holds ctx->mu until it has

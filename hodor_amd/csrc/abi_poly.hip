@@ -84,6 +84,7 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got, hipStream_
             *got = it->first;
             ctx->pool_cached -= it->first;
             ctx->pool_live += it->first;
+            if (ctx->pool_live > ctx->pool_peak_live) ctx->pool_peak_live = ctx->pool_live;
             ctx->pool_free.erase(it);
             hipError_t e = hipSuccess;
             if (b.ev && b.last != consumer) e = hipStreamWaitEvent(consumer, b.ev, 0);
@@ -92,6 +93,7 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got, hipStream_
                 (void)hipGetLastError();
                 (void)hipStreamSynchronize(b.last);
             }
+            BOUNDS_NOTE(*out, bytes);   // the bounds build knows a block by what was ASKED for, not by its size class
             return HODOR_OK;
         }
         reap = !ctx->pool_zombies.empty();
@@ -109,8 +111,10 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got, hipStream_
         return HODOR_ERR_DEVICE;
     }
     *got = want;
+    BOUNDS_NOTE(*out, bytes);
     std::lock_guard<std::mutex> lk(ctx->pool_mu);
     ctx->pool_live += want;
+    if (ctx->pool_live > ctx->pool_peak_live) ctx->pool_peak_live = ctx->pool_live;
     return HODOR_OK;
 }
 int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got) { return pool_alloc(ctx, bytes, out, got, ctx->stream); }
@@ -118,6 +122,7 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got) { return p
 void pool_release(hodor_ctx *ctx, void *p, size_t bytes, hipStream_t last_user)
 {
     if (!p) return;
+    BOUNDS_FORGET(p);
     std::lock_guard<std::mutex> lk(ctx->pool_mu);
     hipEvent_t ev = nullptr;
     if (!ctx->pool_events.empty()) { ev = ctx->pool_events.back(); ctx->pool_events.pop_back(); }
@@ -410,6 +415,17 @@ extern "C" int hodor_ctx_trim(hodor_ctx *ctx)
     host_images_drain(ctx);
     return HODOR_OK;
 }
+// the largest number of pool bytes that were live (handed out) at one time since creation / the last reset: what a run NEEDS,
+// as opposed to what the pool has kept cached since
+extern "C" size_t hodor_ctx_pool_peak(hodor_ctx *ctx, int reset)
+{
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    const size_t peak = ctx->pool_peak_live;
+    if (reset) ctx->pool_peak_live = ctx->pool_live;
+    return peak;
+}
+
 extern "C" int hodor_ctx_pool_stats(const hodor_ctx *ctx_, size_t *cached, size_t *live)
 {
     hodor_ctx *ctx = const_cast<hodor_ctx *>(ctx_);
@@ -1257,6 +1273,24 @@ extern "C" int hodor_fri_commit_h(const hodor_poly *lde_values, size_t lde_facto
                                                          lde_factor, out_deg, combiner, out);
     return hodor_fri_commit_combined_dev(ctx, lde_values->stream(), lde_values->dfr(), lde_values->n, lde_factor, out_deg,
                                          combiner, out);
+}
+
+extern "C" int hodor_fri_commit_batch_h(const hodor_poly *const *lde_values, size_t count, size_t lde_factor, size_t out_deg,
+                                        int combiner, hodor_fri_proto **outs)
+{
+    if (!lde_values || !outs || count == 0 || count > 8 || !lde_values[0]) return HODOR_ERR_INVALID;
+    hodor_ctx *ctx = lde_values[0]->ctx;
+    NEED_DEVICE();
+    const hodor_fr *ptrs[8];
+    size_t ns[8];
+    for (size_t i = 0; i < count; i++) {
+        if (!lde_values[i] || lde_values[i]->ctx != ctx) return HODOR_ERR_INVALID;
+        NEED_FORM(lde_values[i], HODOR_FORM_VALUES);
+        POLY_SYNC(lde_values[i]);
+        ptrs[i] = lde_values[i]->dfr();
+        ns[i] = lde_values[i]->n;
+    }
+    return hodor_fri_commit_batch_dev(ctx, ptrs, ns, count, lde_factor, out_deg, combiner, outs);
 }
 
 extern "C" size_t hodor_fri_produce_proof_h(hodor_fri_proto *p, const hodor_poly *lde_values,

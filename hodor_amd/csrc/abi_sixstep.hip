@@ -26,18 +26,23 @@
 // pointwise work, iNTT — never pays them).
 #include "ctx.hpp"
 
+#ifdef HODOR_BOUNDS
+// abi_exchange.hip: the receive buffers of a slot as the host knows them; returns the size of the library's own ones (0: the caller's)
+extern "C" uint64_t hodor_exchange_direct_host_table(hodor_exchange *x, uint32_t slot, uint64_t out[8]);
+#endif
+
 namespace hodor {
 
 // dst[c][r] = src[r][c] for 32-byte elements; 16 x 16 tiles through LDS (512-byte runs both ways)
 __global__ void __launch_bounds__(256)
-k_transpose(const uint4 *src, uint4 *dst, uint64_t rows, uint64_t cols, uint32_t tiles_c)
+k_transpose(const uint4 *src, uint4 *dst, uint64_t rows, uint64_t cols, uint32_t tiles_c BXPARAM)
 {
     __shared__ uint4 lo[16][17], hi[16][17];
     const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const uint64_t by = blockIdx.x / tiles_c, bx = blockIdx.x % tiles_c;
     uint64_t r = by * 16 + ty, c = bx * 16 + tx;
     if (r < rows && c < cols) {
-        const uint4 *s = src + 2 * (r * cols + c);
+        const uint4 *s = BAT(1, src, 2 * (r * cols + c), 2);
         lo[ty][tx] = s[0];
         hi[ty][tx] = s[1];
     }
@@ -45,7 +50,7 @@ k_transpose(const uint4 *src, uint4 *dst, uint64_t rows, uint64_t cols, uint32_t
     r = by * 16 + tx;
     c = bx * 16 + ty;
     if (r < rows && c < cols) {
-        uint4 *d = dst + 2 * (c * rows + r);
+        uint4 *d = BATS(2, dst, 2 * (c * rows + r), 2);
         d[0] = lo[tx][ty];
         d[1] = hi[tx][ty];
     }
@@ -54,7 +59,7 @@ k_transpose(const uint4 *src, uint4 *dst, uint64_t rows, uint64_t cols, uint32_t
 // dst[(t*rows + i)*c2 + j] = src[i*(P*c2) + t*c2 + j]: a rows x (P*c2) block cut into the P slabs of an
 // all-to-all (runs of c2 contiguous elements)
 __global__ void __launch_bounds__(256)
-k_pack_slabs(const uint4 *src, uint4 *dst, uint32_t log_rows, uint32_t log_c2, uint32_t log_p)
+k_pack_slabs(const uint4 *src, uint4 *dst, uint32_t log_rows, uint32_t log_c2, uint32_t log_p BXPARAM)
 {
     const uint64_t total = 1ull << (log_rows + log_c2 + log_p);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -63,9 +68,9 @@ k_pack_slabs(const uint4 *src, uint4 *dst, uint32_t log_rows, uint32_t log_c2, u
         uint64_t t = (e >> log_c2) & ((1ull << log_p) - 1);
         uint64_t i = e >> (log_c2 + log_p);
         uint64_t d = (((t << log_rows) + i) << log_c2) + j;
-        const uint4 *s = src + 2 * e;
+        const uint4 *s = BAT(1, src, 2 * e, 2);
         uint4 a = s[0], b = s[1];
-        dst[2 * d] = a;
+        *BATS(2, dst, 2 * d, 2) = a;
         dst[2 * d + 1] = b;
     }
 }
@@ -220,6 +225,11 @@ extern "C" int hodor_sixstep_columns_direct_dev(hodor_ctx *ctx, void *stream, co
     L.peer_log = log_r1;                                   // output row k1 goes to rank k1 >> log_r1 ...
     L.peer_self = rank;                                    // ... as row rank*r1 + (k1 mod r1) of its [P][r1][cw] chunk buffer
     L.peer_off = (uint64_t)chunk << (log_n1 + log_cw);     // chunk buffers back to back: n_local / K elements each
+#ifdef HODOR_BOUNDS
+    L.bx_peers = P;
+    L.bx_peer_bytes = hodor_exchange_direct_host_table(x, slot, L.bx_peer_host);
+    if (!L.bx_peer_bytes) L.bx_peer_bytes = 32ull << (log_n - log_p);   // the caller's own receive buffers: n / P elements by contract
+#endif
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, nullptr, log_n1, w1, 1ull << log_n1, nullptr, nullptr,
                     nullptr, 1u << L.log_width, &L);
@@ -257,6 +267,11 @@ extern "C" int hodor_sixstep_rows_direct_dev(hodor_ctx *ctx, void *stream, const
     L.peer_tab = tab;
     L.peer_self = rank;
     L.peer_off = (uint64_t)chunk << (log_p + log_rows + log_c2);   // [K][P][rb][c2]
+#ifdef HODOR_BOUNDS
+    L.bx_peers = P;
+    L.bx_peer_bytes = hodor_exchange_direct_host_table(x, slot, L.bx_peer_host);
+    if (!L.bx_peer_bytes) L.bx_peer_bytes = 32ull << (log_n1 + log_n2 - log_p);
+#endif
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ntt_exec(ctx, pick_stream(ctx, stream), (const uint4 *)src, nullptr, log_n2, w2, 1ull << log_n2, nullptr, nullptr,
                     nullptr, 1u << log_rows, &L);
@@ -271,8 +286,11 @@ extern "C" int hodor_sixstep_pack_dev(hodor_ctx *ctx, void *stream, const hodor_
     uint64_t total = 1ull << (log_rows + log_cols);
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
+    BX_BEGIN(bx, KID_SIXSTEP_PACK);
+    BX_ADD(bx, src, total * 32);
+    BX_ADD(bx, dst, total * 32);
     hipLaunchKernelGGL(k_pack_slabs, dim3((unsigned)blocks), dim3(256), 0, pick_stream(ctx, stream),
-                       (const uint4 *)src, (uint4 *)dst, log_rows, log_cols - log_p, log_p);
+                       (const uint4 *)src, (uint4 *)dst, log_rows, log_cols - log_p, log_p BXARG(bx));
     HIPCHK(hipGetLastError());
     return HODOR_OK;
 }
@@ -285,8 +303,11 @@ extern "C" int hodor_transpose_dev(hodor_ctx *ctx, void *stream, const hodor_fr 
     if (rows == 0 || cols == 0) return HODOR_OK;
     const uint64_t tiles_c = (cols + 15) / 16, tiles_r = (rows + 15) / 16;
     if (tiles_c * tiles_r > 0x7fffffffull || tiles_c > 0xffffffffull) { set_err(ctx, "transpose: too many tiles"); return HODOR_ERR_SIZE; }
+    BX_BEGIN(bx, KID_TRANSPOSE);
+    BX_ADD(bx, src, (uint64_t)rows * cols * 32);
+    BX_ADD(bx, dst, (uint64_t)rows * cols * 32);
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)(tiles_c * tiles_r)), dim3(256), 0, pick_stream(ctx, stream),
-                       (const uint4 *)src, (uint4 *)dst, (uint64_t)rows, (uint64_t)cols, (uint32_t)tiles_c);
+                       (const uint4 *)src, (uint4 *)dst, (uint64_t)rows, (uint64_t)cols, (uint32_t)tiles_c BXARG(bx));
     HIPCHK(hipGetLastError());
     return HODOR_OK;
 }

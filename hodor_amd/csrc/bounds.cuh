@@ -3,7 +3,7 @@
 // ROCm has no compute-sanitizer and AddressSanitizer does not survive the GPU boxes, while the handle API hands out
 // POOLED device memory (abi_poly.hip): an out-of-range store lands in a neighbouring polynomial and only a lucky
 // differential test sees it.  In this build every kernel carries, as its last argument, the EXTENTS of the buffers it was
-// given (`BX`: up to 12 (base pointer, bytes) pairs filled in by its host launcher from the sizes of the call), and every
+// given (`BX`: up to 32 (base pointer, bytes) pairs filled in by its host launcher from the sizes of the call), and every
 // global load / store goes through BAT(site, base, offset, count): the element range [offset, offset + count) of the
 // buffer that starts at `base` must lie inside the extent declared for THAT base — exact per buffer, views into a shared
 // slab included.  LDS slots go through LAT(site, slot, slots).  A violation is recorded (kernel id, site, offset, extent;
@@ -42,7 +42,7 @@ struct BoundsReport {           // device memory, one per process
     unsigned long long offset, count, extent, base;
 };
 
-constexpr int BX_SLOTS = 12;
+constexpr int BX_SLOTS = 32;
 struct BX {
     const void *lo[BX_SLOTS];
     unsigned long long bytes[BX_SLOTS];
@@ -65,7 +65,7 @@ __device__ __attribute__((noinline)) inline void bx_report(const BX &X, uint32_t
     }
 }
 
-__device__ uint4 hodor_bounds_sink[64];   // where refused stores go (per translation unit; never read)
+static __device__ uint4 hodor_bounds_sink[64];   // where refused stores go (per translation unit; never read)
 
 // elements [off, off + cnt) of the array of T at `base`: inside the extent declared for `base`?
 template <class T>
@@ -89,21 +89,28 @@ __device__ __forceinline__ uint32_t bx_lds(const BX &X, uint32_t site, uint32_t 
 }
 
 #define BXPARAM , BX X
+#define BXPARAM_DEF , BX X = BX()   // after parameters that have default arguments
 #define BXDECL BX X
 #define BXARG(x) , x
 #define BXPASS , X
 #define BAT(site, base, off, cnt) hodor::bx_at(X, (site), (base), (unsigned long long)(off), (unsigned long long)(cnt), false)
 #define BATS(site, base, off, cnt) hodor::bx_at(X, (site), (base), (unsigned long long)(off), (unsigned long long)(cnt), true)
 #define LAT(site, slot, slots) hodor::bx_lds(X, (site), (slot), (slots))
+// BATP / BATSP: the shipped build keeps the pointer expression it always had (`plain`), so that its code does not move
+#define BATP(site, base, off, cnt, plain) ((void)(plain), BAT(site, base, off, cnt))
+#define BATSP(site, base, off, cnt, plain) ((void)(plain), BATS(site, base, off, cnt))
 
 #else
 
 #define BXPARAM
+#define BXPARAM_DEF
 #define BXARG(x)
 #define BXPASS
 #define BAT(site, base, off, cnt) ((base) + (off))
 #define BATS(site, base, off, cnt) ((base) + (off))
 #define LAT(site, slot, slots) (slot)
+#define BATP(site, base, off, cnt, plain) (plain)
+#define BATSP(site, base, off, cnt, plain) (plain)
 
 #endif
 
@@ -114,6 +121,9 @@ __device__ __forceinline__ uint32_t bx_lds(const BX &X, uint32_t site, uint32_t 
 namespace hodor {
 BoundsReport *bounds_report_dev();                                   // abi_bounds.hip: the process's report block
 void bounds_check_declared(uint32_t kid, const void *p, size_t bytes);   // against the allocation registry (host)
+void bounds_alloc_note(const void *p, size_t bytes);                  // a device allocation of the library's (REQUESTED size)
+void bounds_alloc_forget(const void *p);
+bool bounds_shrink();
 struct BXB {
     BX x;
     explicit BXB(uint32_t kid)
@@ -126,6 +136,9 @@ struct BXB {
     BXB &add(const void *p, size_t bytes)
     {
         if (!p) return *this;
+        // HODOR_BOUNDS_SHRINK=1 (the test of the test, tests/test_gpu_bounds.py): every extent is declared one element
+        // short, so that the kernels' own last accesses are violations
+        if (bounds_shrink() && bytes >= 64) bytes -= 32;
         for (uint32_t i = 0; i < x.n; i++)
             if (x.lo[i] == p) { if (bytes > x.bytes[i]) x.bytes[i] = bytes; return *this; }   // in place: one buffer, two roles
         if (x.n < (uint32_t)BX_SLOTS) {
@@ -141,7 +154,11 @@ struct BXB {
 }  // namespace hodor
 #define BX_BEGIN(name, kid) hodor::BXB name(kid)
 #define BX_ADD(name, p, bytes) name.add((const void *)(p), (size_t)(bytes))
+#define BOUNDS_NOTE(p, bytes) hodor::bounds_alloc_note((p), (bytes))
+#define BOUNDS_FORGET(p) hodor::bounds_alloc_forget((p))
 #else
 #define BX_BEGIN(name, kid) do {} while (0)
 #define BX_ADD(name, p, bytes) do {} while (0)
+#define BOUNDS_NOTE(p, bytes) ((void)0)
+#define BOUNDS_FORGET(p) ((void)0)
 #endif

@@ -145,6 +145,7 @@ struct hodor_ctx {
     W9Consts K9;               // 2^(29 (c + 1)) mod p, c = 0 .. 8, for the W9 table generator
     B2Mid mid;
     hipStream_t stream = nullptr;
+    hipStream_t aux_streams[7] = {};   // hodor_fri_commit_batch_*: commits beside the one on `stream` (created on first use)
     std::mutex mu;
     std::vector<PowTable> pow_tables;
     std::vector<RadixTable> radix_tables;
@@ -202,7 +203,7 @@ struct hodor_ctx {
     size_t pool_zombie_bytes = 0;
     std::vector<hipEvent_t> pool_events;        // idle events, reused
     uint64_t pool_seq = 0;
-    size_t pool_cached = 0, pool_live = 0;
+    size_t pool_cached = 0, pool_live = 0, pool_peak_live = 0;
     size_t pool_cache_cap = (size_t)64 << 30;   // idle bytes kept before blocks go back to HIP (HODOR_POOL_CACHE_GIB)
     std::mutex pool_mu;
     // device -> host results handed out so far (roots, evaluations, query answers, prototypes, as_ref() copies): every one
@@ -237,6 +238,9 @@ static inline void set_err(hodor_ctx *ctx, const std::string &msg)
     std::lock_guard<std::mutex> lk(ctx->err_mu);
     ctx->err = msg;
 }
+#ifdef HODOR_BOUNDS
+namespace hodor { int bounds_poll(hodor_ctx *ctx); }   // abi_bounds.hip: 1 = new violations (the message is in ctx->err)
+#endif
 
 // Small transfers between device and host through the context's own pinned buffer (see hodor_ctx::pinned).  Holds the
 // buffer's mutex for its lifetime; d2h() results are in the caller's memory after finish() (which synchronises `stream`);
@@ -278,6 +282,9 @@ class HostXfer {
         if (!pending_) return hipSuccess;
         pending_ = false;
         hipError_t e = hipStreamSynchronize(stream_);
+#ifdef HODOR_BOUNDS
+        if (e == hipSuccess && hodor::bounds_poll(ctx_)) e = hipErrorAssert;   // a result is about to reach the host: was every access in range?
+#endif
         if (e == hipSuccess)
             for (auto &it : items_) memcpy(it.host, (uint8_t *)ctx_->pinned + it.off, it.n);
         items_.clear();
@@ -325,7 +332,7 @@ struct hodor_fri_proto {
         hipError_t e__ = (expr);                                                      \
         if (e__ != hipSuccess) {                                                      \
             (void)hipGetLastError();   /* reported through the ABI: do not leave it for the next HIP user */ \
-            set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));         \
+            if (e__ != hipErrorAssert) set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));   /* hipErrorAssert: the bounds build's poll has written the message */ \
             return HODOR_ERR_DEVICE;                                                  \
         }                                                                             \
     } while (0)
@@ -355,7 +362,7 @@ static inline uint32_t log2u(size_t n)
 namespace {
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) { BOUNDS_FORGET(p); (void)hipFree(p); } }
 };
 }  // namespace
 
@@ -424,6 +431,11 @@ struct NttLayout {
     const uint64_t *peer_tab = nullptr;
     uint64_t peer_off = 0;
     uint32_t peer_log = 0, peer_self = 0;
+#ifdef HODOR_BOUNDS
+    uint64_t bx_peer_host[8] = {};      // bounds build: the receive buffers behind peer_tab and their size
+    uint64_t bx_peer_bytes = 0;
+    uint32_t bx_peers = 0;
+#endif
 };
 int ntt_exec(hodor_ctx *ctx, hipStream_t stream, const uint4 *src, uint4 *dst, uint32_t log_n, const HFr &omega,
              uint64_t nnz, const HFr *scale, const HFr *pre, const HFr *post, uint32_t batch = 1,

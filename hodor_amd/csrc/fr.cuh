@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bounds.cuh"
+
 namespace hodor {
 
 struct FrParams {        // passed by value as a kernel argument -> SGPRs

@@ -24,18 +24,18 @@ namespace hodor {
 // R'-form entry is R-form, i.e. short by 2^5; 2^5 / 2 = 16.
 __global__ void __launch_bounds__(256)
 k_fri_round_table(const uint4 *nodes, uint4 *chal_out, uint4 *root_out, const uint4 *hi, uint4 *hi_out,
-                  uint64_t count, Fr9 c16, Fr r2, uint32_t shave, Fr9Params Q, FrParams P)
+                  uint64_t count, Fr9 c16, Fr r2, uint32_t shave, Fr9Params Q, FrParams P BXPARAM)
 {
     __shared__ uint32_t beta_w[8];
     if (threadIdx.x == 0) {
-        const uint4 r0 = nodes[2], r1 = nodes[3];   // nodes[1] = the root
+        const uint4 r0 = *BAT(60, nodes, 2, 2), r1 = nodes[3];   // nodes[1] = the root
         const uint32_t d[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         Fr beta = b2s_digest_to_challenge(d, r2, shave, P);
 #pragma unroll
         for (int i = 0; i < 8; i++) beta_w[i] = beta.v[i];
         if (blockIdx.x == 0) {
-            fr_store(chal_out, beta);
-            root_out[0] = r0;
+            fr_store(BATS(1, chal_out, 0, 2), beta);
+            *BATS(61, root_out, 0, 2) = r0;
             root_out[1] = r1;
         }
     }
@@ -46,28 +46,28 @@ k_fri_round_table(const uint4 *nodes, uint4 *chal_out, uint4 *root_out, const ui
 #pragma unroll
     for (int i = 0; i < 8; i++) beta.v[i] = beta_w[i];
     Fr9 b16 = fr9_mul(fr9_unpack(beta), c16, Q);           // beta * 16, R-form, normalized, < 2p
-    Fr9 h = fr9_mul(b16, fr9_load48(hi + 3 * j), Q);       // beta * 16 * h_j * 2^256 = (beta h_j / 2) 2^261
-    fr9_store48(hi_out + 3 * j, h);
+    Fr9 h = fr9_mul(b16, fr9_load48(BAT(2, hi, 3 * j, 3)), Q);       // beta * 16 * h_j * 2^256 = (beta h_j / 2) 2^261
+    fr9_store48(BATS(3, hi_out, 3 * j, 3), h);
 }
 
 __global__ void __launch_bounds__(256)
-k_fri_fold(FoldArgs F, Fr9Params Q)
+k_fri_fold(FoldArgs F, Fr9Params Q BXPARAM)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < F.half; i += stride)
-        fr_store(F.dst + 2 * i, fri_fold_one(F, i, Q));
+        fr_store(BATS(4, F.dst, 2 * i, 2), fri_fold_one(F, i, Q BXPASS));
 }
 
 // The coefficient fold of NaiveFriIop::proof_from_lde_through_coefficients
 // (/root/reference/src/fri/mod.rs:194-203): next[i] = a[2i] + beta * a[2i+1], beta read from device memory
 // (the challenge the previous tree's root gave, R-form) so the chain of rounds never visits the host.
 __global__ void __launch_bounds__(256)
-k_fri_fold_coeffs(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *chal, FrParams P)
+k_fri_fold_coeffs(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *chal, FrParams P BXPARAM)
 {
-    const Fr beta = fr_load(chal);
+    const Fr beta = fr_load(BAT(5, chal, 0, 2));
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
-        fr_store(dst + 2 * i, fr_add(fr_load(src + 4 * i), fr_mul(fr_load(src + 4 * i + 2), beta, P), P));
+        fr_store(BATS(8, dst, 2 * i, 2), fr_add(fr_load(BAT(6, src, 4 * i, 2)), fr_mul(fr_load(BAT(7, src, 4 * i + 2, 2)), beta, P), P));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -85,7 +85,7 @@ k_fri_fold_coeffs(const uint4 *src, uint4 *dst, uint64_t half, const uint4 *chal
 // the h/2 leaves has h/2 heap entries.  Rounds of fewer than 4 outputs do not occur (abi_fri.hip refuses them).
 template <bool COMB>
 __global__ void __launch_bounds__(FRI_TAIL_THREADS)
-k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
+k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P BXPARAM)
 {
     constexpr uint32_t QUADS = FRI_TAIL_THREADS / 4;       // hashes per pass in quad-lane mode
     __shared__ uint4 buf_a[2 * FRI_TAIL_THREADS];          // leaf hashes, then every other level
@@ -103,16 +103,16 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
         const bool quad_leafs = leaves <= QUADS;
         if (tid < h) {
             // fold (fri_on_values.rs:77-100), same arithmetic as k_fri_round_table + k_fri_fold
-            Fr9 b16 = fr9_mul(fr9_unpack(fr_load(A.chal + 2 * gi)), c16, Q);
-            Fr9 a = fr9_unpack(fr_load(src + 2 * tid)), b = fr9_unpack(fr_load(src + 2 * (tid + h)));
+            Fr9 b16 = fr9_mul(fr9_unpack(fr_load(BAT(9, A.chal, 2 * gi, 2))), c16, Q);
+            Fr9 a = fr9_unpack(fr_load(BAT(10, src, 2 * tid, 2))), b = fr9_unpack(fr_load(BAT(11, src, 2 * (tid + h), 2)));
             uint64_t e = (uint64_t)tid << gi;
-            Fr9 tw = fr9_load48(A.hi + 3 * (e >> A.lo_bits));
-            if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(A.lo + 3 * (e & lo_mask)), Q);
+            Fr9 tw = fr9_load48(BAT(12, A.hi, 3 * (e >> A.lo_bits), 3));
+            if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(BAT(13, A.lo, 3 * (e & lo_mask), 3)), Q);
             tw = fr9_mul(b16, tw, Q);                            // w^-e * beta / 2, R'-form
             Fr9 odd = fr9_mul(fr9_sub(a, b, Q), tw, Q);
             Fr9 even = fr9_halve(fr9_add(a, b), Q);
             Fr y = fr9_to_canonical(fr9_add(even, odd), Q);
-            fr_store(dst + 2 * tid, y);
+            fr_store(BATS(14, dst, 2 * tid, 2), y);
             const uint4 y0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]), y1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
             if (COMB) {
                 // message block of leaf tid mod h/2, lower or upper 32 bytes; the blocks of a round too wide for
@@ -155,7 +155,7 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
                     b2q_compress(bq, reinterpret_cast<const uint32_t *>(s + 4 * quad), B2Q_NODE, lo, hi);
                     uint32_t *o = reinterpret_cast<uint32_t *>(d + 2 * quad);
                     o[j] = lo; o[4 + j] = hi;
-                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes + 2 * (w + quad));
+                    uint32_t *g = reinterpret_cast<uint32_t *>(BATS(62, nodes, 2 * (w + quad), 2));
                     g[j] = lo; g[4 + j] = hi;
                 }
             } else if (tid < w) {
@@ -165,7 +165,7 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
                 uint32_t out[8];
                 b2s_node(mid, l, r, out);
                 uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
-                nodes[2 * (w + tid)] = o0; nodes[2 * (w + tid) + 1] = o1;
+                *BATS(63, nodes, 2 * (w + tid), 2) = o0; nodes[2 * (w + tid) + 1] = o1;
                 d[2 * tid] = o0; d[2 * tid + 1] = o1;
             }
             __syncthreads();
@@ -174,10 +174,10 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
         if (tid == 0) {                                          // s[0..1] = the root: challenge of the next round
             uint4 o0 = s[0], o1 = s[1];
             uint32_t out[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-            nodes[0] = make_uint4(0, 0, 0, 0);
+            *BATS(64, nodes, 0, 2) = make_uint4(0, 0, 0, 0);
             nodes[1] = make_uint4(0, 0, 0, 0);
-            A.roots[2 * (gi + 1)] = o0; A.roots[2 * (gi + 1) + 1] = o1;
-            fr_store(A.chal + 2 * (gi + 1), b2s_digest_to_challenge(out, r2, A.shave, P));
+            *BATS(65, A.roots, 2 * (gi + 1), 2) = o0; A.roots[2 * (gi + 1) + 1] = o1;
+            fr_store(BATS(15, A.chal, 2 * (gi + 1), 2), b2s_digest_to_challenge(out, r2, A.shave, P));
         }
         __syncthreads();
         src = dst;
@@ -187,8 +187,19 @@ k_fri_tail(FriTailArgs A, Fr9 c16, Fr r2, B2Mid mid, Fr9Params Q, FrParams P)
 hipError_t fri_tail_launch(hipStream_t s, const FriTailArgs &A, const Fr9 &c16, const Fr &r2, const B2Mid &mid,
                            const Fr9Params &Q, const FrParams &P, bool comb)
 {
-    if (comb) hipLaunchKernelGGL(k_fri_tail<true>, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P);
-    else hipLaunchKernelGGL(k_fri_tail<false>, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P);
+    BX_BEGIN(bx, KID_FRI_TAIL);
+    BX_ADD(bx, A.src, 2ull * A.half0 * 32);
+    for (uint32_t k = 0; k < A.rounds; k++) {
+        BX_ADD(bx, A.values[k], (uint64_t)(A.half0 >> k) * 32);
+        BX_ADD(bx, A.nodes[k], (uint64_t)((A.half0 >> k) >> (comb ? 1 : 0)) * 32);
+    }
+    BX_ADD(bx, A.chal, (uint64_t)(A.first_round + A.rounds + 1) * 32);
+    BX_ADD(bx, A.roots, (uint64_t)(A.first_round + A.rounds + 1) * 32);
+#ifdef HODOR_BOUNDS
+    bx.add(A.lo, A.lo_bytes).add(A.hi, A.hi_bytes);
+#endif
+    if (comb) hipLaunchKernelGGL(k_fri_tail<true>, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P BXARG(bx));
+    else hipLaunchKernelGGL(k_fri_tail<false>, dim3(1), dim3(FRI_TAIL_THREADS), 0, s, A, c16, r2, mid, Q, P BXARG(bx));
     return hipGetLastError();
 }
 
@@ -196,8 +207,14 @@ hipError_t fri_round_table_launch(hipStream_t s, const uint4 *nodes, uint4 *chal
                                   const uint4 *hi, uint4 *hi_out, uint64_t count, const Fr9 &c16, const Fr &r2,
                                   uint32_t shave, const Fr9Params &Q, const FrParams &P)
 {
+    BX_BEGIN(bx, KID_FRI_ROUND_TABLE);
+    BX_ADD(bx, nodes, 64);
+    BX_ADD(bx, chal_out, 32);
+    BX_ADD(bx, root_out, 32);
+    BX_ADD(bx, hi, count * 48);
+    BX_ADD(bx, hi_out, count * 48);
     hipLaunchKernelGGL(k_fri_round_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, nodes, chal_out,
-                       root_out, hi, hi_out, count, c16, r2, shave, Q, P);
+                       root_out, hi, hi_out, count, c16, r2, shave, Q, P BXARG(bx));
     return hipGetLastError();
 }
 
@@ -206,7 +223,11 @@ hipError_t fri_fold_coeffs_launch(hipStream_t s, const uint4 *src, uint4 *dst, u
 {
     uint64_t blocks = (half + 255) / 256;
     unsigned grid = (unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
-    hipLaunchKernelGGL(k_fri_fold_coeffs, dim3(grid), dim3(256), 0, s, src, dst, half, chal, P);
+    BX_BEGIN(bx, KID_FRI_FOLD_COEFFS);
+    BX_ADD(bx, src, 2 * half * 32);
+    BX_ADD(bx, dst, half * 32);
+    BX_ADD(bx, chal, 32);
+    hipLaunchKernelGGL(k_fri_fold_coeffs, dim3(grid), dim3(256), 0, s, src, dst, half, chal, P BXARG(bx));
     return hipGetLastError();
 }
 
@@ -214,7 +235,13 @@ hipError_t fri_fold_launch(hipStream_t s, const FoldArgs &F, const Fr9Params &Q)
 {
     uint64_t blocks = (F.half + 255) / 256;
     unsigned grid = (unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
-    hipLaunchKernelGGL(k_fri_fold, dim3(grid), dim3(256), 0, s, F, Q);
+    BX_BEGIN(bx, KID_FRI_FOLD);
+    BX_ADD(bx, F.src, 2 * F.half * 32);
+    BX_ADD(bx, F.dst, F.half * 32);
+#ifdef HODOR_BOUNDS
+    bx.add(F.lo, F.lo_bytes).add(F.hi_beta, F.hi_bytes);
+#endif
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid), dim3(256), 0, s, F, Q BXARG(bx));
     return hipGetLastError();
 }
 

@@ -906,6 +906,24 @@ struct NaiveFriIop {
     {
         return commit(lde_values, lde_factor, output_coeffs_at_degree_plus_one, combiner, 0, "proof_from_lde_by_values");
     }
+    // several commits at once — h1 and h2 of Prover::prove (src/prover/mod.rs:112-113): their latency-bound tails overlap
+    // on streams of the context, one wait hands all prototypes over (hodor_fri_commit_batch_h); the prototypes are those
+    // of one proof_from_lde each
+    static std::vector<FRIProofPrototype> proof_from_lde_all(const std::vector<const Polynomial<Values> *> &ldes, size_t lde_factor,
+                                                             size_t output_coeffs_at_degree_plus_one, int combiner = HODOR_COMBINER_TRIVIAL)
+    {
+        std::vector<FRIProofPrototype> out;
+        if (ldes.empty()) return out;
+        const Field &F = *ldes[0]->F;
+        std::vector<const hodor_poly *> in;
+        for (auto *l : ldes) in.push_back(l->h);
+        std::vector<hodor_fri_proto *> hs(ldes.size(), nullptr);
+        F.check(hodor_fri_commit_batch_h(in.data(), in.size(), lde_factor, output_coeffs_at_degree_plus_one, combiner, hs.data()),
+                "proof_from_lde (batch)");
+        out.resize(ldes.size());
+        for (size_t i = 0; i < ldes.size(); i++) out[i].load(F, hs[i], ldes[i]->size(), lde_factor, output_coeffs_at_degree_plus_one);
+        return out;
+    }
     static FRIProofPrototype proof_from_lde_by_values(const Polynomial<Values> &lde_values, size_t lde_factor,
                                                       size_t output_coeffs_at_degree_plus_one)
     {

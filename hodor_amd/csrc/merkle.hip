@@ -58,8 +58,16 @@ constexpr uint32_t MERKLE_LAT_LOG_CH = 8;    // latency: 256 inputs per workgrou
 template <bool LEAF, bool LAT, bool FOLD = false, bool COMB = false>
 __global__ void __launch_bounds__(256)
 k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, uint32_t levels, uint64_t n,
-                 B2Mid mid, FoldArgs fold = FoldArgs(), Fr9Params Q = Fr9Params())
+                 B2Mid mid, FoldArgs fold = FoldArgs(), Fr9Params Q = Fr9Params() BXPARAM_DEF)
 {
+#ifdef HODOR_BOUNDS
+    // the buffers as the launcher declared them, and where this tree's arrays start in them (bounds.cuh)
+    const uint4 *const leafs0 = leafs;
+    uint4 *const nodes0 = nodes;
+    const uint64_t leaf_off = 2 * (uint64_t)blockIdx.y * n, node_off = 2 * (uint64_t)blockIdx.y * (COMB ? n >> 1 : n);
+    const uint4 *const in_base = LEAF ? leafs0 : (const uint4 *)nodes0;
+    const uint64_t in_off = LEAF ? leaf_off + 2 * ((uint64_t)blockIdx.x << log_ch) : node_off + 2 * (m + ((uint64_t)blockIdx.x << log_ch));
+#endif
     // blockIdx.y selects one of several independent trees over n values each (batched commit)
     leafs += 2 * (uint64_t)blockIdx.y * n;
     nodes += 2 * (uint64_t)blockIdx.y * (COMB ? n >> 1 : n);
@@ -81,20 +89,20 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
             uint4 a0, a1, b0, b1;
             if (FOLD) {
                 const uint64_t i = (chunk << log_ch) + p;
-                Fr y = fri_fold_one(fold, i, Q);
-                fr_store(fold.dst + 2 * i, y);
+                Fr y = fri_fold_one(fold, i, Q BXPASS);
+                fr_store(BATS(1, fold.dst, 2 * i, 2), y);
                 a0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
                 a1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
                 if (COMB) {
-                    y = fri_fold_one(fold, i + half, Q);
-                    fr_store(fold.dst + 2 * (i + half), y);
+                    y = fri_fold_one(fold, i + half, Q BXPASS);
+                    fr_store(BATS(2, fold.dst, 2 * (i + half), 2), y);
                     b0 = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
                     b1 = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
                 }
             } else {
-                a0 = in[2 * p];
+                a0 = *BATP(3, in_base, in_off + 2 * p, 2, in + 2 * p);
                 a1 = in[2 * p + 1];
-                if (COMB) { b0 = in[2 * (p + half)]; b1 = in[2 * (p + half) + 1]; }
+                if (COMB) { b0 = *BATP(4, in_base, in_off + 2 * (p + half), 2, in + 2 * (p + half)); b1 = in[2 * (p + half) + 1]; }
             }
             if (LEAF) {
                 uint32_t out[8];
@@ -116,27 +124,27 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
                 // the two leaves of this lane are FRI fold outputs that do not exist yet: compute them
                 // (two products each), store them as the round's values, hash them from registers
                 const uint64_t i = (chunk << log_ch) + 2 * p;
-                Fr y0 = fri_fold_one(fold, i, Q), y1 = fri_fold_one(fold, i + 1, Q);
-                fr_store(fold.dst + 2 * i, y0);
-                fr_store(fold.dst + 2 * i + 2, y1);
+                Fr y0 = fri_fold_one(fold, i, Q BXPASS), y1 = fri_fold_one(fold, i + 1, Q BXPASS);
+                fr_store(BATS(5, fold.dst, 2 * i, 2), y0);
+                fr_store(BATS(6, fold.dst, 2 * i + 2, 2), y1);
                 a0 = make_uint4(y0.v[0], y0.v[1], y0.v[2], y0.v[3]);
                 a1 = make_uint4(y0.v[4], y0.v[5], y0.v[6], y0.v[7]);
                 b0 = make_uint4(y1.v[0], y1.v[1], y1.v[2], y1.v[3]);
                 b1 = make_uint4(y1.v[4], y1.v[5], y1.v[6], y1.v[7]);
                 if (COMB) {
-                    y0 = fri_fold_one(fold, i + half, Q);
-                    y1 = fri_fold_one(fold, i + half + 1, Q);
-                    fr_store(fold.dst + 2 * (i + half), y0);
-                    fr_store(fold.dst + 2 * (i + half) + 2, y1);
+                    y0 = fri_fold_one(fold, i + half, Q BXPASS);
+                    y1 = fri_fold_one(fold, i + half + 1, Q BXPASS);
+                    fr_store(BATS(7, fold.dst, 2 * (i + half), 2), y0);
+                    fr_store(BATS(8, fold.dst, 2 * (i + half) + 2, 2), y1);
                     c0 = make_uint4(y0.v[0], y0.v[1], y0.v[2], y0.v[3]);
                     c1 = make_uint4(y0.v[4], y0.v[5], y0.v[6], y0.v[7]);
                     d0 = make_uint4(y1.v[0], y1.v[1], y1.v[2], y1.v[3]);
                     d1 = make_uint4(y1.v[4], y1.v[5], y1.v[6], y1.v[7]);
                 }
             } else {
-                const uint4 *q = in + 4 * p;
+                const uint4 *q = BATP(9, in_base, in_off + 4 * p, 4, in + 4 * p);
                 a0 = q[0]; a1 = q[1]; b0 = q[2]; b1 = q[3];
-                if (COMB) { q += 2 * half; c0 = q[0]; c1 = q[1]; d0 = q[2]; d1 = q[3]; }
+                if (COMB) { q = BATP(10, in_base, in_off + 4 * p + 2 * half, 4, q + 2 * half); c0 = q[0]; c1 = q[1]; d0 = q[2]; d1 = q[3]; }
             }
             uint32_t l[8], r[8], out[8];
             if (LEAF && COMB) {
@@ -151,7 +159,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
             }
             b2s_node(mid, l, r, out);
             uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
-            lvl_out[2 * p] = o0; lvl_out[2 * p + 1] = o1;
+            *BATSP(11, nodes0, node_off + 2 * ((m >> 1) + chunk * (ch >> 1)) + 2 * p, 2, lvl_out + 2 * p) = o0; lvl_out[2 * p + 1] = o1;
             buf_a[2 * p] = o0; buf_a[2 * p + 1] = o1;
         }
         k0 = 2;
@@ -171,7 +179,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
                 b2q_compress(bq, reinterpret_cast<const uint32_t *>(src + 4 * quad), B2Q_NODE, lo, hi);
                 uint32_t *o = reinterpret_cast<uint32_t *>(dst + 2 * quad);
                 o[j] = lo; o[4 + j] = hi;
-                uint32_t *g = reinterpret_cast<uint32_t *>(lvl_out + 2 * quad);
+                uint32_t *g = reinterpret_cast<uint32_t *>(BATSP(12, nodes0, node_off + 2 * ((m >> k) + chunk * w) + 2 * quad, 2, lvl_out + 2 * quad));
                 g[j] = lo; g[4 + j] = hi;
             }
         } else {
@@ -182,7 +190,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
                 uint32_t out[8];
                 b2s_node(mid, l, r, out);
                 uint4 o0 = make_uint4(out[0], out[1], out[2], out[3]), o1 = make_uint4(out[4], out[5], out[6], out[7]);
-                lvl_out[2 * g] = o0; lvl_out[2 * g + 1] = o1;
+                *BATSP(13, nodes0, node_off + 2 * ((m >> k) + chunk * w) + 2 * g, 2, lvl_out + 2 * g) = o0; lvl_out[2 * g + 1] = o1;
                 dst[2 * g] = o0; dst[2 * g + 1] = o1;
             }
         }
@@ -191,7 +199,7 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
     }
     // the launch that produces the root also clears nodes[0], which the heap layout leaves unused
     if ((m >> levels) == 1 && tid == 0) {
-        nodes[0] = make_uint4(0, 0, 0, 0);
+        *BATSP(14, nodes0, node_off, 2, nodes) = make_uint4(0, 0, 0, 0);
         nodes[1] = make_uint4(0, 0, 0, 0);
     }
 }
@@ -200,18 +208,18 @@ k_merkle_subtree(const uint4 *leafs, uint4 *nodes, uint64_t m, uint32_t log_ch, 
 // 256 - CAPACITY bits, convert to Montgomery form (multiply by R^2).
 // `root_out` (optional) receives a copy of the root digest: the FRI round loop collects its roots there.
 __global__ void k_challenge(const uint4 *nodes, uint4 *out, uint4 *root_out, Fr r2, uint32_t shave_bits,
-                            FrParams P)
+                            FrParams P BXPARAM)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (root_out) {
-        root_out[0] = nodes[2];
+        *BATS(1, root_out, 0, 2) = nodes[2];
         root_out[1] = nodes[3];
     }
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(nodes + 2);   // nodes[1]
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(BAT(2, nodes, 2, 2));   // nodes[1]
     uint32_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) w[i] = d[i];
-    fr_store(out, b2s_digest_to_challenge(w, r2, shave_bits, P));
+    fr_store(BATS(3, out, 0, 2), b2s_digest_to_challenge(w, r2, shave_bits, P));
 }
 
 // Query phase on device-resident oracles: IOP::query + IopTree::get_path
@@ -219,14 +227,14 @@ __global__ void k_challenge(const uint4 *nodes, uint4 *out, uint4 *root_out, Fr 
 // out[1] = hash of its sibling leaf, out[1 + k] = sibling node at tree level log2(n) - 1 - k.
 // `leaf_pair` points at the even leaf of the pair {index & ~1, index | 1}.
 __global__ void k_iop_query(const uint4 *leaf_pair, const uint4 *nodes, uint64_t n, uint64_t index,
-                            uint4 *out, B2Mid mid)
+                            uint4 *out, B2Mid mid BXPARAM)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t levels = 0;
     for (uint64_t w = n >> 1; w >= 2; w >>= 1) levels++;   // log2(n) - 1 node levels on the path
     if (lane == 0) {
-        const uint4 *me = leaf_pair + 2 * (index & 1), *sib = leaf_pair + 2 * ((index & 1) ^ 1);
-        out[0] = me[0];
+        const uint4 *me = BAT(1, leaf_pair, 2 * (index & 1), 2), *sib = BAT(2, leaf_pair, 2 * ((index & 1) ^ 1), 2);
+        *BATS(3, out, 0, 4) = me[0];
         out[1] = me[1];
         uint32_t h[8];
         b2s_leaf(mid, sib[0], sib[1], h);
@@ -236,8 +244,8 @@ __global__ void k_iop_query(const uint4 *leaf_pair, const uint4 *nodes, uint64_t
         uint32_t k = lane - 1;                       // k-th node level from the bottom
         uint64_t width = n >> (k + 1);               // level stored at nodes[width .. 2*width)
         uint64_t idx = (index >> (k + 1)) ^ 1;
-        const uint4 *src = nodes + 2 * (width + idx);
-        out[2 * (lane + 1)] = src[0];
+        const uint4 *src = BAT(4, nodes, 2 * (width + idx), 2);
+        *BATS(5, out, 2 * (lane + 1), 2) = src[0];
         out[2 * (lane + 1) + 1] = src[1];
     }
 }
@@ -245,17 +253,17 @@ __global__ void k_iop_query(const uint4 *leaf_pair, const uint4 *nodes, uint64_t
 // The same for a COSET2 tree (n values, n/2 leaves): out[0] = value[k], out[1] = value[k + n/2] for the leaf
 // k = index mod n/2, out[2] = hash of the sibling leaf, out[2 + j] = sibling node at tree level log2(n/2) - 1 - j.
 __global__ void k_iop_query_coset2(const uint4 *values, const uint4 *nodes, uint64_t n, uint64_t index, uint4 *out,
-                                   B2Mid mid)
+                                   B2Mid mid BXPARAM)
 {
     const uint32_t lane = threadIdx.x;
     const uint64_t leaves = n >> 1, k = index & (leaves - 1);
     uint32_t levels = 0;
     for (uint64_t w = leaves >> 1; w >= 2; w >>= 1) levels++;   // log2(leaves) - 1 node levels on the path
     if (lane == 0) {
-        const uint4 *lo = values + 2 * k, *hi = values + 2 * (k + leaves);
-        out[0] = lo[0]; out[1] = lo[1];
+        const uint4 *lo = BAT(1, values, 2 * k, 2), *hi = BAT(2, values, 2 * (k + leaves), 2);
+        *BATS(3, out, 0, 6) = lo[0]; out[1] = lo[1];
         out[2] = hi[0]; out[3] = hi[1];
-        const uint4 *slo = values + 2 * (k ^ 1), *shi = values + 2 * ((k ^ 1) + leaves);
+        const uint4 *slo = BAT(4, values, 2 * (k ^ 1), 2), *shi = BAT(5, values, 2 * ((k ^ 1) + leaves), 2);
         uint32_t h[8];
         b2s_pair(mid, slo[0], slo[1], shi[0], shi[1], h);
         out[4] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -264,8 +272,8 @@ __global__ void k_iop_query_coset2(const uint4 *values, const uint4 *nodes, uint
         uint32_t j = lane - 1;
         uint64_t width = leaves >> (j + 1);
         uint64_t idx = (k >> (j + 1)) ^ 1;
-        const uint4 *src = nodes + 2 * (width + idx);
-        out[2 * (lane + 2)] = src[0];
+        const uint4 *src = BAT(6, nodes, 2 * (width + idx), 2);
+        *BATS(7, out, 2 * (lane + 2), 2) = src[0];
         out[2 * (lane + 2) + 1] = src[1];
     }
 }
@@ -276,14 +284,22 @@ __global__ void k_iop_query_coset2(const uint4 *values, const uint4 *nodes, uint
 hipError_t iop_query_coset2_launch(hipStream_t s, const uint4 *values, const uint4 *nodes, uint64_t n,
                                    uint64_t index, uint4 *out, const B2Mid &mid)
 {
-    hipLaunchKernelGGL(k_iop_query_coset2, dim3(1), dim3(64), 0, s, values, nodes, n, index, out, mid);
+    BX_BEGIN(bx, KID_IOP_QUERY_COSET2);
+    BX_ADD(bx, values, n * 32);
+    BX_ADD(bx, nodes, (n / 2) * 32);
+    BX_ADD(bx, out, (uint64_t)(64 - __builtin_clzll(n)) * 32);   // two values + log2(n) - 1 digests = log2(n) + 1 entries
+    hipLaunchKernelGGL(k_iop_query_coset2, dim3(1), dim3(64), 0, s, values, nodes, n, index, out, mid BXARG(bx));
     return hipGetLastError();
 }
 
 hipError_t iop_query_launch(hipStream_t s, const uint4 *leaf_pair, const uint4 *nodes, uint64_t n,
                             uint64_t index, uint4 *out, const B2Mid &mid)
 {
-    hipLaunchKernelGGL(k_iop_query, dim3(1), dim3(64), 0, s, leaf_pair, nodes, n, index, out, mid);
+    BX_BEGIN(bx, KID_IOP_QUERY);
+    BX_ADD(bx, leaf_pair, 64);
+    BX_ADD(bx, nodes, n * 32);
+    BX_ADD(bx, out, (uint64_t)(64 - __builtin_clzll(n)) * 32);   // the value + log2(n) digests = log2(n) + 1 entries
+    hipLaunchKernelGGL(k_iop_query, dim3(1), dim3(64), 0, s, leaf_pair, nodes, n, index, out, mid BXARG(bx));
     return hipGetLastError();
 }
 
@@ -326,27 +342,35 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
             if (threads < 64) threads = 64;
         }
         dim3 grid((unsigned)chunks, batch);
+        BX_BEGIN(bx, KID_MERKLE_SUBTREE);
+        BX_ADD(bx, leafs, (uint64_t)batch * n * 32);
+        BX_ADD(bx, nodes, (uint64_t)batch * (comb ? n >> 1 : n) * 32);
+#ifdef HODOR_BOUNDS
+        if (fold) {
+            bx.add(fold->src, 2 * fold->half * 32).add(fold->dst, fold->half * 32).add(fold->lo, fold->lo_bytes).add(fold->hi_beta, fold->hi_bytes);
+        }
+#endif
         if (first && comb) {
             const FoldArgs fa = fold ? *fold : FoldArgs();
             const Fr9Params qa = Q ? *Q : Fr9Params();
-            if (lat && fold)  hipLaunchKernelGGL((k_merkle_subtree<true, true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
-            else if (lat)     hipLaunchKernelGGL((k_merkle_subtree<true, true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
-            else if (fold)    hipLaunchKernelGGL((k_merkle_subtree<true, false, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
-            else              hipLaunchKernelGGL((k_merkle_subtree<true, false, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa);
+            if (lat && fold)  hipLaunchKernelGGL((k_merkle_subtree<true, true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa BXARG(bx));
+            else if (lat)     hipLaunchKernelGGL((k_merkle_subtree<true, true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa BXARG(bx));
+            else if (fold)    hipLaunchKernelGGL((k_merkle_subtree<true, false, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa BXARG(bx));
+            else              hipLaunchKernelGGL((k_merkle_subtree<true, false, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, fa, qa BXARG(bx));
         } else if (first && lat && fold)
-            hipLaunchKernelGGL((k_merkle_subtree<true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
+            hipLaunchKernelGGL((k_merkle_subtree<true, true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q BXARG(bx));
         else if (first && lat)
-            hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
+            hipLaunchKernelGGL((k_merkle_subtree<true, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params() BXARG(bx));
         else if (first && fold)
-            hipLaunchKernelGGL((k_merkle_subtree<true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q);
+            hipLaunchKernelGGL((k_merkle_subtree<true, false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, *fold, *Q BXARG(bx));
         else if (first)
-            hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params());
+            hipLaunchKernelGGL((k_merkle_subtree<true, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, n, mid, FoldArgs(), Fr9Params() BXARG(bx));
         // (the launches above the leaves use `n` only as the distance between the batch's node arrays: n/2 entries for a
         // COSET2 tree)
         else if (lat)
-            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, comb ? n >> 1 : n, mid, FoldArgs(), Fr9Params());
+            hipLaunchKernelGGL((k_merkle_subtree<false, true>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, comb ? n >> 1 : n, mid, FoldArgs(), Fr9Params() BXARG(bx));
         else
-            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, comb ? n >> 1 : n, mid, FoldArgs(), Fr9Params());
+            hipLaunchKernelGGL((k_merkle_subtree<false, false>), grid, dim3(threads), 0, s, leafs, nodes, m, log_ch, levels, comb ? n >> 1 : n, mid, FoldArgs(), Fr9Params() BXARG(bx));
         m >>= levels;
         first = false;
     }
@@ -356,7 +380,11 @@ hipError_t merkle_build_launch(hipStream_t s, const uint4 *leafs, uint4 *nodes, 
 hipError_t challenge_launch(hipStream_t s, const uint4 *nodes, uint4 *out, uint4 *root_out, const Fr &r2,
                             uint32_t shave_bits, const FrParams &P)
 {
-    hipLaunchKernelGGL(k_challenge, dim3(1), dim3(64), 0, s, nodes, out, root_out, r2, shave_bits, P);
+    BX_BEGIN(bx, KID_CHALLENGE);
+    BX_ADD(bx, nodes, 64);       // nodes[0..2): the root is nodes[1]
+    BX_ADD(bx, out, 32);
+    BX_ADD(bx, root_out, 32);
+    hipLaunchKernelGGL(k_challenge, dim3(1), dim3(64), 0, s, nodes, out, root_out, r2, shave_bits, P BXARG(bx));
     return hipGetLastError();
 }
 

@@ -18,6 +18,9 @@ struct TwoLevel {
     const uint4 *lo;
     const uint4 *hi;
     uint32_t lo_bits;
+#ifdef HODOR_BOUNDS
+    uint64_t lo_bytes, hi_bytes;   // sizes of the two tables, for the launchers' extent declarations (bounds.cuh)
+#endif
 };
 
 // 2^87, 2^174, 2^261 mod p as plain integers: turn an R-form power into its W3 entry (fr9w3.cuh)
@@ -84,6 +87,12 @@ struct PassArgs {
     uint32_t peer_log;       // column mode: log2(rows per slab): output row o goes to rank o >> peer_log, as row
     uint32_t peer_self;      //   (peer_self << peer_log) + (o mod rows per slab); split mode: rank x >> hi_log, slab peer_self
     uint32_t dbg;            // read only by -DHODOR_ABLATE builds (bench/ablate.sh): 1 skip butterflies, 2 twiddles, 4 loads, 8 stores
+#ifdef HODOR_BOUNDS
+    // host side only (ntt_exec -> ntt_launch_pass): the extents of the buffers of this pass (bounds.cuh)
+    uint64_t bx_src_bytes, bx_dst_bytes, bx_rtw_bytes, bx_rtw9_bytes, bx_peer_bytes;
+    uint64_t bx_peer_host[8];    // the receive buffers peer_tab points at, as the host knows them
+    uint32_t bx_peers;
+#endif
 };
 
 // One FRI folding step (src/fri/fri_on_values.rs:77-100), shared by k_fri_fold (fri.hip) and the fused
@@ -96,6 +105,9 @@ struct FoldArgs {
     const uint4 *hi_beta;    // ... its `hi` half scaled by beta / 2 for this round (k_fri_round_table)
     uint32_t lo_bits;
     uint32_t log_stride;     // round index: element i pairs with exponent i << log_stride
+#ifdef HODOR_BOUNDS
+    uint64_t lo_bytes, hi_bytes;   // sizes of the two tables (host side, for the launchers' extent declarations)
+#endif
 };
 
 // exact halving of a lazy value: add p when odd, shift right one bit across the 29-bit limbs
@@ -114,12 +126,12 @@ __device__ __forceinline__ Fr9 fr9_halve(Fr9 a, const Fr9Params &Q)
 }
 
 // next[i] = (f[i] + f[i+half]) / 2 + (f[i] - f[i+half]) * w^-(i << log_stride) * beta / 2, canonical
-__device__ __forceinline__ Fr fri_fold_one(const FoldArgs &F, uint64_t i, const Fr9Params &Q)
+__device__ __forceinline__ Fr fri_fold_one(const FoldArgs &F, uint64_t i, const Fr9Params &Q BXPARAM)
 {
-    Fr9 a = fr9_unpack(fr_load(F.src + 2 * i)), b = fr9_unpack(fr_load(F.src + 2 * (i + F.half)));
+    Fr9 a = fr9_unpack(fr_load(BAT(40, F.src, 2 * i, 2))), b = fr9_unpack(fr_load(BAT(41, F.src, 2 * (i + F.half), 2)));
     const uint64_t e = i << F.log_stride, lo_mask = (1ull << F.lo_bits) - 1;
-    Fr9 tw = fr9_load48(F.hi_beta + 3 * (e >> F.lo_bits));
-    if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(F.lo + 3 * (e & lo_mask)), Q);
+    Fr9 tw = fr9_load48(BAT(42, F.hi_beta, 3 * (e >> F.lo_bits), 3));
+    if (e & lo_mask) tw = fr9_mul(tw, fr9_load48(BAT(43, F.lo, 3 * (e & lo_mask), 3)), Q);
     Fr9 odd = fr9_mul(fr9_sub(a, b, Q), tw, Q);          // (a - b) * beta * w^-e / 2
     Fr9 even = fr9_halve(fr9_add(a, b), Q);              // (a + b) / 2
     return fr9_to_canonical(fr9_add(even, odd), Q);
@@ -141,6 +153,9 @@ struct FriTailArgs {
     uint32_t first_round;                   // index i of the first fused round
     uint32_t half0;                         // outputs of the first fused round (power of two, 2 .. FRI_TAIL_THREADS)
     uint32_t shave;                         // 256 - CAPACITY
+#ifdef HODOR_BOUNDS
+    uint64_t lo_bytes, hi_bytes;            // sizes of the two tables (host side: extent declarations)
+#endif
 };
 
 }  // namespace hodor

@@ -46,18 +46,18 @@ namespace hodor {
 // R' = 2^261 form (value * 2^5), the multiplier operand of fr9_mul.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_pow_table(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, uint32_t fmt, FrParams P)
+k_pow_table(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, uint32_t fmt, FrParams P BXPARAM)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fr w = fr_pow(base, j << log_stride, P);
     w = fr_mul(w, mult, P);
     if (fmt == 0) {
-        fr_store(out + 2 * j, w);
+        fr_store(BATS(1, out, 2 * j, 2), w);
     } else {
 #pragma unroll
         for (int i = 0; i < 5; i++) w = fr_add(w, w, P);   // * 2^5: R-form -> R'-form
-        fr9_store48(out + 3 * j, fr9_unpack(w));
+        fr9_store48(BATS(2, out, 3 * j, 3), fr9_unpack(w));
     }
 }
 
@@ -65,7 +65,7 @@ k_pow_table(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, u
 // v = mult * base^(j << log_stride).  K.k[c] holds 2^(87 (c + 1)) mod p as a plain integer, so the
 // Montgomery product with the R-form power strips the R and leaves the plain, canonical W_c.
 __global__ void __launch_bounds__(256)
-k_pow_table_w3(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, W3Consts K, FrParams P)
+k_pow_table_w3(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count, W3Consts K, FrParams P BXPARAM)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
@@ -78,18 +78,18 @@ k_pow_table_w3(uint4 *out, Fr base, Fr mult, uint32_t log_stride, uint64_t count
 #pragma unroll
         for (int i = 0; i < 9; i++) e.w[c][i] = t.v[i];
     }
-    fr9w3_store(out + 7 * j, e);
+    fr9w3_store(BATS(1, out, 7 * j, 7), e);
 }
 
 // W9 entries (fr9w3.cuh): out[j] = V[k][c] = limb k of ( v 2^(29 (c + 1)) mod p ), column-major with 12 words per
 // column, for the plain integer v = base^(j << log_stride).
 __global__ void __launch_bounds__(64)
-k_pow_table_w9(uint32_t *out, Fr base, uint32_t log_stride, uint32_t count, W9Consts K, FrParams P)
+k_pow_table_w9(uint32_t *out, Fr base, uint32_t log_stride, uint32_t count, W9Consts K, FrParams P BXPARAM)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fr w = fr_pow(base, (uint64_t)j << log_stride, P);
-    uint32_t *e = out + (size_t)j * W9_WORDS;
+    uint32_t *e = BATS(1, out, (size_t)j * W9_WORDS, W9_WORDS);
     for (int c = 0; c < 9; c++) {
         Fr9 t = fr9_unpack(fr_mul(w, K.k[c], P));
         for (int k = 0; k < 9; k++) e[12 * k + c] = t.v[k];
@@ -147,11 +147,11 @@ __device__ __forceinline__ Fr9 fr9_sub5(const Fr9 &a, const Fr9 &b, const Fr9Par
 // successive data x constant products (x normalized on entry, result normalized and < 4p).
 // `always`: hi[0] is not 1 (it carries the folded n^-1 scale), so it is applied even for exponent 0.
 template <bool P1>
-__device__ __forceinline__ Fr9 mul_two_level(Fr9 x, const TwoLevel &t, uint64_t e, bool always, const Fr9Params &Q)
+__device__ __forceinline__ Fr9 mul_two_level(Fr9 x, const TwoLevel &t, uint64_t e, bool always, const Fr9Params &Q BXPARAM)
 {
     const uint64_t lo_i = e & ((1ull << t.lo_bits) - 1), hi_i = e >> t.lo_bits;
-    if (hi_i != 0 || always) x = fr9_mul3<P1>(x, fr9w3_load(t.hi + 7 * hi_i), Q);
-    if (lo_i != 0) x = fr9_mul3<P1>(x, fr9w3_load(t.lo + 7 * lo_i), Q);
+    if (hi_i != 0 || always) x = fr9_mul3<P1>(x, fr9w3_load(BAT(20, t.hi, 7 * hi_i, 7)), Q);
+    if (lo_i != 0) x = fr9_mul3<P1>(x, fr9w3_load(BAT(21, t.lo, 7 * lo_i, 7)), Q);
     return x;
 }
 
@@ -203,6 +203,9 @@ struct PassKArgs {
     Fr9 scale;
     uint32_t has_scale;
     Fr9Params Q;
+#ifdef HODOR_BOUNDS
+    BX X;                      // the extents of this pass's buffers (bounds.cuh)
+#endif
 };
 typedef const __attribute__((address_space(4))) PassKArgs *PassKArgsLate;
 
@@ -212,6 +215,9 @@ k_ntt_pass(PassKArgs K)
 {
     const PassArgs &A = K.A;
     const Fr9Params &Q = K.Q;
+#ifdef HODOR_BOUNDS
+    const BX &X = K.X;
+#endif
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t log_r = A.log_r, log_c = A.log_c;
@@ -247,7 +253,7 @@ k_ntt_pass(PassKArgs K)
     // stage omega_R^e (e < R/2, e a multiple of 2^tw_sub) into LDS
     for (uint32_t e = tid; e < 7 * tw_entries; e += nthreads) {
         uint32_t ent = e / 7, q = e - 7 * ent;
-        T[e] = A.rtw[7 * (ent << tw_sub) + q];
+        T[LAT(31, e, 7 * tw_entries)] = *BAT(1, A.rtw, 7 * (ent << tw_sub) + q, 1);
     }
 
     // batched transforms: grid.y (continued in grid.z beyond 65535, see ntt_launch_pass) selects one of `batch`
@@ -280,29 +286,29 @@ k_ntt_pass(PassKArgs K)
             } else if (MODE == 1 && colm) {
                 // the row of a column-mode source may itself arrive cut into slabs / chunks (src_split)
                 const uint64_t srow = A.src_split.on ? split_index(A.src_split, g, 0) : g;
-                x = fr9_unpack(fr_load(A.src + 2 * ((srow << A.src_log_width) + A.src_col_off + colbase + c)));
-                if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level<P1>(x, A.tw2d, g * (A.col0 + colbase + c), false, Q);
+                x = fr9_unpack(fr_load(BAT(2, A.src, 2 * ((srow << A.src_log_width) + A.src_col_off + colbase + c), 2)));
+                if (A.tw2d.lo != nullptr && A.tw2d_on_load) x = mul_two_level<P1>(x, A.tw2d, g * (A.col0 + colbase + c), false, Q BXPASS);
             } else if (MODE == 1 && A.src_split.on) {
-                x = fr9_unpack(fr_load(A.src + 2 * split_index(A.src_split, g, by)));
+                x = fr9_unpack(fr_load(BAT(3, A.src, 2 * split_index(A.src_split, g, by), 2)));
             } else if (ABL(32) && A.apply_tw) {   // upper bound of "lazy intermediates": the words as they are, no unpack
-                Fr raw = fr_load(src_b + 2 * g);
+                Fr raw = fr_load(BATP(4, A.src, 2ull * by * A.src_batch_stride + 2 * g, 2, src_b + 2 * g));
 #pragma unroll
                 for (int k = 0; k < 8; k++) x.v[k] = raw.v[k] & HODOR_M29;
                 x.v[8] = 0;
             } else {
-                x = fr9_unpack(fr_load(src_b + 2 * g));
+                x = fr9_unpack(fr_load(BATP(4, A.src, 2ull * by * A.src_batch_stride + 2 * g, 2, src_b + 2 * g)));
             }
-            if (A.pre.lo != nullptr) x = mul_two_level<P1>(x, A.pre, g, false, Q);
+            if (A.pre.lo != nullptr) x = mul_two_level<P1>(x, A.pre, g, false, Q BXPASS);
             if (A.apply_tw && !ABL(2)) {
                 uint64_t ex = ((uint64_t)i * (j & Lmask)) << tw_shift;
-                x = mul_two_level<P1>(x, A.tw, ex, A.tw_always != 0, Q);
+                x = mul_two_level<P1>(x, A.tw, ex, A.tw_always != 0, Q BXPASS);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 9; k++) x.v[k] = 0;
         }
         uint32_t row = log_r ? (__brev(i) >> (32 - log_r)) : 0u;
-        for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, SLOT(row + d, c), x);
+        for (uint32_t d = 0; d < (1u << log_skip); d++) lds_put(D, LAT(30, SLOT(row + d, c), slots), x);
     }
     STAMP(1);
     __builtin_amdgcn_s_setprio(0);
@@ -319,14 +325,14 @@ k_ntt_pass(PassKArgs K)
             uint32_t jp = q & (m - 1);
             uint32_t r0 = ((q >> log_m) << (log_m + 1)) + jp;
             uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c);
-            Fr9 x0 = lds_get(D, s0), x1 = lds_get(D, s1);
+            Fr9 x0 = lds_get(D, LAT(30, s0, slots)), x1 = lds_get(D, LAT(30, s1, slots));
             // m == 1: twiddle 1 and x1 is a stored value (normalized, < 4p), a valid subtrahend
-            if (m > 1) x1 = fr9_mul3<P1>(x1, fr9w3_load(T + 7 * ((jp << (log_r - log_m - 1)) >> tw_sub)), Q);
+            if (m > 1) x1 = fr9_mul3<P1>(x1, fr9w3_load(T + 7 * LAT(32, (jp << (log_r - log_m - 1)) >> tw_sub, tw_entries)), Q);
             Fr9 y0 = fr9_add(x0, x1), y1 = fr9_sub5(x0, x1, Q);
             fr9_normalize(y0);
             fr9_normalize(y1);
-            lds_put(D, s0, y0);
-            lds_put(D, s1, y1);
+            lds_put(D, LAT(30, s0, slots), y0);
+            lds_put(D, LAT(30, s1, slots), y1);
         }
         log_m += 1;
         __syncthreads();
@@ -372,10 +378,10 @@ k_ntt_pass(PassKArgs K)
                 const uint32_t r0 = (kb << (log_m + 2)) + jp;
                 const uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c), s2 = SLOT(r0 + 2 * m, c),
                                s3 = SLOT(r0 + 3 * m, c);
-                Fr9 x0 = lds_get(D, s0);
-                Fr9 x1 = lds_get(D, s1);
-                Fr9 x2 = lds_get(D, s2);
-                Fr9 x3 = lds_get(D, s3);
+                Fr9 x0 = lds_get(D, LAT(30, s0, slots));
+                Fr9 x1 = lds_get(D, LAT(30, s1, slots));
+                Fr9 x2 = lds_get(D, LAT(30, s2, slots));
+                Fr9 x3 = lds_get(D, LAT(30, s3, slots));
                 Fr9 t;
                 if (LAZY && log_m != first_lm) {
                     fr9_normalize(x0);
@@ -384,11 +390,13 @@ k_ntt_pass(PassKArgs K)
                 }
                 const bool ones = jp == 0 && (m == 1 || A.w9_skip_one);   // wa = wb = 1 (wave-uniform branch)
                 if (!ones) {
+                    (void)BAT(6, A.rtw9, W9_WORDS * ((jp << (log_r - log_m - 1)) >> e_shift), W9_WORDS);
                     fr9_mul9x2<P1>(x1, x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 1)) >> e_shift), Q);
                     t = x1; x1 = fr9_sub11(x0, t, Q); x0 = fr9_add(x0, t);
                     t = x3; x3 = fr9_sub11(x2, t, Q); x2 = fr9_add(x2, t);
                     fr9_normalize(x2);
                     fr9_normalize(x3);
+                    (void)BAT(7, A.rtw9, W9_WORDS * ((jp << (log_r - log_m - 2)) >> e_shift), W9_WORDS);
                     t = fr9_mul9<P1>(x2, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane((jp << (log_r - log_m - 2)) >> e_shift), Q);
                     x2 = fr9_sub11(x0, t, Q); x0 = fr9_add(x0, t);
                 } else {
@@ -402,6 +410,7 @@ k_ntt_pass(PassKArgs K)
                     x2 = fr9_sub5(x0, t, Q); x0 = fr9_add(x0, t);
                     fr9_normalize(x3);
                 }
+                (void)BAT(8, A.rtw9, W9_WORDS * (((jp + m) << (log_r - log_m - 2)) >> e_shift), W9_WORDS);
                 t = fr9_mul9<P1>(x3, W9 + W9_WORDS * __builtin_amdgcn_readfirstlane(((jp + m) << (log_r - log_m - 2)) >> e_shift), Q);
                 x3 = fr9_sub11(x1, t, Q); x1 = fr9_add(x1, t);
                 if (!LAZY) {   // (a W9 step is never the last step of a pass: ntt_launch_pass)
@@ -410,10 +419,10 @@ k_ntt_pass(PassKArgs K)
                     fr9_normalize(x2);
                     fr9_normalize(x3);
                 }
-                lds_put(D, s0, x0);
-                lds_put(D, s1, x1);
-                lds_put(D, s2, x2);
-                lds_put(D, s3, x3);
+                lds_put(D, LAT(30, s0, slots), x0);
+                lds_put(D, LAT(30, s1, slots), x1);
+                lds_put(D, LAT(30, s2, slots), x2);
+                lds_put(D, LAT(30, s3, slots), x3);
             }
             STAMP(3 + log_m);
             __syncthreads();
@@ -425,8 +434,8 @@ k_ntt_pass(PassKArgs K)
             constexpr bool G = decltype(from_global)::value;
             constexpr bool CARRY_OUT = decltype(carry_out)::value;   // last step of the pass (or a HODOR_NO_LAZY build)
             auto twiddle = [&](uint32_t idx) -> Fr9W3 {
-                if constexpr (G) return fr9w3_load(A.rtw + 7 * idx);
-                else return fr9w3_load(T + 7 * (idx >> tw_sub));
+                if constexpr (G) return fr9w3_load(BAT(5, A.rtw, 7 * idx, 7));
+                else return fr9w3_load(T + 7 * LAT(32, idx >> tw_sub, tw_entries));
             };
             for (uint32_t w = tid; w < items; w += nthreads) {
                 uint32_t c = w & (C - 1), q = w >> log_c;
@@ -435,10 +444,10 @@ k_ntt_pass(PassKArgs K)
                 const uint32_t r0 = k + jp;
                 const uint32_t s0 = SLOT(r0, c), s1 = SLOT(r0 + m, c), s2 = SLOT(r0 + 2 * m, c),
                                s3 = SLOT(r0 + 3 * m, c);
-                Fr9 x0 = lds_get(D, s0);
-                Fr9 x1 = lds_get(D, s1);
-                Fr9 x2 = lds_get(D, s2);
-                Fr9 x3 = lds_get(D, s3);
+                Fr9 x0 = lds_get(D, LAT(30, s0, slots));
+                Fr9 x1 = lds_get(D, LAT(30, s1, slots));
+                Fr9 x2 = lds_get(D, LAT(30, s2, slots));
+                Fr9 x3 = lds_get(D, LAT(30, s3, slots));
                 Fr9 t;
                 if (m > 1) {
                     if (LAZY) {   // (also when this is the pass's first radix-4 step and the limbs are normalized already)
@@ -489,10 +498,10 @@ k_ntt_pass(PassKArgs K)
                     fr9_normalize(x2);
                     fr9_normalize(x3);
                 }
-                lds_put(D, s0, x0);
-                lds_put(D, s1, x1);
-                lds_put(D, s2, x2);
-                lds_put(D, s3, x3);
+                lds_put(D, LAT(30, s0, slots), x0);
+                lds_put(D, LAT(30, s1, slots), x1);
+                lds_put(D, LAT(30, s2, slots), x2);
+                lds_put(D, LAT(30, s3, slots), x3);
             }
         };
         // three forms: a step that is followed by another one reads the LDS twiddle table (its indices are multiples
@@ -542,12 +551,12 @@ k_ntt_pass(PassKArgs K)
         uint64_t j = colm ? j0 : j0 + c;
         uint64_t p = j & s_lmask;
         uint64_t o = ((j - p) << log_r) + p + ((uint64_t)cc << s_log_l);
-        Fr9 x = lds_get(D, SLOT(cc, c));
+        Fr9 x = lds_get(D, LAT(30, SLOT(cc, c), slots));
         if (s_has_scale) x = fr9_mul(x, s_scale, QS);
-        if (s_post.lo != nullptr) x = mul_two_level<P1>(x, s_post, o, false, QS);
+        if (s_post.lo != nullptr) x = mul_two_level<P1>(x, s_post, o, false, QS BXPASS);
         if (MODE == 1 && colm && late->A.tw2d.lo != nullptr && !late->A.tw2d_on_load) {
             const TwoLevel t2 = {late->A.tw2d.lo, late->A.tw2d.hi, late->A.tw2d.lo_bits};
-            x = mul_two_level<P1>(x, t2, o * (late->A.col0 + colbase + c), false, QS);
+            x = mul_two_level<P1>(x, t2, o * (late->A.col0 + colbase + c), false, QS BXPASS);
         }
         // x is normalized here: either straight from LDS (carry-propagated by the last step) or a product
         Fr y;
@@ -575,15 +584,15 @@ k_ntt_pass(PassKArgs K)
                 at = peer_self * late->A.dst_split.stride_hi + ((o >> lo_log) & late->A.dst_split.mid_mask) * late->A.dst_split.stride_mid +
                      by * late->A.dst_split.batch_stride + (o & ((1ull << lo_log) - 1));
             }
-            uint4 *base = reinterpret_cast<uint4 *>(late->A.peer_tab[t]);
-            fr_store_nt(base + 2 * (late->A.peer_off + at), y);
-        } else if (MODE == 1 && colm) fr_store_nt(s_dst + 2 * ((o << late->A.dst_log_width) + late->A.dst_col_off + colbase + c), y);
+            uint4 *base = reinterpret_cast<uint4 *>(*BAT(12, late->A.peer_tab, t, 1));
+            fr_store_nt(BATS(13, base, 2 * (late->A.peer_off + at), 2), y);
+        } else if (MODE == 1 && colm) fr_store_nt(BATS(14, s_dst, 2 * ((o << late->A.dst_log_width) + late->A.dst_col_off + colbase + c), 2), y);
         else if (MODE == 1 && late->A.dst_split.on) {
             SplitAddr S;
             S.on = 1; S.lo_log = late->A.dst_split.lo_log; S.hi_log = late->A.dst_split.hi_log; S.mid_mask = late->A.dst_split.mid_mask;
             S.stride_mid = late->A.dst_split.stride_mid; S.stride_hi = late->A.dst_split.stride_hi; S.batch_stride = late->A.dst_split.batch_stride;
-            fr_store_nt(s_dst + 2 * split_index(S, o, by), y);
-        } else fr_store_nt(s_dst_b + 2 * o, y);
+            fr_store_nt(BATS(15, s_dst, 2 * split_index(S, o, by), 2), y);
+        } else fr_store_nt(BATSP(16, s_dst, ((2ull * by) << s_log_n) + 2 * o, 2, s_dst_b + 2 * o), y);
     }
     STAMP(11);
 }
@@ -700,6 +709,19 @@ hipError_t ntt_launch_pass(hipStream_t stream, const PassArgs &A, const Fr9 *sca
     K.scale = s;
     K.has_scale = hs;
     K.Q = Q;
+#ifdef HODOR_BOUNDS
+    {
+        BXB bx(KID_NTT_PASS);
+        bx.add(A.src, A.bx_src_bytes).add(A.dst, A.bx_dst_bytes).add(A.rtw, A.bx_rtw_bytes).add(A.rtw9, A.bx_rtw9_bytes);
+        bx.add(A.tw.lo, A.tw.lo_bytes).add(A.tw.hi, A.tw.hi_bytes).add(A.pre.lo, A.pre.lo_bytes).add(A.pre.hi, A.pre.hi_bytes);
+        bx.add(A.post.lo, A.post.lo_bytes).add(A.post.hi, A.post.hi_bytes).add(A.tw2d.lo, A.tw2d.lo_bytes).add(A.tw2d.hi, A.tw2d.hi_bytes);
+        if (A.peer_tab) {
+            bx.add(A.peer_tab, A.bx_peers * sizeof(uint64_t));
+            for (uint32_t t = 0; t < A.bx_peers; t++) bx.add((const void *)(uintptr_t)A.bx_peer_host[t], A.bx_peer_bytes);
+        }
+        K.X = bx;
+    }
+#endif
     if (general && p1) hipLaunchKernelGGL((k_ntt_pass<1, true>), g3, dim3(threads), lds, stream, K);
     else if (general)  hipLaunchKernelGGL((k_ntt_pass<1, false>), g3, dim3(threads), lds, stream, K);
     else if (p1)       hipLaunchKernelGGL((k_ntt_pass<0, true>), g3, dim3(threads), lds, stream, K);
@@ -711,15 +733,19 @@ hipError_t pow_table_launch(hipStream_t stream, uint4 *out, const Fr &base, cons
                             uint32_t log_stride, uint64_t count, uint32_t fmt, const FrParams &P)
 {
     unsigned grid = (unsigned)((count + 255) / 256);
+    BX_BEGIN(bx, KID_POW_TABLE);
+    BX_ADD(bx, out, count * (fmt ? 48 : 32));
     hipLaunchKernelGGL(k_pow_table, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride, count, fmt,
-                       P);
+                       P BXARG(bx));
     return hipGetLastError();
 }
 
 hipError_t pow_table_w9_launch(hipStream_t stream, uint32_t *out, const Fr &base, uint32_t log_stride, uint32_t count,
                                const W9Consts &K, const FrParams &P)
 {
-    hipLaunchKernelGGL(k_pow_table_w9, dim3((count + 63) / 64), dim3(64), 0, stream, out, base, log_stride, count, K, P);
+    BX_BEGIN(bx, KID_POW_TABLE_W9);
+    BX_ADD(bx, out, (size_t)count * W9_WORDS * sizeof(uint32_t));
+    hipLaunchKernelGGL(k_pow_table_w9, dim3((count + 63) / 64), dim3(64), 0, stream, out, base, log_stride, count, K, P BXARG(bx));
     return hipGetLastError();
 }
 
@@ -727,8 +753,10 @@ hipError_t pow_table_w3_launch(hipStream_t stream, uint4 *out, const Fr &base, c
                                uint32_t log_stride, uint64_t count, const W3Consts &K, const FrParams &P)
 {
     unsigned grid = (unsigned)((count + 255) / 256);
+    BX_BEGIN(bx, KID_POW_TABLE_W3);
+    BX_ADD(bx, out, count * 112);
     hipLaunchKernelGGL(k_pow_table_w3, dim3(grid), dim3(256), 0, stream, out, base, mult, log_stride, count, K,
-                       P);
+                       P BXARG(bx));
     return hipGetLastError();
 }
 

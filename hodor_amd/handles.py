@@ -412,6 +412,25 @@ class FriPrototypeHandle:
                                                     C.c_int(1 if through_coefficients else 0), C.byref(h)))
         self.proto = FriPrototype(self.ctx, h)      # roots, challenges, final coefficients, canonical serialization
 
+    @classmethod
+    def commit_all(cls, ldes, lde_factor, output_coeffs_at_degree_plus_one, combiner=TRIVIAL):
+        """proof_from_lde of several polynomials at once (h1 and h2, src/prover/mod.rs:112-113): hodor_fri_commit_batch_h —
+        the commits overlap on streams of the context, one wait hands all prototypes over; same prototypes as one
+        FriPrototypeHandle(...) each."""
+        from ._lib import FriPrototype
+        ctx = ldes[0].ctx
+        ins = (C.c_void_p * len(ldes))(*[l.h for l in ldes])
+        outs = (C.c_void_p * len(ldes))()
+        ctx._chk(ctx.L.hodor_fri_commit_batch_h(ins, C.c_size_t(len(ldes)), C.c_size_t(lde_factor),
+                                                C.c_size_t(output_coeffs_at_degree_plus_one), C.c_int(combiner), outs))
+        res = []
+        for l, h in zip(ldes, outs):
+            obj = cls.__new__(cls)
+            obj.ctx, obj.lde_values = ctx, l
+            obj.proto = FriPrototype(ctx, C.c_void_p(h))
+            res.append(obj)
+        return res
+
     def produce_proof_bytes(self, natural_first_element_index):
         """prototype_into_proof / produce_proof (src/fri/query_producer.rs:10-53), in this build's wire format"""
         L = self.ctx.L

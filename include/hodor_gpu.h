@@ -615,6 +615,7 @@ void     hodor_ctx_reset_host_round_trips(hodor_ctx *ctx);       /* ... and the 
 void     hodor_ctx_host_traffic(const hodor_ctx *ctx, uint64_t *h2d_bytes, uint64_t *d2h_bytes);
 int      hodor_ctx_trim(hodor_ctx *ctx);                      /* cached pool blocks back to HIP (synchronises the device) */
 int      hodor_ctx_pool_stats(const hodor_ctx *ctx, size_t *cached_bytes, size_t *live_bytes);
+size_t   hodor_ctx_pool_peak(hodor_ctx *ctx, int reset);       /* most pool bytes live at one time since creation / the last reset */
 
 /* Polynomial::from_coeffs / from_values (:146-166, :722-742): `len` host elements, zero-padded to the next power of
  * two (Domain::new_for_size; HODOR_ERR_SIZE beyond the field's two-adicity).  new_for_size (:140-144, :716-720): zeros. */
@@ -710,6 +711,16 @@ int hodor_iop_query_h(hodor_iop *t, const hodor_poly *values, size_t natural_ind
  * and verify_prototype (src/fri/verifier.rs:10-129) against the handle the prototype was committed from. */
 int hodor_fri_commit_h(const hodor_poly *lde_values, size_t lde_factor, size_t output_coeffs_at_degree_plus_one,
                        int combiner, int through_coefficients, hodor_fri_proto **out);
+/* proof_from_lde of several polynomials at once — h1 and h2 of Prover::prove (src/prover/mod.rs:112-113): commit 0 on the
+ * context's stream, the others on auxiliary streams of the context, so that the latency-bound last rounds of one hide
+ * behind the hashing of another; one wait hands all prototypes over (counted as one round trip) and the context's
+ * stream continues behind all of them.  The prototypes are, byte for byte, those of `count` separate calls (by-values
+ * route).  count <= 8.  The `_dev` form takes device pointers the caller has made ready on hodor_ctx_stream. */
+int hodor_fri_commit_batch_h(const hodor_poly *const *lde_values, size_t count, size_t lde_factor,
+                             size_t output_coeffs_at_degree_plus_one, int combiner, hodor_fri_proto **outs);
+int hodor_fri_commit_batch_dev(hodor_ctx *ctx, const hodor_fr *const *lde_values, const size_t *ns, size_t count,
+                               size_t lde_factor, size_t output_coeffs_at_degree_plus_one, int combiner,
+                               hodor_fri_proto **outs);
 size_t hodor_fri_produce_proof_h(hodor_fri_proto *p, const hodor_poly *lde_values, size_t natural_first_element_index,
                                  uint8_t *buf, size_t cap);
 int hodor_fri_verify_prototype_h(hodor_fri_proto *p, const hodor_poly *lde_values, size_t natural_element_index,

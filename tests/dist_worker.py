@@ -23,7 +23,10 @@ def main():
     transport, log_n, lde_log_n, factor = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=0)
+    # the pool's boxes have one GPU, which the ranks share; on a node (bench/first_node.sh) every rank takes its own device
+    device = int(os.environ.get("LOCAL_RANK", rank)) if os.environ.get("HODOR_DIST_DEVICE_PER_RANK") else 0
+    torch.cuda.set_device(device)
+    ctx = hodor_amd.Context(hodor_amd.BN256_FR_MODULUS, hodor_amd.BN256_FR_GENERATOR, device=device)
     n, P = 1 << log_n, world
     m = n // P
     big = (1 << lde_log_n) * factor

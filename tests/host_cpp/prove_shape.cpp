@@ -14,7 +14,7 @@
 // boundary divisors and adjustment polynomials (tests/host_cpp/ali_instance.hpp), AS WRITTEN in the reference through
 // Polynomial::as_mut() (ali_mode 0) or device-resident (ali_mode 1) — same proof bytes either way.
 //
-//   prove_shape <log_rows> <registers> <lde_factor> <combiner 0|1> <out.bin> [reps=1] [sync_phases=0] [ali_mode=0]
+//   prove_shape <log_rows> <registers> <lde_factor> <combiner 0|1> <out.bin> [reps=1] [sync_phases=0] [ali_mode=0] [fri_batch=1]
 // prints one JSON line: total / per-phase milliseconds (median run), host round trips and PCIe bytes of one proof and of
 // the from_arp precompute before it, proof size.
 // Build: g++ -O2 -std=c++17 prove_shape.cpp -L<repo>/hodor_amd -lhodor_gpu
@@ -35,6 +35,8 @@ static const uint64_t SEED = 0x50524F56;     // tests/prove_shape_ref.py:make_tr
 
 typedef Polynomial<Coefficients> PolyC;
 typedef Polynomial<Values> PolyV;
+
+static bool g_fri_batch = true;   // argv[9]: 0 = one proof_from_lde after the other (the A/B of hodor_fri_commit_batch_h)
 
 struct Prep {   // ALIInstance::from_arp's vectors + fixed scalars (prove_shape_ref.make_trace)
     Fr coeff, constant[2], boundary_value, masks[2];
@@ -190,9 +192,16 @@ static std::vector<uint8_t> prove(const Field &F, const std::vector<PolyV> &trac
     for (auto &a : alphas) a = T.get_challenge();
     Deep d = calculate_deep(F, w_polys, f_ldes, g_poly, g_lde, z, P.masks, alphas);
     clk.lap("H1 and H2");
-    // FRI (:110-111)
-    FRIProofPrototype p1 = NaiveFriIop::proof_from_lde(d.h1, lde_factor, 1, combiner);
-    FRIProofPrototype p2 = NaiveFriIop::proof_from_lde(d.h2, lde_factor, 1, combiner);
+    // FRI (:110-111): the two commits are independent — issued together their latency-bound tails overlap
+    FRIProofPrototype p1, p2;
+    if (g_fri_batch) {
+        auto both = NaiveFriIop::proof_from_lde_all({&d.h1, &d.h2}, lde_factor, 1, combiner);
+        p1 = std::move(both[0]);
+        p2 = std::move(both[1]);
+    } else {
+        p1 = NaiveFriIop::proof_from_lde(d.h1, lde_factor, 1, combiner);
+        p2 = NaiveFriIop::proof_from_lde(d.h2, lde_factor, 1, combiner);
+    }
     clk.lap("FRI");
     // query phase (:113-151)
     for (FRIProofPrototype *p : {&p1, &p2}) {
@@ -230,6 +239,7 @@ int main(int argc, char **argv)
     const int reps = argc > 6 ? atoi(argv[6]) : 1;
     const bool sync_phases = argc > 7 && atoi(argv[7]) != 0;
     const int ali_mode = argc > 8 ? atoi(argv[8]) : 0;   // 0: from_arp as written (as_mut), 1: device-resident precompute
+    g_fri_batch = argc > 9 ? atoi(argv[9]) != 0 : true;
     try {
         Field F(BN256_FR, 7, 0);
         const size_t n = (size_t)1 << log_rows;
@@ -259,11 +269,13 @@ int main(int argc, char **argv)
         std::vector<uint8_t> proof;
         std::vector<std::pair<double, std::map<std::string, double>>> runs;
         uint64_t trips = 0;
+        size_t peak_live = 0;
         std::pair<uint64_t, uint64_t> bytes;
         for (int rep = 0; rep < reps + 1; rep++) {   // run 0 warms the twiddle tables, the pool and the FRI slab
             Clock clk{F, sync_phases, {}, {}};
             F.synchronize();
             F.reset_host_round_trips();
+            hodor_ctx_pool_peak(F.ctx(), 1);
             auto t0 = std::chrono::steady_clock::now();
             std::vector<uint8_t> got = combiner ? prove<Coset2Blake2sIOP>(F, trace, P, lde_factor, clk)
                                                 : prove<TrivialBlake2sIOP>(F, trace, P, lde_factor, clk);
@@ -271,6 +283,7 @@ int main(int argc, char **argv)
             double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             trips = F.host_round_trips();
             bytes = F.host_traffic();
+            peak_live = hodor_ctx_pool_peak(F.ctx(), 0);
             if (rep == 0) proof = got;
             else if (got != proof) { fprintf(stderr, "the run is not deterministic\n"); return 1; }
             if (rep > 0 || reps == 0) runs.emplace_back(total, clk.ms);
@@ -283,15 +296,15 @@ int main(int argc, char **argv)
         auto &med = runs[runs.size() / 2];
         size_t cached = 0, live = 0;
         hodor_ctx_pool_stats(F.ctx(), &cached, &live);
-        printf("{\"log_rows\": %u, \"registers\": %zu, \"lde_factor\": %zu, \"combiner\": %d, \"ali_mode\": \"%s\", \"proof_bytes\": %zu, \"reps\": %d, "
+        printf("{\"log_rows\": %u, \"registers\": %zu, \"lde_factor\": %zu, \"combiner\": %d, \"ali_mode\": \"%s\", \"fri_batch\": %s, \"proof_bytes\": %zu, \"reps\": %d, "
                "\"sync_phases\": %s, \"total_ms\": %.3f, \"best_ms\": %.3f, \"host_round_trips\": %llu, \"h2d_bytes\": %llu, \"d2h_bytes\": %llu, "
                "\"from_arp\": {\"ms_cold\": %.3f, \"ms\": %.3f, \"host_threads\": %zu, \"host_round_trips\": %llu, \"h2d_bytes\": %llu, \"d2h_bytes\": %llu}, "
-               "\"pool_gib\": %.2f, \"phases_ms\": {",
-               log_rows, registers, lde_factor, combiner, ali_mode ? "device-resident" : "as written (as_mut)", proof.size(), reps,
+               "\"pool_gib\": %.2f, \"pool_peak_live_gib\": %.2f, \"phases_ms\": {",
+               log_rows, registers, lde_factor, combiner, ali_mode ? "device-resident" : "as written (as_mut)", g_fri_batch ? "true" : "false", proof.size(), reps,
                sync_phases ? "true" : "false", med.first, runs[0].first, (unsigned long long)trips, (unsigned long long)bytes.first,
                (unsigned long long)bytes.second, from_arp_ms[0], from_arp_ms[1], worker.cpus, (unsigned long long)from_arp_trips,
                (unsigned long long)from_arp_bytes.first, (unsigned long long)from_arp_bytes.second,
-               (double)(cached + live) / (1ull << 30));
+               (double)(cached + live) / (1ull << 30), (double)peak_live / (1ull << 30));
         for (size_t i = 0; i < 9; i++) printf("%s\"%s\": %.3f", i ? ", " : "", PHASES[i], med.second[PHASES[i]]);
         printf("}, \"runs_ms\": [");
         for (size_t i = 0; i < runs.size(); i++) printf("%s%.3f", i ? ", " : "", runs[i].first);

@@ -521,6 +521,30 @@ def test_fri_commit_on_a_handle_matches_oracle(gpu_ctxs, oracles, log_deg, lde_f
     p.free()
 
 
+@pytest.mark.parametrize("combiner", [hodor_amd.TRIVIAL, hodor_amd.COSET2])
+def test_several_fri_commits_at_once_are_the_separate_ones(gpu_ctxs, oracles, combiner):
+    """hodor_fri_commit_batch_h — h1 and h2 of Prover::prove (src/prover/mod.rs:112-113) committed together, on streams of
+    the context so that their small rounds overlap: the prototypes equal, byte for byte, the oracle's and the ones of one
+    call each; ONE host round trip hands all of them over; the context's stream is ordered behind every commit (the
+    queries right after see finished trees)."""
+    ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    shapes = [(10, 8), (14, 8), (8, 8), (17, 8)]              # different sizes, as h1 (f domain) and h2 (g domain) are
+    polys = [Polynomial.from_coeffs(ctx, O.random_elements(1 << lg, 170 + lg)) for lg, _ in shapes]
+    ldes = [p.lde(f) for p, (_, f) in zip(polys, shapes)]
+    exp = [O.fri_commit(O.poly_lde(p.as_ref(), f), f, 1, combiner=combiner) for p, (_, f) in zip(polys, shapes)]
+    reset_host_round_trips(ctx)
+    got = FriPrototypeHandle.commit_all(ldes, 8, 1, combiner=combiner)
+    assert host_round_trips(ctx) == 1
+    for g, e, l in zip(got, exp, ldes):
+        assert g.proto.serialized == e["serialized"]
+        assert g.verify_prototype(l.size() // 3)
+        one = FriPrototypeHandle(l, 8, 1, combiner=combiner)
+        assert one.proto.serialized == g.proto.serialized and one.produce_proof_bytes(5) == g.produce_proof_bytes(5)
+        one.free()
+    for x in got + ldes + polys:
+        x.free()
+
+
 @pytest.mark.parametrize("log_deg,lde_factor,index", [(3, 4, 7), (5, 4, 71), (5, 8, 255)])
 def test_fri_proof_from_a_handle_matches_restated_query_producer(gpu_ctxs, log_deg, lde_factor, index):
     """produce_proof (src/fri/query_producer.rs:10-53) from device-resident values and trees: the bytes of the Python
