@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 [ -f hodor_amd/libhodor_gpu_bounds.so ] || make -C hodor_amd/csrc bounds > "$OUT/build.log" 2>&1 || { echo "bounds build failed"; exit 9; }
 rm -f "$OUT/bounds_report.txt"
-export HODOR_LIB=$ROOT/hodor_amd/libhodor_gpu_bounds.so HODOR_BOUNDS_REPORT=$OUT/bounds_report.txt
+export HODOR_LIB=$ROOT/hodor_amd/libhodor_gpu_bounds.so HODOR_BOUNDS_REPORT=$OUT/bounds_report.txt HODOR_SUITE_LIB=1
 # (tests that A/B other twin builds through HODOR_LIB of their own — nolate — and the bounds build's own tests keep their library)
 ( time python -m pytest tests -m gpu -q -p no:cacheprovider ) > "$OUT/suite.log" 2>&1
 tail -5 "$OUT/suite.log"

@@ -1153,7 +1153,7 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
         if (ds && ds != us) (void)hipStreamSynchronize(ds);
         // set_err takes err_mu only: this runs while a HostXfer (pinned_mu) may still be in scope, and the commit /
         // batch_inversion / evaluate_at paths take ctx->mu BEFORE pinned_mu — taking ctx->mu here was an inversion
-        set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
+        if (e != hipErrorAssert) set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));   // hipErrorAssert: the bounds build's poll wrote the message
         lane_release(ctx, L);
         return HODOR_ERR_DEVICE;
     };

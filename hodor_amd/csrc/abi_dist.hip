@@ -549,10 +549,15 @@ extern "C" int hodor_dist_commit_dev(hodor_exchange *x, void *stream_, const hod
     hodor_fr *gathered = nullptr;
     if ((rc = dist_all_to_all(x, stream, (const hodor_fr *)mine, P, 6, &gathered, &h))) return leave(rc);
     memset(top, 0, 2 * P * 32);
-    HostXfer xfer(ctx, stream);
-    hipError_t e = xfer.d2h(top + 32 * P, gathered, 32 * P);
-    int r2 = dist_a2a_release(x, stream, h);
-    if (e == hipSuccess) e = xfer.finish();
+    // lock order (advisor, round 5): the pinned staging buffer (HostXfer) is released BEFORE x->mu is taken — set_peers
+    // takes them the other way round
+    hipError_t e;
+    {
+        HostXfer xfer(ctx, stream);
+        e = xfer.d2h(top + 32 * P, gathered, 32 * P);
+        if (e == hipSuccess) e = xfer.finish();
+    }
+    int r2 = dist_a2a_release(x, stream, h);   // (the copy above has completed: the peers may overwrite the slot)
     {
         std::lock_guard<std::mutex> lk(x->mu);
         (void)work_done(x, 5, stream);

@@ -97,7 +97,7 @@ int fri_commit_enqueue(hodor_ctx *ctx, hipStream_t stream, const hodor_fr *lde_v
         hipError_t e__ = (expr);                                                       \
         if (e__ != hipSuccess) {                                                       \
             (void)hipGetLastError();                                                   \
-            set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));             \
+            if (e__ != hipErrorAssert) set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));   \
             fri_release(p);                                                            \
             return HODOR_ERR_DEVICE;                                                   \
         }                                                                              \
@@ -380,7 +380,7 @@ extern "C" int hodor_fri_commit_through_coefficients_dev(hodor_ctx *ctx, void *s
         hipError_t e__ = (expr);                                                       \
         if (e__ != hipSuccess) {                                                       \
             (void)hipGetLastError();                                                   \
-            set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));             \
+            if (e__ != hipErrorAssert) set_err(ctx, std::string(#expr) + ": " + hipGetErrorString(e__));   \
             release(p);                                                                \
             return HODOR_ERR_DEVICE;                                                   \
         }                                                                              \

@@ -308,7 +308,7 @@ static int poly_flush(hodor_poly *p)
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        set_err(ctx, std::string("as_mut write-back: ") + hipGetErrorString(e));
+        if (e != hipErrorAssert) set_err(ctx, std::string("as_mut write-back: ") + hipGetErrorString(e));
         return HODOR_ERR_DEVICE;
     }
     p->host_dirty = false;
@@ -484,7 +484,7 @@ extern "C" int hodor_poly_from_host_h(hodor_ctx *ctx, int form, const hodor_fr *
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        set_err(ctx, std::string("from_host: ") + hipGetErrorString(e));
+        if (e != hipErrorAssert) set_err(ctx, std::string("from_host: ") + hipGetErrorString(e));
         hodor_poly_free_h(p);
         return HODOR_ERR_DEVICE;
     }

@@ -658,6 +658,8 @@ def test_pool_keeps_the_block_just_released_whatever_the_cap():
 import numpy as np, hodor_amd
 from hodor_amd.handles import Polynomial, VALUES
 ctx = hodor_amd.Context(device=0)
+ctx.trim()                                                 # (the start-up self-test leaves a few warm blocks behind)
+assert ctx.pool_stats() == (0, 0)
 a = Polynomial.new_for_size(ctx, VALUES, 1 << 16)          # 2 MiB
 a.free()
 cached, live = ctx.pool_stats()
