@@ -109,7 +109,7 @@ def cpu_baseline(seconds_budget=20.0):
                            "sample": "one 2^20-point NTT, parallel_fft with the fastest thread count of 1..64"}}
 
 
-KERNEL_SOURCES = ("ntt.hip", "ntt.cuh", "fr.cuh", "fr9.cuh", "fr9w3.cuh", "abi.hip", "ctx.hpp", "knobs.hpp", "Makefile")
+KERNEL_SOURCES = ("ntt.hip", "ntt.cuh", "fr.cuh", "fr9.cuh", "fr9w3.cuh", "bounds.cuh", "abi.hip", "ctx.hpp", "knobs.hpp", "Makefile")
 
 
 def kernel_sources_sha256():

@@ -44,6 +44,24 @@ int main(int argc, char **argv)
         CHECK((Domain::coset_for_natural_index_and_size(13, 16) == std::vector<size_t>{5, 13}));
         CHECK((Domain::index_and_size_for_next_domain(13, 16) == std::pair<size_t, size_t>{5, 8}));
     }
+    {   // Worker (src/fft/multicore.rs:16-107): chunk sizes, log_num_cpus, and a scope that runs every chunk exactly once
+        Worker w(6);
+        CHECK(w.log_num_cpus() == 2 && Worker(1).log_num_cpus() == 0 && Worker(256).log_num_cpus() == 8);
+        CHECK(w.get_chunk_size(3) == 1 && w.get_chunk_size(6) == 1 && w.get_chunk_size(100) == 16);
+        std::vector<Fr> v(100, F.zero());
+        MutSlice all(v.data(), v.size(), nullptr);                 // (no handle behind it: nothing to write back)
+        w.scope(v.size(), [&](Worker::Scope &scope, size_t chunk) {
+            size_t i = 0;
+            for (auto c : all.chunks_mut(chunk)) {
+                scope.spawn([&F, c, i, chunk] { size_t k = i * chunk; for (Fr &e : c) e = F.from_u64(++k); });
+                i++;
+            }
+        });
+        bool ok = true;
+        for (size_t k = 0; k < v.size(); k++) ok = ok && v[k] == F.from_u64(k + 1);
+        CHECK(ok);
+        CHECK(all.chunks_mut(16).size() == 7 && all.chunks_mut(16).back().size() == 4);
+    }
     for (size_t n : {4u, 16u, 1024u})                 // the combiners' index maps are inverse to each other
         for (size_t i = 0; i < n; i++) {
             CHECK(TrivialCombiner::tree_index_into_natural_index(TrivialCombiner::natural_index_into_tree_index(i, n), n) == i);

@@ -197,7 +197,7 @@ def test_host_only_half_of_the_mirror_runs_without_a_device(tmp_path):
     fixture.write_bytes(fx)
     exe = str(tmp_path / "test_host_cpu")
     libdir = os.path.join(ROOT, "hodor_amd")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "host_cpp", "test_host_cpu.cpp"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", os.path.join(ROOT, "tests", "host_cpp", "test_host_cpu.cpp"),
                            "-L" + libdir, LIBFLAG, "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe, str(fixture)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "host-only checks passed" in out.stdout, out.stdout + out.stderr
