@@ -9,6 +9,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 bash bench/profile.sh $TAG > "$OUT/profile.log" 2>&1
+# the bench line quotes counter traffic only from a profile of THIS build: make the one just taken the committed one's stand-in
+mkdir -p "$ROOT/profiles/$TAG" && cp "$ROOT/gpurun_out/prof_$TAG/pmc_traffic.json" "$ROOT/profiles/$TAG/pmc_traffic.json" 2>/dev/null
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 bash bench/prove_shape_cpp.sh "$OUT/prove_shape_cpp.txt"
 python bench/selftest_cost.py > "$OUT/selftest.txt" 2>&1

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "host_cpp", "test_host.cpp")
 # the C / C++ programs link against the library the Python tests load: HODOR_LIB selects a twin build (the bounds-checked
-# one, bench/bounds_suite.sh) for them too
-LIBFLAG = "-l:" + os.path.basename(os.environ.get("HODOR_LIB") or "libhodor_gpu.so")
+# one, bench/bounds_suite.sh, which sets HODOR_SUITE_LIB) for them too; other twins (asan) are for the Python process only
+LIBFLAG = "-l:" + os.path.basename((os.environ.get("HODOR_SUITE_LIB") and os.environ.get("HODOR_LIB")) or "libhodor_gpu.so")
 
 
 def _build(tmp_path):
