@@ -13,7 +13,7 @@ export TMPDIR=/tmp
   for reps in 2 6; do
     D=/tmp/hiptrace_$reps
     rm -rf $D
-    (cd /tmp && rocprofv3 --hip-trace --stats -d $D -o t -- $EXE 20 4 16 0 /tmp/proof_trace.bin $reps 0 1 > $D.log 2>&1)
+    (cd /tmp && rocprofv3 --hip-trace --stats --output-format csv -d $D -o t -- $EXE 20 4 16 0 /tmp/proof_trace.bin $reps 0 1 > $D.log 2>&1)
     echo "== $reps proofs (+ 1 warm-up): $(grep -m1 total_ms $D.log | grep -o '"total_ms": [0-9.]*') under the tracer"
     python3 - "$D" <<'PY'
 import csv, glob, sys
