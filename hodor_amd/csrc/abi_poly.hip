@@ -912,7 +912,10 @@ extern "C" int hodor_poly_lde_batch_h(const hodor_poly *const *ps, size_t count,
         if (!ps[i] || ps[i]->ctx != ctx || ps[i]->n != n) return HODOR_ERR_INVALID;
         POLY_SYNC(ps[i]);
         NEED_FORM(ps[i], HODOR_FORM_COEFFICIENTS);
-        if ((uint8_t *)ps[i]->d() != (uint8_t *)ps[0]->d() + i * n * 32) contiguous = false;
+        // back to back INSIDE ONE allocation (views of a batched result): two pool blocks that merely happen to be
+        // neighbours in the address space are two buffers — a launch must not run across the seam (found by the handle
+        // fuzzer on the bounds build, round 6)
+        if (ps[i]->slab != ps[0]->slab || ps[i]->off != ps[0]->off + i * n * 32) contiguous = false;
     }
     {   // the size-n*factor domain must exist before anything is allocated
         HFr w;
@@ -1161,7 +1164,7 @@ extern "C" int hodor_iop_create_batch_h(const hodor_poly *const *vs, size_t coun
     for (size_t i = 0; i < count; i++) {
         if (!vs[i] || vs[i]->ctx != ctx || vs[i]->n != n) return HODOR_ERR_INVALID;
         POLY_SYNC(vs[i]);
-        if ((uint8_t *)vs[i]->d() != (uint8_t *)vs[0]->d() + i * n * 32) contiguous = false;
+        if (vs[i]->slab != vs[0]->slab || vs[i]->off != vs[0]->off + i * n * 32) contiguous = false;   // one allocation, as in lde_batch
     }
     const size_t entries = iop_entries(n, combiner);
     int rc = HODOR_OK;

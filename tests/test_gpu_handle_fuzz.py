@@ -438,8 +438,11 @@ class _Program:
         weights = [w for _, w in self.STEPS]
         done = 0
         while done < steps:
-            if getattr(self, self.rng.choices(names, weights)[0])():
-                done += 1
+            try:
+                if getattr(self, self.rng.choices(names, weights)[0])():
+                    done += 1
+            except hodor_amd.HodorError as e:          # an error code nobody asked for: say where in the program
+                raise AssertionError("%s; last steps: %s" % (e, self.trace[-12:])) from e
         for p in list(self.live):
             self.check(p)
             self.drop(p)
