@@ -10,6 +10,7 @@ host images recycled by size, the "host image is the vector" state of `as_mut()`
 free, binary operand, tree, FRI, batched LDE, equality), the known-zero state of `new_for_size`, size changes in place.
 A wrong ordering or a stale copy there shows up as a differing vector a few steps later, which is what is compared.
 Nothing here reads /root/reference."""
+import os
 import random
 
 import numpy as np
@@ -448,13 +449,19 @@ class _Program:
             self.drop(p)
 
 
-@pytest.mark.parametrize("seed", range(8))
+# HODOR_FUZZ_PROGRAMS / HODOR_FUZZ_STEPS / HODOR_FUZZ_SEED0: a longer hunt than the suite's (bench/handle_fuzz_hunt.sh)
+PROGRAMS = int(os.environ.get("HODOR_FUZZ_PROGRAMS", "8"))
+STEPS = int(os.environ.get("HODOR_FUZZ_STEPS", "150"))
+SEED0 = int(os.environ.get("HODOR_FUZZ_SEED0", "0"))
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + PROGRAMS))
 def test_random_programs_over_live_handles(gpu_ctxs, oracles, field_name, seed):
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
     live0 = ctx.pool_stats()[1]
     prog = _Program(ctx, O, 1000 * seed + sorted(gpu_ctxs).index(field_name))
     try:
-        prog.run(150)
+        prog.run(STEPS)
     finally:
         for p in prog.live:                                           # a failed program must not poison the session's context
             p.h.free()
@@ -469,12 +476,12 @@ def test_concurrent_programs_share_one_context(gpu_ctxs, oracles):
     import threading
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
     live0 = ctx.pool_stats()[1]
-    progs = [_Program(ctx, O, 777000 + t) for t in range(3)]
+    progs = [_Program(ctx, O, 777000 + 10 * SEED0 + t) for t in range(3)]
     errors = []
 
     def work(prog):
         try:
-            prog.run(120)
+            prog.run(min(STEPS, 400))
         except BaseException as e:          # noqa: BLE001 — reported below, on the main thread
             errors.append((prog.trace[-12:], e))
 
