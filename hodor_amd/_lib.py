@@ -28,7 +28,7 @@ TRIVIAL, COSET2 = 0, 1   # HODOR_COMBINER_*: the tree format (CosetCombiner, src
 # every symbol include/hodor_gpu.h declares
 EXPORTS = [
     "hodor_abi_version", "hodor_ctx_try_destroy", "hodor_ctx_create", "hodor_ctx_destroy", "hodor_ctx_field_info", "hodor_last_error",
-    "hodor_ctx_synchronize", "hodor_knobs_set",
+    "hodor_ctx_synchronize", "hodor_knobs_set", "hodor_debug_alloc_calls", "hodor_debug_fail_alloc",
     "hodor_fr_mul", "hodor_fr_add", "hodor_fr_sub", "hodor_fr_pow", "hodor_fr_inverse",
     "hodor_fr_from_repr", "hodor_fr_into_repr", "hodor_domain_new_for_size",
     "hodor_fft", "hodor_lde", "hodor_distribute_powers",
@@ -143,6 +143,9 @@ def lib():
                               % (_lib.hodor_abi_version(), ABI_VERSION))
         _lib.hodor_last_error.restype = C.c_char_p
         _lib.hodor_knobs_set.restype = C.c_char_p
+        _lib.hodor_debug_alloc_calls.restype = C.c_longlong
+        _lib.hodor_debug_fail_alloc.restype = None
+        _lib.hodor_debug_fail_alloc.argtypes = [C.c_longlong, C.c_int]
         _lib.hodor_fri_num_steps.restype = C.c_size_t
         _lib.hodor_fri_serialize.restype = C.c_size_t
         _lib.hodor_fri_produce_proof.restype = C.c_size_t

@@ -132,19 +132,33 @@ int get_pow_table(hodor_ctx *ctx, const HFr &base, uint32_t log_n, TwoLevel *out
     t.hi_mult = hi_mult;
     const size_t esz = fmt == 2 ? 112 : (fmt ? 48 : 32);
     uint64_t lo_cnt = 1ull << t.lo_bits, hi_cnt = 1ull << (log_n - t.lo_bits);
-    HIPCHK(hipMalloc((void **)&t.lo, lo_cnt * esz));
-    HIPCHK(hipMalloc((void **)&t.hi, hi_cnt * esz));
+    t.lo = t.hi = nullptr;
+    auto fail = [&](hipError_t e, const char *what) {   // a half-built table is not cached and not leaked
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        BOUNDS_FORGET(t.lo);
+        BOUNDS_FORGET(t.hi);
+        if (t.lo) (void)hipFree(t.lo);
+        if (t.hi) (void)hipFree(t.hi);
+        set_err(ctx, std::string(what) + ": " + hipGetErrorString(e));
+        return HODOR_ERR_DEVICE;
+    };
+    hipError_t e;
+    if ((e = dev_malloc((void **)&t.lo, lo_cnt * esz)) != hipSuccess) return fail(e, "power table (hipMalloc)");
     BOUNDS_NOTE(t.lo, lo_cnt * esz);
+    if ((e = dev_malloc((void **)&t.hi, hi_cnt * esz)) != hipSuccess) return fail(e, "power table (hipMalloc)");
     BOUNDS_NOTE(t.hi, hi_cnt * esz);
     Fr b = to_dev(base), one = to_dev(ctx->F.one);
     if (fmt == 2) {
-        HIPCHK(pow_table_w3_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, ctx->K3, ctx->P));
-        HIPCHK(pow_table_w3_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, ctx->K3, ctx->P));
+        if ((e = pow_table_w3_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, ctx->K3, ctx->P)) != hipSuccess ||
+            (e = pow_table_w3_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, ctx->K3, ctx->P)) != hipSuccess)
+            return fail(e, "power table (k_pow_table_w3)");
     } else {
-        HIPCHK(pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, fmt, ctx->P));
-        HIPCHK(pow_table_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, fmt, ctx->P));
+        if ((e = pow_table_launch(ctx->stream, t.lo, b, one, 0, lo_cnt, fmt, ctx->P)) != hipSuccess ||
+            (e = pow_table_launch(ctx->stream, t.hi, b, to_dev(hi_mult), t.lo_bits, hi_cnt, fmt, ctx->P)) != hipSuccess)
+            return fail(e, "power table (k_pow_table)");
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // tables are shared across streams afterwards
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "power table");   // tables are shared across streams afterwards
     ctx->pow_tables.push_back(t);
     *out = TwoLevel{t.lo, t.hi, t.lo_bits};
 #ifdef HODOR_BOUNDS
@@ -184,13 +198,13 @@ static int get_radix_table(hodor_ctx *ctx, const HFr &omega, uint32_t log_n, uin
         return HODOR_ERR_DEVICE;
     };
     hipError_t e;
-    if ((e = hipMalloc((void **)&t.rtw, cnt * 112)) != hipSuccess) return fail(e, "radix table (hipMalloc)");
+    if ((e = dev_malloc((void **)&t.rtw, cnt * 112)) != hipSuccess) return fail(e, "radix table (hipMalloc)");
     BOUNDS_NOTE(t.rtw, cnt * 112);
     if ((e = pow_table_w3_launch(ctx->stream, t.rtw, to_dev(omega), to_dev(ctx->F.one), log_n - log_r, cnt, ctx->K3,
                                  ctx->P)) != hipSuccess)
         return fail(e, "radix table (k_pow_table_w3)");
     if (log_r >= 6) {   // the 16 powers omega_R^(e R/32) = omega^(e << (log_n - 5)) the wave-uniform steps use
-        if ((e = hipMalloc((void **)&t.rtw9, 16 * W9_WORDS * sizeof(uint32_t))) != hipSuccess ||
+        if ((e = dev_malloc((void **)&t.rtw9, 16 * W9_WORDS * sizeof(uint32_t))) != hipSuccess ||
             (BOUNDS_NOTE(t.rtw9, 16 * W9_WORDS * sizeof(uint32_t)), false) ||
             (e = pow_table_w9_launch(ctx->stream, t.rtw9, to_dev(omega), log_n - 5, 16, ctx->K9, ctx->P)) != hipSuccess) {
             // the W9 table is an optimisation: without it the pass takes the W3 path for every step
@@ -238,7 +252,7 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
         L->buf[which] = nullptr;
         L->bytes[which] = 0;
     }
-    if ((e = hipMalloc(&L->buf[which], bytes)) != hipSuccess) return e;
+    if ((e = dev_malloc(&L->buf[which], bytes)) != hipSuccess) return e;
     BOUNDS_NOTE(L->buf[which], bytes);
     L->bytes[which] = bytes;
     return hipSuccess;
@@ -249,30 +263,43 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
 // runtime finds the upload's engine busy and gives the download another one.
 static hipError_t dir_streams_prepare(hodor_ctx *ctx)
 {
-    std::call_once(ctx->dir_once, [ctx] {
-        hipError_t &e = ctx->dir_err;
-        void *scratch = nullptr;
-        const size_t half = hodor_ctx::PINNED_BYTES / 2;
-        if ((e = hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking)) != hipSuccess) return;
-        if ((e = hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking)) != hipSuccess) return;
-        if ((e = hipMalloc(&scratch, hodor_ctx::PINNED_BYTES)) != hipSuccess) return;
-        {
-            std::lock_guard<std::mutex> lk(ctx->pinned_mu);
-            if (!ctx->pinned && (e = hipHostMalloc(&ctx->pinned, hodor_ctx::PINNED_BYTES, hipHostMallocDefault)) != hipSuccess) {
-                ctx->pinned = nullptr;
-                (void)hipFree(scratch);
-                return;
-            }
-            for (int i = 0; i < 256 && e == hipSuccess; i++)
-                e = hipMemcpyAsync(scratch, ctx->pinned, half, hipMemcpyHostToDevice, ctx->up_stream);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync((char *)ctx->pinned + half, (char *)scratch + half, half, hipMemcpyDeviceToHost, ctx->down_stream);
-            hipError_t e1 = hipStreamSynchronize(ctx->up_stream), e2 = hipStreamSynchronize(ctx->down_stream);
-            if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    std::lock_guard<std::mutex> once(ctx->dir_mu);
+    if (ctx->dir_ready) return hipSuccess;
+    // Nothing is latched on failure (round 6: a std::call_once here turned ONE refused allocation into a slice API that
+    // answered "out of memory" for the rest of the context's life): what was created is destroyed and the next call tries again.
+    hipError_t e;
+    hipStream_t up = nullptr, down = nullptr;
+    void *scratch = nullptr;
+    const size_t half = hodor_ctx::PINNED_BYTES / 2;
+    auto undo = [&](hipError_t err) {
+        (void)hipGetLastError();
+        if (scratch) (void)hipFree(scratch);
+        if (up) (void)hipStreamDestroy(up);
+        if (down) (void)hipStreamDestroy(down);
+        return err;
+    };
+    if ((e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking)) != hipSuccess) return undo(e);
+    if ((e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking)) != hipSuccess) return undo(e);
+    if ((e = dev_malloc(&scratch, hodor_ctx::PINNED_BYTES)) != hipSuccess) return undo(e);
+    {
+        std::lock_guard<std::mutex> lk(ctx->pinned_mu);
+        if (!ctx->pinned && (e = pinned_malloc(&ctx->pinned, hodor_ctx::PINNED_BYTES, hipHostMallocDefault)) != hipSuccess) {
+            ctx->pinned = nullptr;
+            return undo(e);
         }
-        (void)hipFree(scratch);
-    });
-    return ctx->dir_err;
+        for (int i = 0; i < 256 && e == hipSuccess; i++)
+            e = hipMemcpyAsync(scratch, ctx->pinned, half, hipMemcpyHostToDevice, up);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((char *)ctx->pinned + half, (char *)scratch + half, half, hipMemcpyDeviceToHost, down);
+        hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(down);
+        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    }
+    if (e != hipSuccess) return undo(e);
+    (void)hipFree(scratch);
+    ctx->up_stream = up;
+    ctx->down_stream = down;
+    ctx->dir_ready = true;
+    return hipSuccess;
 }
 
 // Caller holds ctx->mu.  `user`: the stream whose work is about to use the pool.  Every call that uses the pool
@@ -293,7 +320,7 @@ int ensure_scratch(hodor_ctx *ctx, int which, size_t bytes, hipStream_t user)
         ctx->scratch[which] = nullptr;
         ctx->scratch_bytes[which] = 0;
     }
-    HIPCHK(hipMalloc(&ctx->scratch[which], bytes));
+    HIPCHK(dev_malloc(&ctx->scratch[which], bytes));
     BOUNDS_NOTE(ctx->scratch[which], bytes);
     ctx->scratch_bytes[which] = bytes;
     return HODOR_OK;
@@ -676,7 +703,7 @@ extern "C" int hodor_buf_alloc(hodor_ctx *ctx, size_t bytes, void **dev_ptr)
 {
     NEED_DEVICE();
     if (!dev_ptr) return HODOR_ERR_INVALID;
-    HIPCHK(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    HIPCHK(dev_malloc(dev_ptr, bytes ? bytes : 1));
     BOUNDS_NOTE(*dev_ptr, bytes);
     return HODOR_OK;
 }

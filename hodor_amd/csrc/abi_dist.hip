@@ -44,7 +44,7 @@ int work_acquire(hodor_exchange *x, int i, size_t bytes, hipStream_t stream, voi
             x->work[i] = nullptr;
             x->work_bytes[i] = 0;
         }
-        HIPCHK(hipMalloc(&x->work[i], bytes));
+        HIPCHK(dev_malloc(&x->work[i], bytes));
         BOUNDS_NOTE(x->work[i], bytes);
         x->work_bytes[i] = bytes;
     } else if (x->work_used[i] && x->work_free[i]) {

@@ -394,9 +394,9 @@ extern "C" int hodor_exchange_create_direct(hodor_ctx *ctx, uint32_t n_ranks, ui
     // fine-grained: the flags are written by other devices while kernels of this one poll them
     if (e == hipSuccess) e = hipExtMallocWithFlags((void **)&x->my_flags, flag_bytes, hipDeviceMallocFinegrained);
     if (e == hipSuccess) e = hipMemset(x->my_flags, 0, flag_bytes);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&x->d_err, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = pinned_malloc((void **)&x->d_err, sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) *x->d_err = 0;
-    for (uint32_t i = 0; e == hipSuccess && i < n_slots; i++) e = hipMalloc((void **)&x->slots[i].d_tab, n_ranks * sizeof(uint64_t));
+    for (uint32_t i = 0; e == hipSuccess && i < n_slots; i++) e = dev_malloc((void **)&x->slots[i].d_tab, n_ranks * sizeof(uint64_t));
     // copy-engine transport (hodor_exchange_direct_copy_dev): a stream of its own for the peer copies and their flags
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ready, hipEventDisableTiming);
@@ -429,7 +429,7 @@ extern "C" int hodor_exchange_direct_alloc_recv(hodor_exchange *x, size_t n_loca
     std::lock_guard<std::mutex> lk(x->mu);
     if (x->own_recv[0]) { set_err(ctx, "exchange (direct): the receive buffers exist already"); return HODOR_ERR_INVALID; }
     for (uint32_t i = 0; i < x->n_slots; i++) {
-        hipError_t e = coarse ? hipMalloc(&x->own_recv[i], n_local * 32)
+        hipError_t e = coarse ? dev_malloc(&x->own_recv[i], n_local * 32)
                               : hipExtMallocWithFlags(&x->own_recv[i], n_local * 32, hipDeviceMallocFinegrained);
         if (e != hipSuccess) {
             (void)hipGetLastError();

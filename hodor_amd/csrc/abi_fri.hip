@@ -458,7 +458,7 @@ extern "C" int hodor_fri_commit_through_coefficients(hodor_ctx *ctx, const hodor
     if (!lde_values || !out) return HODOR_ERR_INVALID;
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
     DevBuf dv;
-    HIPCHK(hipMalloc(&dv.p, n * 32));
+    HIPCHK(dev_malloc(&dv.p, n * 32));
     BOUNDS_NOTE(dv.p, n * 32);
     if (int rc_up = hodor_buf_upload(ctx, dv.p, lde_values, n * 32)) return rc_up;   // small codewords through the pinned buffer
     return hodor_fri_commit_through_coefficients_dev(ctx, (void *)ctx->stream, (const hodor_fr *)dv.p, n, lde_factor,
@@ -478,7 +478,7 @@ extern "C" int hodor_fri_commit_combined(hodor_ctx *ctx, const hodor_fr *lde_val
     if (!lde_values || !out) return HODOR_ERR_INVALID;
     if (!is_pow2(n) || n < 2) return HODOR_ERR_SIZE;
     DevBuf dv;
-    HIPCHK(hipMalloc(&dv.p, n * 32));
+    HIPCHK(dev_malloc(&dv.p, n * 32));
     BOUNDS_NOTE(dv.p, n * 32);
     if (int rc_up = hodor_buf_upload(ctx, dv.p, lde_values, n * 32)) return rc_up;   // small codewords through the pinned buffer
     // the context's own compute stream, like every other slice entry point: in-order with the other

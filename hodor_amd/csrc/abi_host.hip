@@ -320,3 +320,52 @@ const Knobs &knobs()
 
 extern "C" const char *hodor_knobs_set(void) { return hodor::knobs().set; }
 
+// ---- allocation wrappers + fault injection (ctx.hpp)
+namespace hodor {
+namespace {
+struct FailAlloc {
+    long long k = 0;        // 0: off
+    bool from_on = false;   // "<k>+"
+    FailAlloc()
+    {
+        const char *e = getenv("HODOR_DEBUG_FAIL_ALLOC");
+        if (!e || !*e) return;
+        char *end = nullptr;
+        k = strtoll(e, &end, 10);
+        if (k < 0) k = 0;
+        from_on = end && *end == '+';
+    }
+};
+std::atomic<long long> g_alloc_calls{0};
+std::atomic<long long> g_fail_at{-1};     // -1: not armed at run time (the environment decides)
+std::atomic<int> g_fail_from_on{0};
+bool alloc_fails()
+{
+    static const FailAlloc f;
+    const long long c = g_alloc_calls.fetch_add(1) + 1;
+    const long long at = g_fail_at.load();
+    if (at >= 0) return at && (g_fail_from_on.load() ? c >= at : c == at);
+    return f.k && (f.from_on ? c >= f.k : c == f.k);
+}
+}  // namespace
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    if (alloc_fails()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+hipError_t pinned_malloc(void **p, size_t bytes, unsigned flags)
+{
+    if (alloc_fails()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipHostMalloc(p, bytes, flags);
+}
+}  // namespace hodor
+
+// allocations the library has asked for so far in this process (what HODOR_DEBUG_FAIL_ALLOC counts)
+extern "C" long long hodor_debug_alloc_calls(void) { return hodor::g_alloc_calls.load(); }
+// arm at run time: the k-th allocation FROM NOW fails (k = 0: none does); from_on != 0: so does every later one
+extern "C" void hodor_debug_fail_alloc(long long k, int from_on)
+{
+    hodor::g_fail_from_on.store(from_on ? 1 : 0);
+    hodor::g_fail_at.store(k > 0 ? hodor::g_alloc_calls.load() + k : 0);
+}
+

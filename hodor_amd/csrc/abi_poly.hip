@@ -99,11 +99,11 @@ int pool_alloc(hodor_ctx *ctx, size_t bytes, void **out, size_t *got, hipStream_
         reap = !ctx->pool_zombies.empty();
     }
     if (reap) pool_reap(ctx);   // entering the allocator anyway: the evicted blocks go back to HIP first
-    hipError_t e = hipMalloc(out, want);
+    hipError_t e = dev_malloc(out, want);
     if (e != hipSuccess) {   // give the cache back and try once more
         (void)hipGetLastError();
         pool_drain(ctx);
-        e = hipMalloc(out, want);
+        e = dev_malloc(out, want);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -210,9 +210,9 @@ struct HostImage {
                 auto it = c->host_free.find(want);
                 if (it != c->host_free.end()) { q = it->second; c->host_cached -= want; c->host_free.erase(it); }
             }
-            if (!q && hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) {
+            if (!q && pinned_malloc(&q, want, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
-                return HODOR_ERR_INVALID;   // no host memory for a copy of the polynomial
+                return HODOR_ERR_DEVICE;    // the runtime has no pinned memory for a copy of the polynomial
             }
             p = (hodor_fr *)q;
             pinned = true;
@@ -594,9 +594,9 @@ static int poly_materialise(hodor_poly *p)
 {
     hodor_ctx *ctx = p->ctx;
     if (p->host_valid || p->host_dirty) return HODOR_OK;
-    if (p->host.reserve(ctx, p->n)) {   // no exception crosses the ABI: a host copy of a vector that large is simply refused
+    if (int rc = p->host.reserve(ctx, p->n)) {   // no exception crosses the ABI: a host copy of a vector that large is simply refused
         set_err(ctx, "as_ref / as_mut: no host memory for a copy of the polynomial");
-        return HODOR_ERR_INVALID;
+        return rc;                               // HODOR_ERR_DEVICE: hipHostMalloc said no; HODOR_ERR_INVALID: malloc did
     }
     if (p->all_zero) {   // Polynomial::new_for_size(..) followed by as_mut() (src/ali/per_register/mod.rs:112-118): zeros need no PCIe
         memset(p->host.data(), 0, p->n * 32);

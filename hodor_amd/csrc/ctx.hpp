@@ -132,6 +132,11 @@ struct RadixTable {
     uint32_t *rtw9;        // omega_R^(e R/32), e < 16, W9 entries (null for R < 64)
 };
 
+// Every device / pinned allocation of the library goes through these two (abi_host.hip): hipMalloc / hipHostMalloc, except
+// that HODOR_DEBUG_FAIL_ALLOC=<k> makes the k-th allocation of the process (counted from 1, both kinds together) fail with
+// hipErrorOutOfMemory, and "<k>+" every allocation from the k-th on — the fault injection of tests/test_gpu_alloc_faults.py.
+hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t pinned_malloc(void **p, size_t bytes, unsigned flags);
 }  // namespace hodor
 
 using namespace hodor;
@@ -183,8 +188,8 @@ struct hodor_ctx {
     // engine: measured, 17-19 ms each instead of 9.6 (profiles/r05/slice_trace.txt).  One stream that only ever uploads and
     // one that only ever downloads, bound while the other is busy, get two engines.
     hipStream_t up_stream = nullptr, down_stream = nullptr;
-    std::once_flag dir_once;
-    hipError_t dir_err = hipSuccess;
+    std::mutex dir_mu;           // the first slice call prepares them; a failed preparation is retried by the next call
+    bool dir_ready = false;
     std::atomic<int> live_exchanges{0};   // hodor_exchange handles that point at this context (abi_exchange.hip)
     std::atomic<int> live_handles{0};     // hodor_poly / hodor_iop / hodor_fri_proto objects whose memory is this context's pool
     uint32_t max_log_r = 9;    // largest per-pass radix (2^max_log_r points)      } measured best on MI355X
@@ -297,7 +302,7 @@ class HostXfer {
     hipError_t room(size_t n)
     {
         if (!ctx_->pinned) {
-            hipError_t e = hipHostMalloc(&ctx_->pinned, hodor_ctx::PINNED_BYTES, hipHostMallocDefault);
+            hipError_t e = pinned_malloc(&ctx_->pinned, hodor_ctx::PINNED_BYTES, hipHostMallocDefault);
             if (e != hipSuccess) { ctx_->pinned = nullptr; return e; }
         }
         if (n <= hodor_ctx::PINNED_BYTES && used_ + n > hodor_ctx::PINNED_BYTES) return finish();   // drain, start over at 0

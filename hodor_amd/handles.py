@@ -436,13 +436,13 @@ class FriPrototypeHandle:
         L = self.ctx.L
         need = L.hodor_fri_produce_proof_h(self.proto.h, self.lde_values.h, C.c_size_t(natural_first_element_index),
                                            None, C.c_size_t(0))
-        if need == 0:
-            raise HodorError(ERR_INVALID, "hodor_fri_produce_proof_h")
+        if need == 0:      # "0 on error": the size-returning entry point has no code to give; the reason is the context's last error
+            raise HodorError(ERR_INVALID, "hodor_fri_produce_proof_h: " + (L.hodor_last_error(self.ctx.h) or b"").decode())
         buf = (C.c_uint8 * need)()
         got = L.hodor_fri_produce_proof_h(self.proto.h, self.lde_values.h, C.c_size_t(natural_first_element_index),
                                           buf, C.c_size_t(need))
         if got != need:
-            raise HodorError(ERR_INVALID, "hodor_fri_produce_proof_h")
+            raise HodorError(ERR_INVALID, "hodor_fri_produce_proof_h: " + (L.hodor_last_error(self.ctx.h) or b"").decode())
         return bytes(buf)
 
     def verify_prototype(self, natural_element_index):

@@ -89,6 +89,12 @@ int  hodor_ctx_synchronize(hodor_ctx *ctx);
  * They are read once per process, change schedules only (never results), and a benchmark must echo
  * them (bench.py does, and refuses to run with any of them set unless told otherwise). */
 const char *hodor_knobs_set(void);
+/* Debug aid (fault injection): HODOR_DEBUG_FAIL_ALLOC=<k> makes the k-th device / pinned allocation the library asks the
+ * runtime for in this process fail as out of memory ("<k>+": every one from the k-th on); this returns how many it has
+ * asked for so far.  Every entry point must answer such a failure with an error code and leave every object usable
+ * (tests/test_gpu_alloc_faults.py walks k over a whole proof-shaped sequence). */
+long long hodor_debug_alloc_calls(void);
+void hodor_debug_fail_alloc(long long k, int from_on);   /* the same, armed at run time: the k-th allocation FROM NOW (0 = disarm) */
 
 /* ---- scalar field helpers on the host (ff_ce Field/PrimeField methods the callers use to derive
  * omegainv / minv / geninv, src/polynomials/mod.rs:146-166) */

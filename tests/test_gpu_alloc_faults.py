@@ -1,0 +1,174 @@
+"""Allocation faults (-m gpu): the library asks the runtime for device and pinned memory in ~60 places of a proof-shaped
+sequence (twiddle and radix tables, the transform scratch, pool blocks behind every handle, pinned host images, the slice
+API's staging lanes, FRI prototypes); `hodor_debug_fail_alloc(k, from_on)` (include/hodor_gpu.h) makes the k-th such request
+FROM NOW fail as out of memory.  This walks k over the whole sequence — context creation and its self-test included — and
+asks of every entry point what an integrator needs when a 288 GB part does fill up:
+
+  * the call answers with an error code (HODOR_ERR_DEVICE) — no crash, no exception from nowhere;
+  * nothing is half done: the SAME call, repeated, succeeds and every result of the sequence is byte-identical to the
+    un-faulted run's (an in-place method that had already changed its vector would show here);
+  * nothing leaks: at the end every pool block is back, the context destroys, and the device's free memory returns to
+    where it was before the context existed.
+
+Nothing here reads /root/reference."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import hodor_amd
+from hodor_amd.handles import COEFFICIENTS, VALUES, FriPrototypeHandle, IopTree, Polynomial
+
+pytestmark = pytest.mark.gpu
+
+MOD, GEN = 52435875175126190479447740508185965837690552500527637822603658699938581184513, 7
+
+
+def _elements(n, seed):
+    """canonical Montgomery images are not needed here — any value below the modulus is a field element's image"""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)              # < 2^252 < p
+    a[:, 0] |= np.uint64(1)                          # never zero (batch_inversion below)
+    return a
+
+
+class _Run:
+    """one pass over the sequence; `arm` = (k, from_on) or None"""
+
+    def __init__(self, arm):
+        self.L = hodor_amd._lib.lib()
+        self.arm = arm
+        self.faults = []                 # (step, message) of every refusal seen
+        self.out = hashlib.blake2s()
+
+    def attempt(self, name, f):
+        for tries in range(4):
+            try:
+                return f()
+            except hodor_amd.HodorError as e:
+                # (hodor_fri_produce_proof_h returns a byte count, "0 on error": the binding has no code to pass on)
+                assert e.code == hodor_amd.ERR_DEVICE or (name == "fri proof" and "hipMalloc" in str(e)), (name, e)
+                self.faults.append((name, str(e)))
+                if self.arm and self.arm[1] and tries == 1:
+                    self.L.hodor_debug_fail_alloc(0, 0)      # "every allocation from the k-th on": refused twice, then memory is back
+        raise AssertionError("%s keeps failing: %s" % (name, self.faults[-3:]))
+
+    def put(self, x):
+        self.out.update(x if isinstance(x, (bytes, bytearray)) else np.ascontiguousarray(x).tobytes())
+
+    def run(self):
+        L = self.L
+        if self.arm:
+            L.hodor_debug_fail_alloc(self.arm[0], 1 if self.arm[1] else 0)
+        ctx = self.attempt("ctx_create", lambda: hodor_amd.Context(MOD, GEN, device=0))
+        try:
+            self.sequence(ctx)
+            assert ctx.pool_stats()[1] == 0, "pool blocks still live at the end"
+        except BaseException as e:
+            L.hodor_debug_fail_alloc(0, 0)
+            try:
+                ctx.close()              # (refuses while the failed sequence's handles are alive: the first error is the news)
+            except hodor_amd.HodorError:
+                pass
+            raise AssertionError("armed %s: %r after the refusals %s" % (self.arm, e, self.faults)) from e
+        L.hodor_debug_fail_alloc(0, 0)
+        ctx.close()
+        return self.out.hexdigest()
+
+    def sequence(self, ctx):
+        at = self.attempt
+        small, big = _elements(1 << 12, 1), _elements(1 << 16, 2)            # 128 KiB / 2 MiB: heap and pinned images, both pool regimes
+        p = at("from_coeffs small", lambda: Polynomial.from_coeffs(ctx, small))
+        q = at("from_coeffs big", lambda: Polynomial.from_coeffs(ctx, big))
+        q2 = at("clone", lambda: q.clone())
+        at("distribute_powers", lambda: q2.distribute_powers(ctx.generator))
+        lde = at("lde", lambda: p.lde(8))
+        ldes = at("lde_all", lambda: Polynomial.lde_all([q, q2], 2, coset=True))
+        self.put(at("as_ref lde", lambda: lde.as_ref()))
+        tree = at("iop create", lambda: IopTree.create(lde))
+        self.put(at("root", lambda: tree.get_root()))
+        vals, path = at("query", lambda: tree.query(77, lde))
+        self.put(b"".join(path))
+        trees = at("iop create_all", lambda: IopTree.create_all(ldes))
+        for r in at("roots", lambda: IopTree.get_roots(trees)):
+            self.put(r)
+        proto = at("fri commit", lambda: FriPrototypeHandle(lde, 8, 2))
+        self.put(proto.proto.serialized)
+        self.put(at("fri proof", lambda: proto.produce_proof_bytes(5)))
+        both = at("fri commit_all", lambda: FriPrototypeHandle.commit_all(ldes, 2, 1))
+        for b in both:
+            self.put(b.proto.serialized)
+        at("fft in place", lambda: q.fft())
+        at("batch_inversion", lambda: q.batch_inversion())
+        at("ifft in place", lambda: q.ifft())
+        self.put(at("evaluate_at", lambda: q.evaluate_at(ctx.generator)).to_bytes(32, "little"))
+        v = at("as_mut big", lambda: q2.as_mut())
+        v[5] = v[7]
+        at("commit_mut", lambda: q2.commit_mut())
+        at("coset_fft in place", lambda: q2.coset_fft())
+        at("square", lambda: q2.square())
+        at("icoset_fft in place", lambda: q2.icoset_fft())
+        at("pad_by_factor", lambda: p.pad_by_factor(2))
+        self.put(at("as_ref q", lambda: q.as_ref()))
+        self.put(at("as_ref q2", lambda: q2.as_ref()))
+        self.put(at("as_ref p", lambda: p.as_ref()))
+        z = at("new_for_size", lambda: Polynomial.new_for_size(ctx, VALUES, 1 << 15))
+        d1 = at("degree_one", lambda: Polynomial.degree_one_on_domain(ctx, 1 << 15, ctx.generator, ctx.one, True))
+        at("add_assign", lambda: z.add_assign(d1))
+        self.put(at("as_ref z", lambda: z.as_ref()))
+        # slice API: host memory in, host memory out (staging lanes, the pinned bounce buffer)
+        n, k, omega = ctx.domain(1 << 14)
+        host = _elements(1 << 14, 3)
+        expect = host.copy()
+        at("slice fft", lambda: ctx.fft(host, omega, k))
+        self.put(host)
+        for h in both:
+            h.free()
+        proto.free()
+        for t in trees + [tree]:
+            t.free()
+        for x in ldes + [lde, p, q, q2, z, d1]:
+            x.free()
+        del expect
+
+
+def _free_bytes():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_every_allocation_of_a_proof_shaped_sequence_may_fail():
+    L = hodor_amd._lib.lib()
+    L.hodor_debug_fail_alloc(0, 0)
+    _Run(None).run()                                    # warm: code objects, the runtime's own pools
+    free0 = _free_bytes()
+    c0 = L.hodor_debug_alloc_calls()
+    clean = _Run(None)
+    want = clean.run()
+    total = L.hodor_debug_alloc_calls() - c0
+    assert not clean.faults and 30 <= total <= 400, (total, clean.faults)
+    assert _Run(None).run() == want                     # the sequence is deterministic
+    slack = 8 << 20                                     # the runtime hands small blocks back lazily
+    assert abs(_free_bytes() - free0) <= slack
+    seen, tolerated = set(), []
+    for k in range(1, total + 1):
+        for from_on in (False, True):        # one refusal / memory stays short until the call has been refused twice
+            r = _Run((k, from_on))
+            got = r.run()
+            assert got == want, "allocation %d%s refused at %s: results differ" % (k, "+" if from_on else "", r.faults)
+            if not r.faults and not from_on:
+                tolerated.append(k)             # absorbed: see below
+            seen.update(name for name, _ in r.faults)
+            assert abs(_free_bytes() - free0) <= slack, "device memory lost after a refusal at %s" % (r.faults,)
+    # absorbed = the pool's own second attempt (it hands its cached blocks back to the runtime and asks again) and the W9
+    # constant tables a pass can do without; everything else has to surface
+    print("allocations per sequence: %d; refusals the library absorbed without an error: %s" % (total, tolerated))
+    assert len(tolerated) <= total // 2, tolerated
+    # the walk reached the context, the tables / scratch behind the transforms, the pool, the host images and the slice API
+    print("steps that were refused at least once:", sorted(seen))
+    for name in ("ctx_create", "as_mut big", "slice fft"):
+        assert name in seen, (name, sorted(seen))
+    assert len(seen) >= 12, sorted(seen)
