@@ -495,7 +495,8 @@ static int direct_ready(hodor_exchange *x, uint32_t slot)
     for (uint32_t t = 0; t < x->n_ranks; t++)
         if (!x->peer_flags[t]) { set_err(ctx, "exchange (direct): a peer's flag block is missing"); return HODOR_ERR_INVALID; }
     if (*(volatile uint32_t *)x->d_err) {   // pinned host memory: no synchronisation with the device
-        set_err(ctx, "exchange (direct): a wait for a peer timed out earlier on this handle");
+        set_err(ctx, "exchange (direct): this handle is dead — a schedule failed after it had opened a generation on a slot, or a "
+                     "wait for a peer timed out; destroy it and create a new one on every rank");
         return HODOR_ERR_DEVICE;
     }
     return HODOR_OK;

@@ -172,3 +172,85 @@ def test_every_allocation_of_a_proof_shaped_sequence_may_fail():
     for name in ("ctx_create", "as_mut big", "slice fft"):
         assert name in seen, (name, sorted(seen))
     assert len(seen) >= 12, sorted(seen)
+
+
+class _DistRun(_Run):
+    """the multi-GPU schedules at world 1 with the exchanges forced (work buffers, receive slots, peer tables)"""
+
+    def __init__(self, arm, kind):
+        super().__init__(arm)
+        self.kind = kind
+
+    def sequence(self, ctx):
+        import torch
+        from hodor_amd import _lib
+        at = self.attempt
+        log_n, factor = 13, 4
+        n, big = 1 << log_n, (1 << log_n) * factor
+        a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        ctx.gen_elements_dev(a, 0, n, 4242)
+        w = ctx.domain(n)[2]
+
+        def make():
+            x = hodor_amd.DirectExchange(ctx, 1, 0, big, n_slots=4)
+            try:
+                hodor_amd.DirectExchange.connect_local([x])
+                x.set_transport(_lib.COPY if self.kind == "copy" else _lib.DIRECT, force_collectives=True)
+            except BaseException:
+                x.close()
+                raise
+            return x
+        # A schedule that fails after it has opened a generation on a slot leaves the protocol half open: the handle is
+        # dead by contract (include/hodor_gpu.h, "dist status") — every later call refuses at once, the peers' waits time
+        # out into the same state — and the caller builds a new one.  So the unit that is repeated here is the handle's life.
+        for life in range(4):
+            x = at("exchange create", make)
+            try:
+                b = x.dist_forward(a, torch.empty_like(a), log_n, w, 1)
+                back = x.dist_inverse(b, torch.empty_like(a), log_n, w, 1)
+                nat = x.dist_natural(a, torch.empty_like(a), log_n, w, False)
+                blk = x.dist_lde_by_cosets(a, log_n, factor, torch.empty((big, 4), dtype=torch.int64, device="cuda"))
+                nodes = torch.empty((big, 32), dtype=torch.uint8, device="cuda")
+                root, top = x.dist_commit(blk, nodes, hodor_amd.TRIVIAL)
+                ctx.synchronize()
+            except hodor_amd.HodorError as e:
+                assert e.code == hodor_amd.ERR_DEVICE, e
+                self.faults.append(("dist schedule", str(e)))
+                if self.arm and self.arm[1] and life == 1:
+                    self.L.hodor_debug_fail_alloc(0, 0)
+                with pytest.raises(hodor_amd.HodorError):          # dead or alive, it answers; it never hangs
+                    x.dist_forward(a, torch.empty_like(a), log_n + 9, w, 1)
+                continue
+            finally:
+                x.close()
+            assert torch.equal(back, a)
+            for t in (b, nat, blk, nodes):
+                self.put(t.cpu().numpy())
+            self.put(root)
+            return
+        raise AssertionError("the schedules keep failing: %s" % (self.faults[-3:],))
+
+
+@pytest.mark.parametrize("kind", ["direct", "copy"])
+def test_every_allocation_of_the_distributed_schedules_may_fail(kind):
+    import torch
+    L = hodor_amd._lib.lib()
+    L.hodor_debug_fail_alloc(0, 0)
+    _DistRun(None, kind).run()
+    c0 = L.hodor_debug_alloc_calls()
+    clean = _DistRun(None, kind)
+    want = clean.run()
+    total = L.hodor_debug_alloc_calls() - c0
+    assert not clean.faults and total >= 20, (total, clean.faults)
+    torch.cuda.empty_cache()
+    free0 = _free_bytes()
+    seen = set()
+    for k in range(1, total + 1):
+        for from_on in (False, True):
+            r = _DistRun((k, from_on), kind)
+            assert r.run() == want, "allocation %d%s refused at %s: results differ" % (k, "+" if from_on else "", r.faults)
+            seen.update(name for name, _ in r.faults)
+    torch.cuda.empty_cache()
+    assert abs(_free_bytes() - free0) <= 8 << 20
+    print("%s: %d allocations per sequence; steps refused at least once: %s" % (kind, total, sorted(seen)))
+    assert {"exchange create", "dist schedule"} <= seen, sorted(seen)
