@@ -68,6 +68,22 @@ def gpu_ctxs():
         c.close()
 
 
+def variant_lib(target, name):
+    """hodor_amd/<name>, a build variant of the library (`make <target>` in hodor_amd/csrc: nolate, bounds, ...), rebuilt when
+    it is missing or does not export the binding's whole symbol list — a variant left over from an older tree would fail to
+    load (or load and test yesterday's code).  Returns the path, or None when it cannot be built here."""
+    import subprocess
+    lib = os.path.join(ROOT, "hodor_amd", name)
+    probe = ("import ctypes, sys; sys.path.insert(0, %r); from hodor_amd import _lib; h = ctypes.CDLL(%r); "
+             "sys.exit(0 if all(hasattr(h, s) for s in _lib.EXPORTS) else 1)" % (ROOT, lib))
+
+    def current():     # in a process of its own: two copies of the kernels must not meet in this one
+        return os.path.exists(lib) and subprocess.run([sys.executable, "-c", probe], capture_output=True).returncode == 0
+    if not current():
+        subprocess.run(["make", "-C", os.path.join(ROOT, "hodor_amd", "csrc"), target], capture_output=True)
+    return lib if current() else None
+
+
 def need_hbm(bytes_needed, what):
     """Flagship-size GPU tests must not turn into an unread `s`: free the caching allocator and retry once; skip only on
     a part whose TOTAL memory cannot hold the case (an MI355X has 288 GB), FAIL when a big-enough part is merely full."""

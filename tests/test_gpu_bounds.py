@@ -56,8 +56,8 @@ except hodor_amd.HodorError as e:
 
 
 def _run(code, **env):
-    subprocess.run(["make", "-C", os.path.join(ROOT, "hodor_amd", "csrc"), "bounds"], capture_output=True)   # no-op when current
-    if not os.path.exists(LIB):
+    from conftest import variant_lib
+    if variant_lib("bounds", "libhodor_gpu_bounds.so") is None:
         pytest.skip("libhodor_gpu_bounds.so has not been built (make -C hodor_amd/csrc bounds)")
     if env:      # a run that violates on purpose must not count in the suite's own report (bench/bounds_suite.sh)
         env = dict(env, HODOR_BOUNDS_REPORT="")

@@ -81,10 +81,8 @@ def test_pass_kernel_without_late_kernel_arguments():
     broke the assumption would show up as a difference between the two (round-4 advisor finding)."""
     root = os.path.dirname(HERE)
     lib = os.path.join(root, "hodor_amd", "libhodor_gpu_nolate.so")
-    # always through make (a no-op when the variant is current): a variant left over from an older source tree would lack
-    # newer exports and fail to load — or, worse, load and test yesterday's kernels
-    made = subprocess.run(["make", "-C", os.path.join(root, "hodor_amd", "csrc"), "nolate"], capture_output=True, text=True)
-    assert made.returncode == 0 or os.path.exists(lib), made.stderr[-2000:]
+    from conftest import variant_lib
+    assert variant_lib("nolate", "libhodor_gpu_nolate.so") == lib, "libhodor_gpu_nolate.so is stale and cannot be rebuilt here"
     env = dict(os.environ, HODOR_LIB=lib)
     out = subprocess.run([sys.executable, os.path.join(HERE, "plan_fuzz_worker.py"), "1,5,9,10,13,16,17,20", "16:4:1,13:2:2"],
                          capture_output=True, text=True, timeout=900, env=env)
