@@ -258,6 +258,87 @@ static hipError_t lane_prepare(hodor_ctx::IoLane *L, int which, size_t bytes)
     return hipSuccess;
 }
 
+// ---- pageable caller memory never meets the runtime (ctx.hpp: hodor_ctx::StageRing)
+bool host_is_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime: pageable
+    return at.type == hipMemoryTypeHost;
+}
+
+static hipError_t stage_slot(hodor_ctx::StageRing &R, int slot)   // caller holds R.mu: the slot exists and nobody is using it
+{
+    hipError_t e;
+    if (!R.buf[slot]) {
+        if ((e = pinned_malloc(&R.buf[slot], hodor_ctx::StageRing::CHUNK, hipHostMallocDefault)) != hipSuccess) { R.buf[slot] = nullptr; return e; }
+    }
+    if (!R.ev[slot] && (e = hipEventCreateWithFlags(&R.ev[slot], hipEventDisableTiming)) != hipSuccess) { R.ev[slot] = nullptr; return e; }
+    if (R.recorded[slot]) {
+        if ((e = hipEventSynchronize(R.ev[slot])) != hipSuccess) return e;
+        R.recorded[slot] = false;
+    }
+    return hipSuccess;
+}
+
+hipError_t staged_h2d(hodor_ctx *ctx, hipStream_t stream, void *dev, const void *host, size_t n)
+{
+    hodor_ctx::StageRing &R = ctx->stage_up;
+    constexpr size_t C = hodor_ctx::StageRing::CHUNK;
+    std::lock_guard<std::mutex> lk(R.mu);
+    hipError_t e;
+    size_t i = 0;
+    for (size_t off = 0; off < n; off += C, i++) {
+        const int slot = (int)(i % hodor_ctx::StageRing::K);
+        const size_t len = n - off < C ? n - off : C;
+        if ((e = stage_slot(R, slot)) != hipSuccess) return e;
+        memcpy(R.buf[slot], (const uint8_t *)host + off, len);
+        if ((e = hipMemcpyAsync((uint8_t *)dev + off, R.buf[slot], len, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        if ((e = hipEventRecord(R.ev[slot], stream)) != hipSuccess) return e;
+        R.recorded[slot] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t staged_d2h(hodor_ctx *ctx, hipStream_t stream, void *host, const void *dev, size_t n)
+{
+    hodor_ctx::StageRing &R = ctx->stage_down;
+    constexpr size_t C = hodor_ctx::StageRing::CHUNK;
+    constexpr size_t K = hodor_ctx::StageRing::K;
+    std::lock_guard<std::mutex> lk(R.mu);
+    hipError_t e;
+    const size_t chunks = (n + C - 1) / C;
+    auto collect = [&](size_t j) -> hipError_t {     // chunk j has arrived in its slot: hand it to the caller
+        const int slot = (int)(j % K);
+        hipError_t e2 = hipEventSynchronize(R.ev[slot]);
+        R.recorded[slot] = false;
+        if (e2 != hipSuccess) return e2;
+        const size_t off = j * C, len = n - off < C ? n - off : C;
+        memcpy((uint8_t *)host + off, R.buf[slot], len);
+        return hipSuccess;
+    };
+    for (size_t i = 0; i < chunks; i++) {
+        const int slot = (int)(i % K);
+        if (i >= K && (e = collect(i - K)) != hipSuccess) return e;
+        if ((e = stage_slot(R, slot)) != hipSuccess) return e;
+        const size_t off = i * C, len = n - off < C ? n - off : C;
+        if ((e = hipMemcpyAsync(R.buf[slot], (const uint8_t *)dev + off, len, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipEventRecord(R.ev[slot], stream)) != hipSuccess) return e;
+        R.recorded[slot] = true;
+    }
+    for (size_t j = chunks > K ? chunks - K : 0; j < chunks; j++)
+        if ((e = collect(j)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+static void stage_destroy(hodor_ctx::StageRing &R)
+{
+    for (int i = 0; i < hodor_ctx::StageRing::K; i++) {
+        if (R.ev[i]) (void)hipEventDestroy(R.ev[i]);
+        if (R.buf[i]) (void)hipHostFree(R.buf[i]);
+    }
+}
+
 // The two direction streams of the slice API (ctx.hpp).  Bound to their copy engines here, once: a train of small uploads is
 // put in flight on the upload stream and the download stream's first copy is submitted while they run, so that the
 // runtime finds the upload's engine busy and gives the download another one.
@@ -653,6 +734,8 @@ extern "C" int hodor_ctx_try_destroy(hodor_ctx *ctx)
         if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
         if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        stage_destroy(ctx->stage_up);
+        stage_destroy(ctx->stage_down);
         for (auto &a : ctx->aux_streams)
             if (a) (void)hipStreamDestroy(a);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -723,8 +806,9 @@ extern "C" int hodor_buf_upload(hodor_ctx *ctx, void *dev_dst, const void *host_
         HIPCHK(xfer.finish());
         return HODOR_OK;
     }
-    ctx->h2d_bytes.fetch_add(bytes, std::memory_order_relaxed);
-    HIPCHK(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    HostXfer xfer(ctx, nullptr);   // (counts the bytes; pageable memory goes through the staging ring)
+    HIPCHK(xfer.h2d(dev_dst, host_src, bytes));
+    HIPCHK(xfer.finish());
     return HODOR_OK;
 }
 extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
@@ -735,8 +819,9 @@ extern "C" int hodor_buf_download(hodor_ctx *ctx, void *host_dst, const void *de
         HIPCHK(xfer.d2h(host_dst, dev_src, bytes));
         HIPCHK(xfer.finish());
     } else {
-        ctx->d2h_bytes.fetch_add(bytes, std::memory_order_relaxed);
-        HIPCHK(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+        HostXfer xfer(ctx, nullptr);
+        HIPCHK(xfer.d2h(host_dst, dev_src, bytes));
+        HIPCHK(xfer.finish());
     }
     note_round_trip(ctx);
     return HODOR_OK;
@@ -1204,7 +1289,8 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             if ((e = xfer.h2d(din, in, n_in * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess) return fail(e, "slice upload");
         }
         if (!small_in) ctx->h2d_bytes.fetch_add(n_in * 32, std::memory_order_relaxed);
-        if ((!small_in && (e = hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, us)) != hipSuccess) ||
+        if ((!small_in && (e = host_is_pinned(in) ? hipMemcpyAsync(din, in, n_in * 32, hipMemcpyHostToDevice, us)
+                                                  : staged_h2d(ctx, us, din, in, n_in * 32)) != hipSuccess) ||
             (e = hipEventRecord(L->uploaded, us)) != hipSuccess ||
             (serial && (e = hipStreamSynchronize(us)) != hipSuccess))   // the link is free for the next upload
             return fail(e, "slice upload");
@@ -1235,7 +1321,8 @@ static int with_device_copy(hodor_ctx *ctx, const void *in, size_t n_in, void *o
             if ((e = xfer.d2h(out, dptr_out, n_out * 32)) != hipSuccess || (e = xfer.finish()) != hipSuccess)
                 return fail(e, "slice download");
         } else if ((ctx->d2h_bytes.fetch_add(n_out * 32, std::memory_order_relaxed), false) ||
-                   (e = hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ds)) != hipSuccess ||
+                   (e = host_is_pinned(out) ? hipMemcpyAsync(out, dptr_out, n_out * 32, hipMemcpyDeviceToHost, ds)
+                                            : staged_d2h(ctx, ds, out, dptr_out, n_out * 32)) != hipSuccess ||
                    (e = hipStreamSynchronize(ds)) != hipSuccess)
             return fail(e, "slice download");
         if (trace) tr[6] = slice_trace_us();

@@ -234,6 +234,21 @@ struct hodor_ctx {
     void *pinned = nullptr;
     static constexpr size_t PINNED_BYTES = (size_t)1 << 20;
     std::mutex pinned_mu;
+    // ...and since round 6 the same holds for LARGE transfers: with glibc's dynamic mmap threshold a multi-megabyte vector
+    // lives in the brk heap like any small buffer, its first and last page shared with its neighbours — the abort came back
+    // (same test, same 6 KB torch copy, a heap page) once the suite uploaded many 1-4 MiB numpy arrays through the direct
+    // path.  Pageable caller memory of any size now crosses in chunks through these rings of the library's own pinned
+    // memory (staged_h2d / staged_d2h, abi.hip); only memory the runtime already knows as pinned (hipHostMalloc,
+    // hodor_host_register / hipHostRegister) is handed to a copy directly.
+    struct StageRing {
+        static constexpr int K = 4;
+        static constexpr size_t CHUNK = (size_t)4 << 20;
+        void *buf[K] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[K] = {nullptr, nullptr, nullptr, nullptr};
+        bool recorded[K] = {false, false, false, false};
+        std::mutex mu;
+    };
+    StageRing stage_up, stage_down;
     std::string err;           // written through set_err() only (entry points run concurrently)
     mutable std::mutex err_mu;
 };
@@ -247,11 +262,20 @@ static inline void set_err(hodor_ctx *ctx, const std::string &msg)
 namespace hodor { int bounds_poll(hodor_ctx *ctx); }   // abi_bounds.hip: 1 = new violations (the message is in ctx->err)
 #endif
 
+// abi.hip: is `p` host memory the runtime has pinned (hipHostMalloc / hipHostRegister)?  Only such memory is ever handed
+// to a copy; everything else goes through the context's staging rings, in chunks, copied in / out with memcpy.
+// staged_h2d returns when the caller's bytes have left the caller's memory (the last chunks may still be on their way from
+// the ring to the device, ordered on `stream`); staged_d2h returns when the caller's memory holds the data.
+bool host_is_pinned(const void *p);
+hipError_t staged_h2d(hodor_ctx *ctx, hipStream_t stream, void *dev, const void *host, size_t n);
+hipError_t staged_d2h(hodor_ctx *ctx, hipStream_t stream, void *host, const void *dev, size_t n);
+
 // Small transfers between device and host through the context's own pinned buffer (see hodor_ctx::pinned).  Holds the
 // buffer's mutex for its lifetime; d2h() results are in the caller's memory after finish() (which synchronises `stream`);
 // h2d() copies the caller's bytes into the buffer at once, so stack variables may go out of scope — the buffer itself is
-// not reused before finish().  Transfers that do not fit (> 1 MiB: whole vectors) go straight to / from the caller's
-// memory, which is then an allocation of its own pages and must stay alive until finish().
+// not reused before finish().  Transfers that do not fit (> 1 MiB: whole vectors) go through the staging rings
+// (staged_h2d / staged_d2h) unless the caller's memory is pinned already, in which case it is copied directly and must stay
+// alive until finish().
 class HostXfer {
   public:
     HostXfer(hodor_ctx *c, hipStream_t s) : ctx_(c), stream_(s), lk_(c->pinned_mu) {}
@@ -262,7 +286,10 @@ class HostXfer {
         hipError_t e = room(n);
         if (e != hipSuccess) return e;
         ctx_->d2h_bytes.fetch_add(n, std::memory_order_relaxed);
-        if (n > hodor_ctx::PINNED_BYTES) { pending_ = true; return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream_); }
+        if (n > hodor_ctx::PINNED_BYTES) {
+            pending_ = true;
+            return host_is_pinned(host) ? hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream_) : staged_d2h(ctx_, stream_, host, dev, n);
+        }
         items_.push_back(Item{host, used_, n});
         e = hipMemcpyAsync((uint8_t *)ctx_->pinned + used_, dev, n, hipMemcpyDeviceToHost, stream_);
         used_ += (n + 63) & ~(size_t)63;
@@ -275,7 +302,10 @@ class HostXfer {
         hipError_t e = room(n);
         if (e != hipSuccess) return e;
         ctx_->h2d_bytes.fetch_add(n, std::memory_order_relaxed);
-        if (n > hodor_ctx::PINNED_BYTES) { pending_ = true; return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream_); }
+        if (n > hodor_ctx::PINNED_BYTES) {
+            pending_ = true;
+            return host_is_pinned(host) ? hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream_) : staged_h2d(ctx_, stream_, dev, host, n);
+        }
         memcpy((uint8_t *)ctx_->pinned + used_, host, n);
         e = hipMemcpyAsync(dev, (uint8_t *)ctx_->pinned + used_, n, hipMemcpyHostToDevice, stream_);
         used_ += (n + 63) & ~(size_t)63;

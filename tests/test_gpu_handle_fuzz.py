@@ -457,7 +457,9 @@ SEED0 = int(os.environ.get("HODOR_FUZZ_SEED0", "0"))
 
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + PROGRAMS))
 def test_random_programs_over_live_handles(gpu_ctxs, oracles, field_name, seed):
+    import gc
     ctx, O = gpu_ctxs[field_name], oracles[field_name]
+    gc.collect()                                                      # (handles an earlier test left to the collector)
     live0 = ctx.pool_stats()[1]
     prog = _Program(ctx, O, 1000 * seed + sorted(gpu_ctxs).index(field_name))
     try:
@@ -474,7 +476,9 @@ def test_concurrent_programs_share_one_context(gpu_ctxs, oracles):
     images, one stream — each over its own handles, `trim` and `synchronize` included.  (ctypes drops the GIL for the
     length of every library call, so the calls do interleave.)"""
     import threading
+    import gc
     ctx, O = gpu_ctxs["bn256"], oracles["bn256"]
+    gc.collect()
     live0 = ctx.pool_stats()[1]
     progs = [_Program(ctx, O, 777000 + 10 * SEED0 + t) for t in range(3)]
     errors = []
