@@ -3,6 +3,16 @@ import sys
 
 import pytest
 
+# The tests move their inputs and results with torch (`torch.from_numpy(x).cuda()`, `t.cpu()`) from and to PAGEABLE numpy /
+# torch memory.  For a large pageable copy the HIP runtime pins the caller's pages itself and keeps the pin in a cache; a later
+# small CPU tensor that malloc places inside such a stale range is then copied to DIRECTLY, and when the runtime drops the
+# stale pin under it the GPU loses the mapping: "Memory access fault by GPU ... on address <a heap page>", abort() — seen four
+# times over three rounds, always in the first small `.cpu()` after the multi-megabyte copies of the prover-shaped test
+# (profiles/r06/sigabrt_recurrence.txt).  The library itself hands the runtime no pageable memory (ctx.hpp: staging rings);
+# this keeps torch's copies IN THE TEST PROCESS off the pinning path as well: below this size (MiB) the runtime stages a
+# pageable copy through its own buffers.  Must be set before the HIP runtime is loaded (i.e. before torch is imported).
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
